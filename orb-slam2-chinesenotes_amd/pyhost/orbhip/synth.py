@@ -1,0 +1,81 @@
+"""Seeded synthetic inputs for the ORB front-end.
+
+No dataset can be fetched, so every benchmark / parity input is procedurally generated from a
+counter-based splitmix64 stream: frame i uses seed 0x0B5EED00 + i.  The generator is plain
+numpy (it is input plumbing, not part of the oracle and not part of the measured path).
+"""
+import numpy as np
+
+SEED0 = 0x0B5EED00
+_G = np.uint64(0x9E3779B97F4A7C15)
+_M1 = np.uint64(0xBF58476D1CE4E5B9)
+_M2 = np.uint64(0x94D049BB133111EB)
+
+
+def splitmix64(seed: int, start: int, n: int) -> np.ndarray:
+    """Outputs number start..start+n-1 (0-based) of the splitmix64 stream seeded with `seed`."""
+    with np.errstate(over="ignore"):
+        idx = np.arange(start + 1, start + n + 1, dtype=np.uint64)
+        z = np.uint64(seed & 0xFFFFFFFFFFFFFFFF) + idx * _G
+        z = (z ^ (z >> np.uint64(30))) * _M1
+        z = (z ^ (z >> np.uint64(27))) * _M2
+        return z ^ (z >> np.uint64(31))
+
+
+def synth_frame(index: int, width: int = 640, height: int = 480,
+                n_rect: int = 400, n_disc: int = 200, noise: int = 6) -> np.ndarray:
+    """Mid-grey canvas, n_rect rectangles then n_disc discs (size 4..120 px, grey 0..255, later
+    shapes overwrite earlier ones), then uniform per-pixel noise in [-noise, noise]; u8."""
+    seed = SEED0 + index
+    nshape = 5 * n_rect + 4 * n_disc
+    r = splitmix64(seed, 0, nshape)
+    img = np.full((height, width), 128, dtype=np.int16)
+    p = 0
+    for _ in range(n_rect):
+        x0 = int(r[p] % np.uint64(width)); y0 = int(r[p + 1] % np.uint64(height))
+        w = 4 + int(r[p + 2] % np.uint64(117)); h = 4 + int(r[p + 3] % np.uint64(117))
+        g = int(r[p + 4] % np.uint64(256)); p += 5
+        img[y0:min(height, y0 + h), x0:min(width, x0 + w)] = g
+    for _ in range(n_disc):
+        cx = int(r[p] % np.uint64(width)); cy = int(r[p + 1] % np.uint64(height))
+        rad = 2 + int(r[p + 2] % np.uint64(59)); g = int(r[p + 3] % np.uint64(256)); p += 4
+        xa, xb = max(0, cx - rad), min(width, cx + rad + 1)
+        ya, yb = max(0, cy - rad), min(height, cy + rad + 1)
+        yy, xx = np.mgrid[ya:yb, xa:xb]
+        m = (xx - cx) ** 2 + (yy - cy) ** 2 <= rad * rad
+        img[ya:yb, xa:xb][m] = g
+    if noise > 0:
+        nz = splitmix64(seed, nshape, width * height) % np.uint64(2 * noise + 1)
+        img += nz.astype(np.int16).reshape(height, width) - noise
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def synth_batch(first: int, count: int, width: int = 640, height: int = 480) -> np.ndarray:
+    return np.stack([synth_frame(first + i, width, height) for i in range(count)])
+
+
+def synth_stereo_right(left_index: int, width: int = 1241, height: int = 376, noise: int = 6) -> np.ndarray:
+    """Right image of the C3 pair: the (noise-free) left frame shifted left by the piecewise-constant
+    disparity d(y) = 12 + 8*floor(y/94) px, with fresh noise."""
+    base = synth_frame(left_index, width, height, noise=0).astype(np.int16)
+    out = np.empty_like(base)
+    for y in range(height):
+        d = 12 + 8 * (y // 94)
+        out[y, : width - d] = base[y, d:]
+        out[y, width - d:] = base[y, width - 1]
+    nz = splitmix64(SEED0 + left_index + 0x10000, 0, width * height) % np.uint64(2 * noise + 1)
+    out += nz.astype(np.int16).reshape(height, width) - noise
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
+def synth_vocabulary(seed: int = 0x0B0C0DE) -> np.ndarray:
+    """Stand-in for the absent ORB vocabulary: 10 level-1 + 100 level-2 random 256-bit centroids,
+    (110, 32) u8.  Node id of a descriptor = 11 + 10*c1 + c2 (first-minimum Hamming descent)."""
+    r = splitmix64(seed, 0, 110 * 4)
+    return r.view(np.uint8).reshape(110, 32).copy()
+
+
+def synth_valid_flags(n: int, seed: int, p_num: int = 7, p_den: int = 10) -> np.ndarray:
+    """Bernoulli(p) 'has a good MapPoint' flags for a keyframe's features."""
+    r = splitmix64(0x7A11D000 + seed, 0, n) % np.uint64(p_den)
+    return (r < np.uint64(p_num)).astype(np.uint8)
