@@ -1,0 +1,218 @@
+/* orb_hip.h -- C ABI of the MI355X-native ORB front-end (liborbhip.so).
+ *
+ * This is the drop-in boundary for ONE hot path of ORB-SLAM2 (reference:
+ * Hello-Water/ORB-SLAM2-ChineseNotes): ORBextractor::operator() and the descriptor-matching
+ * core of ORBmatcher.  Plain pointers and sizes only; no C++/torch types.  The C++ shims in
+ * orb-slam2-chinesenotes_amd/host/ keep the reference class signatures and call these entry
+ * points, so Frame.cc / Tracking.cc link unchanged.
+ *
+ * Every entry point cites the reference interface it replaces as file:line relative to the
+ * reference root.  All functions return ORB_OK (0) or a negative orb_status; none aborts.
+ * Handles are thread-compatible: distinct handles may be used concurrently from distinct host
+ * threads (reference src/Frame.cc:82-85 drives two extractors from two threads); one handle
+ * must not be re-entered.  Each handle owns one HIP stream and its scratch buffers.
+ */
+#ifndef ORB_HIP_H
+#define ORB_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum orb_status {
+    ORB_OK = 0,
+    ORB_ERR_INVALID = -1,      /* bad argument                                             */
+    ORB_ERR_HIP = -2,          /* a HIP runtime call failed (see orb_last_error)           */
+    ORB_ERR_NO_DEVICE = -3,    /* no usable gfx950 device: the product has NO CPU fallback */
+    ORB_ERR_CAPACITY = -4,     /* caller buffer too small for the result                   */
+    ORB_ERR_UNSUPPORTED = -5,  /* image/parameter outside the supported envelope           */
+    ORB_ERR_INTERNAL = -6      /* device-side overflow flag raised (never expected)        */
+} orb_status;
+
+/* Same 28-byte layout as cv::KeyPoint {pt.x, pt.y, size, angle, response, octave, class_id}
+ * (what reference src/ORBextractor.cc:1148 appends to _keypoints). */
+typedef struct orb_keypoint {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} orb_keypoint;
+
+/* The five positional arguments of ORBextractor::ORBextractor
+ * (reference include/ORBextractor.h:52-53, src/ORBextractor.cc:498-501). */
+typedef struct orb_extractor_params {
+    int32_t nfeatures;
+    float scale_factor;
+    int32_t nlevels;
+    int32_t ini_th_fast;
+    int32_t min_th_fast;
+} orb_extractor_params;
+
+typedef struct orb_extractor orb_extractor; /* opaque */
+
+#define ORB_MAX_LEVELS 16
+#define ORB_DESC_BYTES 32
+
+/* ---------------------------------------------------------------- life cycle ---------------
+ * replaces: ORBextractor ctor/dtor, reference src/ORBextractor.cc:498-559, include/ORBextractor.h:55. */
+int orb_extractor_create(const orb_extractor_params* params, int device_id, orb_extractor** out);
+void orb_extractor_destroy(orb_extractor* h);
+
+/* replaces the inline getters GetScaleFactors / GetInverseScaleFactors / GetScaleSigmaSquares /
+ * GetInverseScaleSigmaSquares (reference include/ORBextractor.h:64-84) plus mnFeaturesPerLevel
+ * (src/ORBextractor.cc:522-534).  Each array holds nlevels entries; any pointer may be NULL. */
+int orb_extractor_get_tables(const orb_extractor* h, float* scale, float* inv_scale, float* sigma2,
+                             float* inv_sigma2, int32_t* features_per_level);
+
+/* Upper bound on keypoints per frame the handle can return (sum over levels of quota+slack). */
+int orb_extractor_max_keypoints(const orb_extractor* h);
+
+/* Replaces the copy of bit_pattern_31_ into `pattern` (reference src/ORBextractor.cc:537-539).
+ * 512 (x,y) int8 points = 1024 bytes.  A new handle already holds the built-in table; the
+ * batched multi-GPU mode overwrites it on every rank with the table rank 0 broadcast over
+ * RCCL/xGMI.  `_device` takes a device pointer (the broadcast buffer itself). */
+int orb_extractor_set_pattern(orb_extractor* h, const int8_t* pattern_xy_1024);
+int orb_extractor_set_pattern_device(orb_extractor* h, const int8_t* d_pattern_xy_1024);
+/* Copies the built-in table to a caller buffer of 1024 bytes (what rank 0 broadcasts). */
+int orb_builtin_pattern(int8_t* pattern_xy_1024);
+
+/* ---------------------------------------------------------------- extraction ---------------
+ * replaces: ORBextractor::operator()(image, mask, keypoints, descriptors),
+ * reference src/ORBextractor.cc:1084-1150 (mask is ignored there too, include/ORBextractor.h:59).
+ * Host buffers; synchronous.  img: rows x cols u8, `stride` bytes between rows.
+ * kps/desc need room for `cap` entries (orb_extractor_max_keypoints is always enough);
+ * *n receives the count.  An empty image (rows==0 || cols==0 || img==NULL) returns ORB_OK with
+ * *n = 0, like the reference's silent return at :1087-1088. */
+int orb_extract(orb_extractor* h, const uint8_t* img, int rows, int cols, size_t stride,
+                orb_keypoint* kps, uint8_t* desc32, int cap, int* n);
+
+/* Batched-frames mode, host buffers (frames are independent: reference operator() carries no
+ * state across calls except mvImagePyramid, which is overwritten).  Frame f starts at
+ * imgs + f*frame_stride.  kps/desc32 hold n_frames*cap entries; counts[n_frames]. */
+int orb_extract_batch(orb_extractor* h, const uint8_t* imgs, int n_frames, int rows, int cols,
+                      size_t row_stride, size_t frame_stride,
+                      orb_keypoint* kps, uint8_t* desc32, int cap, int32_t* counts);
+
+/* Batched-frames mode, everything resident in HBM; asynchronous on the handle's stream.
+ * d_* are device pointers with the same shapes as above.  Call orb_extractor_sync (or
+ * synchronise the device) before reading results.  Device-side failures (capacity overflow)
+ * are reported by the next orb_extractor_sync. */
+int orb_extract_batch_device(orb_extractor* h, const uint8_t* d_imgs, int n_frames, int rows, int cols,
+                             size_t row_stride, size_t frame_stride,
+                             orb_keypoint* d_kps, uint8_t* d_desc32, int cap, int32_t* d_counts);
+int orb_extractor_sync(orb_extractor* h);
+
+/* replaces reads of the public member mvImagePyramid[level] (reference include/ORBextractor.h:86,
+ * read by src/Frame.cc:520,611,626,633): lazy device->host copy of the interior of one level of
+ * one frame of the last batch (the 19-px border of src/ORBextractor.cc:1168-1174 is not
+ * materialised).  dst may be NULL to query rows/cols only. */
+int orb_get_pyramid_level(orb_extractor* h, int frame, int level, uint8_t* dst, size_t dst_stride,
+                          int* rows, int* cols);
+
+/* Diagnostics for differential tests: per-level keypoint and FAST-candidate counts of one frame
+ * of the last batch (nlevels entries each; either pointer may be NULL). */
+int orb_get_level_counts(orb_extractor* h, int frame, int32_t* kept, int32_t* candidates);
+
+/* Per-stage GPU time of the last batch in milliseconds (HIP events on the handle's stream),
+ * stages: 0 pyramid, 1 FAST cells, 2 quadtree, 3 orientation+descriptors, 4 total.
+ * Profiling must have been enabled before the batch was issued. */
+int orb_extractor_set_profiling(orb_extractor* h, int enable);
+int orb_extractor_get_stage_ms(orb_extractor* h, float* ms5);
+
+/* The HIP stream (hipStream_t) the handle launches on, for callers that need to order their own
+ * device work against it. */
+void* orb_extractor_stream(orb_extractor* h);
+
+/* ---------------------------------------------------------------- matcher ------------------
+ * replaces: static int ORBmatcher::DescriptorDistance(const cv::Mat&, const cv::Mat&),
+ * reference src/ORBmatcher.cc:46-63.  Pure host function on two 32-byte rows. */
+int orb_hamming(const uint8_t* a32, const uint8_t* b32);
+
+/* replaces: ORBmatcher::ComputeThreeMaxima, reference src/ORBmatcher.cc:1663-1707
+ * (counts of the 30 rotation-histogram bins in, three bin indices or -1 out). */
+void orb_three_maxima(const int32_t* counts30, int32_t* ind3);
+
+/* A DBoW2::FeatureVector (std::map<NodeId, std::vector<unsigned>>, reference include/Frame.h:161-162)
+ * flattened to CSR: node_ids ascending, offsets[n_nodes+1], indices ascending within a node. */
+typedef struct orb_featvec {
+    const uint32_t* node_ids;
+    const int32_t* offsets;
+    const int32_t* indices;
+    int32_t n_nodes;
+} orb_featvec;
+
+typedef struct orb_matcher orb_matcher; /* opaque: stream + scratch for the match kernels */
+int orb_matcher_create(int device_id, orb_matcher** out);
+void orb_matcher_destroy(orb_matcher* m);
+int orb_matcher_sync(orb_matcher* m);
+
+/* replaces: int ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&),
+ * reference src/ORBmatcher.cc:552-687.  valid_kf[i] != 0 iff KF feature i has a MapPoint that is
+ * not isBad() (:590-595).  match_f[iF] receives the KF feature index matched to F feature iF or
+ * -1 (the shim maps indices back to MapPoint*).  ratio/check_ori are mfNNratio/mbCheckOrientation.
+ * Host buffers, synchronous.  *nmatches receives the return value of the reference function. */
+int orb_match_bow(orb_matcher* m,
+                  const uint8_t* desc_kf, const float* angle_kf, const uint8_t* valid_kf, int n_kf,
+                  const orb_featvec* fv_kf,
+                  const uint8_t* desc_f, const float* angle_f, int n_f, const orb_featvec* fv_f,
+                  float ratio, int check_ori, int32_t* match_f, int* nmatches);
+
+/* replaces: int ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vector<MapPoint*>&),
+ * reference src/ORBmatcher.cc:690-832 (both sides need valid MapPoints, strict < TH_LOW).
+ * match_12[i1] receives the KF2 feature index or -1. */
+int orb_match_bow_kk(orb_matcher* m,
+                     const uint8_t* desc1, const float* angle1, const uint8_t* valid1, int n1,
+                     const orb_featvec* fv1,
+                     const uint8_t* desc2, const float* angle2, const uint8_t* valid2, int n2,
+                     const orb_featvec* fv2,
+                     float ratio, int check_ori, int32_t* match_12, int* nmatches);
+
+/* replaces: int ORBmatcher::SearchForInitialization(Frame&, Frame&, vector<cv::Point2f>&,
+ * vector<int>&, int windowSize), reference src/ORBmatcher.cc:1055-1180, including the
+ * Frame grid query it makes (src/Frame.cc:243-259, 348-422; 64x48 grid, include/Frame.h:37-38).
+ * kps are the undistorted keypoints (mvKeysUn).  grid4 = {mnMinX, mnMinY,
+ * mfGridElementWidthInv, mfGridElementHeightInv} of frame 2.  prev_xy (n1 x 2 floats) is
+ * vbPrevMatched, updated in place (:1175-1177).  match_12[i1] = index in frame 2 or -1. */
+int orb_match_init(orb_matcher* m,
+                   const orb_keypoint* kps1, const uint8_t* desc1, int n1,
+                   const orb_keypoint* kps2, const uint8_t* desc2, int n2,
+                   const float* grid4, float* prev_xy, int window_size,
+                   float ratio, int check_ori, int32_t* match_12, int* nmatches);
+
+/* Batched device-resident SearchByBoW: pair p matches keyframe kf_index[p] against frame
+ * f_index[p] of a feature store that lives in HBM (the Relocalization candidate loop of
+ * reference src/Tracking.cc:1471-1492 is the batch axis).  See orb_featstore below. */
+typedef struct orb_featstore {
+    /* all device pointers; frame f owns rows [f*cap, (f+1)*cap) */
+    const uint8_t* desc;        /* [n_frames*cap][32]                       */
+    const orb_keypoint* kps;    /* [n_frames*cap] (angle read from here)    */
+    const uint8_t* valid;       /* [n_frames*cap] or NULL (= all valid)     */
+    const int32_t* counts;      /* [n_frames]                               */
+    const uint16_t* node_of;    /* [n_frames*cap] vocabulary node per feature */
+    int32_t cap;
+    int32_t n_frames;
+} orb_featstore;
+
+/* Vocabulary stand-in (DBoW2 transform(...,4) of reference src/Frame.cc:431 is
+ * OUT OF SCOPE this round): 2-level k=10 tree, centroids = 110 x 32 bytes (device pointer).
+ * Fills node_of[f*cap + i] = 11 + 10*c1 + c2 for every feature of every frame. */
+int orb_bow_assign_device(orb_matcher* m, const uint8_t* d_desc, const int32_t* d_counts, int n_frames,
+                          int cap, const uint8_t* d_centroids_110x32, uint16_t* d_node_of);
+
+/* d_match: [n_pairs][cap] int32 (F-feature -> KF-feature or -1); d_nmatches: [n_pairs].
+ * Asynchronous on the matcher's stream. */
+int orb_match_bow_batch_device(orb_matcher* m, const orb_featstore* store,
+                               const int32_t* d_kf_index, const int32_t* d_f_index, int n_pairs,
+                               float ratio, int check_ori, int32_t* d_match, int32_t* d_nmatches);
+
+void* orb_matcher_stream(orb_matcher* m);
+
+/* ---------------------------------------------------------------- misc ---------------------*/
+const char* orb_last_error(void);   /* thread-local description of the last failure */
+const char* orb_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORB_HIP_H */

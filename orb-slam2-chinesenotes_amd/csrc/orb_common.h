@@ -1,0 +1,58 @@
+// orb_common.h -- shared declarations of the HIP implementation behind include/orb_hip.h.
+// gfx950 only.  There is deliberately NO CPU fallback in this library: if no device is usable
+// every entry point fails with ORB_ERR_NO_DEVICE / ORB_ERR_HIP.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/orb_hip.h"
+
+void orb_set_error(const char* fmt, ...);
+
+#define ORB_HIP_TRY(expr)                                                                  \
+    do {                                                                                   \
+        hipError_t e__ = (expr);                                                           \
+        if (e__ != hipSuccess) {                                                           \
+            orb_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e__)); \
+            return ORB_ERR_HIP;                                                            \
+        }                                                                                  \
+    } while (0)
+
+// ---- geometry of one pyramid level, shared by host set-up code and all kernels ----
+struct OrbLevelGeom {
+    int w, h, pitch;            // image size and row pitch (bytes, multiple of 64)
+    int pyrOff;                 // byte offset of the level inside one frame's pyramid slab
+    int nCols, nRows, wCell, hCell;   // FAST cell grid (reference src/ORBextractor.cc:820-823)
+    int candBase, candCap;      // key slots inside one frame's candidate slab
+    int quota;                  // mnFeaturesPerLevel[level]
+    int kpBase, kpCap;          // slots inside one frame's per-level keypoint list
+    int nIni;                   // quadtree roots (reference :567)
+    float hX;                   // root width (reference :568)
+    int boxW, boxH;             // maxX-minX, maxY-minY
+    float scale;                // mvScaleFactor[level]
+    float sizeField;            // (float)(int)(31*scale)
+};
+
+struct OrbGeom {
+    int nlevels;
+    int kpSlab;                 // sum of kpCap
+    unsigned long long umaxPacked;  // umax[v] in nibble v (values <= 15), reference :544-558
+    OrbLevelGeom L[ORB_MAX_LEVELS];
+};
+
+struct OrbCell {                // one FAST cell ROI (reference :826-861), 12 bytes
+    short x0, y0, w, h;         // ROI inside the level image
+    unsigned char level, ci, cj, pad;
+};
+
+// Candidate key layout (64 bit), sorted ascending by the quadtree kernel:
+//   [61:58] quadtree root   [57:34] 12 x 2-bit quadrant path (depth 0 in the top bits)
+//   [33:27] cell row  [26:20] cell col  [19:14] y in ROI  [13:8] x in ROI   [7:0] FAST score
+// (cell row, cell col, y, x) ascending == the order in which the reference appends candidates
+// (src/ORBextractor.cc:826-871), so ties resolve exactly as its "first maximum wins" scan.
+#define ORB_KEY_ROOT_SHIFT 58
+#define ORB_KEY_PATH_SHIFT 34
+#define ORB_KEY_PATH_LEVELS 12

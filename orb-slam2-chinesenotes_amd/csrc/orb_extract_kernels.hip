@@ -1,0 +1,683 @@
+// orb_extract_kernels.hip -- gfx950 kernels of the ORB extractor (wave64, LDS-tiled, no MFMA:
+// this is integer/bitwise stencil + gather work bounded by HBM/LDS, not a dense contraction).
+//
+// Stage map (reference src/ORBextractor.cc):
+//   k_copy_level0 / k_resize_level   ComputePyramid            :1153-1180  (cv::resize INTER_LINEAR)
+//   k_fast_cells                     per-cell cv::FAST + fallback + NMS :795-875
+//   k_quadtree                       DistributeOctTree / DivideNode      :436-495, :562-792
+//   k_orient_desc                    IC_Angle, GaussianBlur, computeOrbDescriptor, operator() tail
+//                                    :78-171, :1118-1148
+// Every kernel takes blockIdx.y (or .z) = frame: batched frames are independent.
+#include "orb_kernels.h"
+
+#pragma clang fp contract(off)
+
+#include "../../include/orb_sincos.h"
+
+#define WAVE 64
+
+// ------------------------------------------------------------------------------------------------
+// Level 0: copy of the input into the pitch-aligned pyramid slab (reference :1173 copies the image
+// into its bordered buffer).  One thread per 16 output bytes.
+__global__ __launch_bounds__(256) void k_copy_level0(const uint8_t* __restrict__ src, size_t rowStride,
+                                                     size_t frameStride, uint8_t* __restrict__ pyr,
+                                                     size_t pyrSlab, int w, int h, int pitch, int vec16)
+{
+    const int x16 = blockIdx.x * blockDim.x + threadIdx.x;   // 16-byte column
+    const int y = blockIdx.y;
+    const int f = blockIdx.z;
+    if (x16 * 16 >= w) return;
+    const uint8_t* s = src + (size_t)f * frameStride + (size_t)y * rowStride + (size_t)x16 * 16;
+    uint8_t* d = pyr + (size_t)f * pyrSlab + (size_t)y * pitch + (size_t)x16 * 16;
+    if (vec16 && x16 * 16 + 16 <= w) {
+        *reinterpret_cast<uint4*>(d) = *reinterpret_cast<const uint4*>(s);
+    } else {
+        const int n = min(16, w - x16 * 16);
+        for (int i = 0; i < n; i++) d[i] = s[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// cv::resize(INTER_LINEAR, 8UC1) of level l-1 into level l, fixed point exactly as OpenCV's
+// HResizeLinear/VResizeLinear.  One thread -> 4 horizontally adjacent output pixels.
+// xtab[dx] = {sx, a0 | a1<<16}; ytab[dy] = {sy0 | sy1<<16, b0 | b1<<16} (built on the host).
+__global__ __launch_bounds__(256) void k_resize_level(uint8_t* __restrict__ pyr, size_t pyrSlab,
+                                                      int srcOff, int srcPitch, int dstOff, int dstPitch,
+                                                      int dw, int dh, const int2* __restrict__ xtab,
+                                                      const int2* __restrict__ ytab)
+{
+    const int x4 = blockIdx.x * 64 + threadIdx.x;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    const int f = blockIdx.z;
+    if (x4 * 4 >= dw || y >= dh) return;
+    const uint8_t* src = pyr + (size_t)f * pyrSlab + srcOff;
+    uint8_t* dst = pyr + (size_t)f * pyrSlab + dstOff;
+    const int2 ty = ytab[y];
+    const uint8_t* r0 = src + (size_t)(ty.x & 0xffff) * srcPitch;
+    const uint8_t* r1 = src + (size_t)(ty.x >> 16) * srcPitch;
+    const int b0 = (short)(ty.y & 0xffff), b1 = (short)(ty.y >> 16);
+    uint32_t out = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int x = x4 * 4 + i;
+        if (x < dw) {
+            const int2 tx = xtab[x];
+            const int sx = tx.x;
+            const int a0 = (short)(tx.y & 0xffff), a1 = (short)(tx.y >> 16);
+            const int sx1 = sx + (a1 != 0);           // a1 == 0 whenever sx+1 would be out of range
+            const int h0 = r0[sx] * a0 + r0[sx1] * a1;
+            const int h1 = r1[sx] * a0 + r1[sx1] * a1;
+            const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            out |= (uint32_t)(v & 0xff) << (8 * i);
+        }
+    }
+    *reinterpret_cast<uint32_t*>(dst + (size_t)y * dstPitch + (size_t)x4 * 4) = out;
+}
+
+// ------------------------------------------------------------------------------------------------
+// FAST-9/16 score V(p) = max over the 16 contiguous 9-arcs of min(+-(centre - ring)).
+// p points into an LDS byte tile with pitch P.  Result may be <= 0 (never a corner then).
+__device__ __forceinline__ int fast_score_v(const uint8_t* p, const int P)
+{
+    const int c = p[0];
+    int d[16];
+    d[0] = c - p[3 * P];        d[1] = c - p[3 * P + 1];   d[2] = c - p[2 * P + 2];   d[3] = c - p[P + 3];
+    d[4] = c - p[3];            d[5] = c - p[-P + 3];      d[6] = c - p[-2 * P + 2];  d[7] = c - p[-3 * P + 1];
+    d[8] = c - p[-3 * P];       d[9] = c - p[-3 * P - 1];  d[10] = c - p[-2 * P - 2]; d[11] = c - p[-P - 3];
+    d[12] = c - p[-3];          d[13] = c - p[P - 3];      d[14] = c - p[2 * P - 2];  d[15] = c - p[3 * P - 1];
+    int lo3[16], hi3[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        lo3[k] = min(min(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
+        hi3[k] = max(max(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
+    }
+    int a = -256, b = 256;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int lo9 = min(min(lo3[k], lo3[(k + 3) & 15]), lo3[(k + 6) & 15]);
+        const int hi9 = max(max(hi3[k], hi3[(k + 3) & 15]), hi3[(k + 6) & 15]);
+        a = max(a, lo9);
+        b = min(b, hi9);
+    }
+    return max(a, -b);
+}
+
+// quadrant path of a candidate inside the quadtree of reference DistributeOctTree/DivideNode
+// (:436-495, :567-593): root index + 12 two-bit digits (0 = n1 UL, 1 = n2 UR, 2 = n3 BL, 3 = n4 BR).
+__device__ __forceinline__ unsigned long long quadtree_path(int x, int y, const OrbLevelGeom& L)
+{
+    const int root = (int)((float)x / L.hX);                       // vpIniNodes[kp.pt.x/hX]  (:593)
+    int ulx = (int)(L.hX * (float)root), urx = (int)(L.hX * (float)(root + 1));   // (:578-579)
+    int uly = 0, bry = L.boxH;
+    unsigned path = 0;
+#pragma unroll
+    for (int d = 0; d < ORB_KEY_PATH_LEVELS; d++) {
+        const int midx = ulx + ((urx - ulx + 1) >> 1);            // UL.x + ceil((UR.x-UL.x)/2)
+        const int midy = uly + ((bry - uly + 1) >> 1);
+        const int right = !(x < midx), down = !(y < midy);
+        path = (path << 2) | (unsigned)(right + 2 * down);
+        if (right) ulx = midx; else urx = midx;
+        if (down) uly = midy; else bry = midy;
+    }
+    return ((unsigned long long)root << ORB_KEY_ROOT_SHIFT) | ((unsigned long long)path << ORB_KEY_PATH_SHIFT);
+}
+
+// One wave64 per FAST cell.  The cell ROI (<= 66x66 px) is staged in LDS with aligned dword loads,
+// V is computed for the whole detection zone, the iniTh -> minTh fallback is decided with a wave
+// ballot count, NMS is cell-local (neighbours outside the zone score 0), survivors are appended to
+// the (frame, level) candidate list with ONE atomic per cell.
+#define FAST_TP 72            // tile pitch in bytes (66 + 3 alignment slack -> 72)
+#define FAST_TH 66            // max ROI rows
+#define FAST_SP 64            // score-map pitch (zone width <= 60, +2 border)
+__global__ __launch_bounds__(WAVE) void k_fast_cells(const OrbGeom G, const uint8_t* __restrict__ pyr,
+                                                     size_t pyrSlab, const OrbCell* __restrict__ cells,
+                                                     unsigned long long* __restrict__ cand, size_t candSlab,
+                                                     int* __restrict__ candCount, int* __restrict__ errFlags,
+                                                     int iniTh, int minTh)
+{
+    __shared__ uint32_t tileDw[FAST_TH * FAST_TP / 4];
+    __shared__ uint8_t smap[(FAST_TH - 6 + 2) * FAST_SP];
+    const int lane = threadIdx.x;
+    const int f = blockIdx.y;
+    const OrbCell cell = cells[blockIdx.x];
+    const OrbLevelGeom& L = G.L[cell.level];
+    const uint8_t* img = pyr + (size_t)f * pyrSlab + L.pyrOff;
+
+    // ---- stage the ROI: aligned dwords, rows [y0, y0+h)
+    const int xa = cell.x0 & ~3, xoff = cell.x0 - xa;
+    const int ndw = (xoff + cell.w + 3) >> 2;                      // <= 18
+    const unsigned inv = ((1u << 20) + ndw - 1) / ndw;
+    for (int idx = lane; idx < ndw * cell.h; idx += WAVE) {
+        const int r = (int)(((unsigned)idx * inv) >> 20);
+        const int c = idx - r * ndw;
+        tileDw[r * (FAST_TP / 4) + c] =
+            *reinterpret_cast<const uint32_t*>(img + (size_t)(cell.y0 + r) * L.pitch + xa + 4 * c);
+    }
+    const int zw = cell.w - 6, zh = cell.h - 6;                    // detection zone
+    for (int idx = lane; idx < (zh + 2) * (FAST_SP / 4); idx += WAVE)
+        reinterpret_cast<uint32_t*>(smap)[idx] = 0;
+    __syncthreads();
+
+    // ---- V for every zone pixel; count corners at iniTh
+    const uint8_t* tile = reinterpret_cast<const uint8_t*>(tileDw);
+    const int npx = zw * zh;
+    const unsigned invz = ((1u << 20) + zw - 1) / zw;
+    int nIni = 0;
+    for (int base = 0; base < npx; base += WAVE) {
+        const int idx = base + lane;
+        int S = 0;
+        if (idx < npx) {
+            const int py = (int)(((unsigned)idx * invz) >> 20);
+            const int px = idx - py * zw;
+            S = max(fast_score_v(tile + (py + 3) * FAST_TP + xoff + px + 3, FAST_TP), 0);
+            smap[(py + 1) * FAST_SP + px + 1] = (uint8_t)S;
+        }
+        nIni += __popcll(__ballot(S > iniTh));
+    }
+    const int th = (nIni > 0) ? iniTh : minTh;                     // reference :857-861
+    __syncthreads();
+
+    // ---- cell-local 3x3 strict NMS on score = (V > th) ? V-1 : 0
+    unsigned long long keep = 0;
+    int total = 0, it = 0;
+    for (int base = 0; base < npx; base += WAVE, it++) {
+        const int idx = base + lane;
+        bool k = false;
+        if (idx < npx) {
+            const int py = (int)(((unsigned)idx * invz) >> 20);
+            const int px = idx - py * zw;
+            const uint8_t* s = smap + (py + 1) * FAST_SP + px + 1;
+            const int S = s[0];
+            if (S > th) {
+                const int sc = S - 1;
+                int m = 0;
+#define NB(o) { const int v = s[o]; m = max(m, v > th ? v - 1 : 0); }
+                NB(-1) NB(1) NB(-FAST_SP - 1) NB(-FAST_SP) NB(-FAST_SP + 1) NB(FAST_SP - 1) NB(FAST_SP) NB(FAST_SP + 1)
+#undef NB
+                k = sc > m;
+            }
+        }
+        if (k) keep |= 1ull << it;
+        total += __popcll(__ballot(k));
+    }
+    if (total == 0) return;
+
+    int base0 = 0;
+    if (lane == 0) base0 = atomicAdd(&candCount[f * ORB_MAX_LEVELS + cell.level], total);
+    base0 = __shfl(base0, 0);
+    if (base0 + total > L.candCap) {                               // cannot happen: candCap is the NMS bound
+        if (lane == 0) atomicOr(&errFlags[f], 1);
+        return;
+    }
+    unsigned long long* out = cand + (size_t)f * candSlab + L.candBase + base0;
+    int run = 0;
+    it = 0;
+    for (int base = 0; base < npx; base += WAVE, it++) {
+        const bool k = (keep >> it) & 1;
+        const unsigned long long b = __ballot(k);
+        if (k) {
+            const int idx = base + lane;
+            const int py = (int)(((unsigned)idx * invz) >> 20);
+            const int px = idx - py * zw;
+            const int xin = px + 3, yin = py + 3;                 // cv::FAST keypoint coords in the ROI
+            const int S = smap[(py + 1) * FAST_SP + px + 1];
+            const int cx = xin + cell.cj * L.wCell, cy = yin + cell.ci * L.hCell;   // :868-869
+            unsigned long long key = quadtree_path(cx, cy, L);
+            key |= ((unsigned long long)cell.ci << 27) | ((unsigned long long)cell.cj << 20) |
+                   ((unsigned long long)yin << 14) | ((unsigned long long)xin << 8) | (unsigned long long)(S - 1);
+            out[run + __popcll(b & ((1ull << lane) - 1))] = key;
+        }
+        run += __popcll(b);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Quadtree keypoint distribution.  One 256-thread workgroup per (frame, level).
+//
+// The reference splits std::list nodes and copies key vectors (:436-495).  Here every candidate
+// carries its quadrant path, so after ONE sort by key every node of the tree -- at any depth --
+// is a contiguous range [lo,hi) of the sorted array and DivideNode is three binary searches on a
+// 2-bit digit.  The list evolution itself (push_front order, erase, the "expand the largest nodes
+// first" phase with its (size, creation-order) tie-break) is replayed exactly by one
+// thread on {lo,hi,depth} triples; the sort and the final per-node arg-max run on all threads.
+struct QtNode {
+    int lo, hi;
+    short depth;
+    short dead;
+    int seq;
+};
+
+__device__ __forceinline__ unsigned key_digit(unsigned long long k, int depth)
+{
+    return (unsigned)(k >> (ORB_KEY_PATH_SHIFT + 2 * (ORB_KEY_PATH_LEVELS - 1 - depth))) & 3u;
+}
+
+// first index in [lo,hi) whose digit at `depth` is >= q
+__device__ int lower_digit(const unsigned long long* keys, int lo, int hi, int depth, unsigned q)
+{
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (key_digit(keys[mid], depth) < q) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// ascending bitonic sort of a[0..n) for arbitrary n (all merges ascending, virtual +inf padding)
+__device__ void block_sort_u64(unsigned long long* a, int n)
+{
+    int np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    for (int k = 2; k <= np2; k <<= 1) {
+        for (int i = threadIdx.x; i < np2; i += blockDim.x) {
+            const int p = i ^ (k - 1);
+            if (p > i && p < n) {
+                const unsigned long long x = a[i], y = a[p];
+                if (x > y) { a[i] = y; a[p] = x; }
+            }
+        }
+        __syncthreads();
+        for (int j = k >> 2; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < np2; i += blockDim.x) {
+                const int p = i ^ j;
+                if (p > i && p < n) {
+                    const unsigned long long x = a[i], y = a[p];
+                    if (x > y) { a[i] = y; a[p] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// Divide node `nd` (reference DivideNode): append its non-empty children to S, register the
+// multi-key ones in `prev` as (size<<48 | seq<<24 | S-index).  Returns number of non-empty children.
+__device__ int qt_divide(const unsigned long long* keys, const QtNode nd, QtNode* S, int& sCount,
+                         unsigned long long* prev, int& prevCount, int& seq, int& nExpand)
+{
+    int cut[5];
+    cut[0] = nd.lo;
+    cut[4] = nd.hi;
+    if (nd.depth >= ORB_KEY_PATH_LEVELS) {        // unreachable inside the supported image envelope
+        cut[1] = cut[2] = cut[3] = nd.hi;
+    } else {
+        cut[2] = lower_digit(keys, nd.lo, nd.hi, nd.depth, 2);
+        cut[1] = lower_digit(keys, nd.lo, cut[2], nd.depth, 1);
+        cut[3] = lower_digit(keys, cut[2], nd.hi, nd.depth, 3);
+    }
+    int made = 0;
+    for (int q = 0; q < 4; q++) {
+        const int a = cut[q], b = cut[q + 1];
+        if (b <= a) continue;
+        QtNode c;
+        c.lo = a; c.hi = b; c.depth = (short)(nd.depth + 1); c.dead = 0; c.seq = seq++;
+        if (b - a > 1) {
+            nExpand++;
+            prev[prevCount++] = ((unsigned long long)(b - a) << 48) | ((unsigned long long)c.seq << 24) |
+                                (unsigned long long)sCount;
+        }
+        S[sCount++] = c;
+        made++;
+    }
+    return made;
+}
+
+__global__ __launch_bounds__(256) void k_quadtree(const OrbGeom G, unsigned long long* __restrict__ cand,
+                                                  size_t candSlab, const int* __restrict__ candCount,
+                                                  uint32_t* __restrict__ kpl, int* __restrict__ kpCount,
+                                                  int* __restrict__ errFlags, int sortCap, int nodeCap)
+{
+    extern __shared__ unsigned long long qsm[];
+    // LDS carve-up: keys[sortCap] | prev[nodeCap] | A[nodeCap] | B[nodeCap] | S[nodeCap]
+    unsigned long long* ldsKeys = qsm;
+    unsigned long long* prev = qsm + sortCap;
+    QtNode* A = reinterpret_cast<QtNode*>(prev + nodeCap);
+    QtNode* B = A + nodeCap;
+    QtNode* S = B + nodeCap;
+    __shared__ int sh_size, sh_prevCount, sh_state, sh_sCount;   // state: 0 main, 1 careful, 2 done
+    __shared__ int sh_listInB;
+
+    const int level = blockIdx.x, f = blockIdx.y;
+    const OrbLevelGeom& L = G.L[level];
+    const int tid = threadIdx.x;
+    int n = candCount[f * ORB_MAX_LEVELS + level];
+    if (n > L.candCap) n = L.candCap;
+    int* outCount = &kpCount[f * ORB_MAX_LEVELS + level];
+    if (n == 0) {
+        if (tid == 0) *outCount = 0;
+        return;
+    }
+    unsigned long long* gk = cand + (size_t)f * candSlab + L.candBase;
+    unsigned long long* keys;
+    if (n <= sortCap) {
+        for (int i = tid; i < n; i += blockDim.x) ldsKeys[i] = gk[i];
+        keys = ldsKeys;
+    } else {
+        keys = gk;                                   // rare: sort in place in global memory (L2)
+    }
+    __syncthreads();
+    block_sort_u64(keys, n);
+
+    const int N = L.quota;
+    // ---- roots (reference :575-612)
+    if (tid == 0) {
+        int cnt = 0, seq = 0;
+        int lo = 0;
+        for (int r = 0; r < L.nIni; r++) {
+            int a = lo, b = n;                      // first key with root > r
+            while (a < b) {
+                const int mid = (a + b) >> 1;
+                if ((int)(keys[mid] >> ORB_KEY_ROOT_SHIFT) <= r) a = mid + 1; else b = mid;
+            }
+            if (a > lo) {
+                QtNode nd;
+                nd.lo = lo; nd.hi = a; nd.depth = 0; nd.dead = 0; nd.seq = seq++;
+                A[cnt++] = nd;
+            }
+            lo = a;
+        }
+        sh_size = cnt;
+        sh_state = 0;
+        sh_listInB = 0;
+        sh_prevCount = 0;
+    }
+    __syncthreads();
+
+    int seq = L.nIni;                                // only thread 0's copy is used
+    while (true) {
+        const int state = sh_state;
+        if (state == 2) break;
+        QtNode* cur = sh_listInB ? B : A;
+        QtNode* nxt = sh_listInB ? A : B;
+        __syncthreads();                             // everyone has read the loop state before thread 0 rewrites it
+        if (state == 1) {                            // sort (size, seq) ascending (:711 with A.6 tie-break)
+            block_sort_u64(prev, sh_prevCount);
+        }
+        if (tid == 0) {
+            const int size0 = sh_size;
+            int size = size0, sCount = 0, newPrev = 0, nExpand = 0;
+            if (state == 0) {
+                // one full pass over the list (:631-691)
+                int prevCount = 0;
+                for (int i = 0; i < size0; i++) {
+                    const QtNode nd = cur[i];
+                    if (nd.hi - nd.lo == 1) continue;               // bNoMore
+                    const int made = qt_divide(keys, nd, S, sCount, prev, prevCount, seq, nExpand);
+                    cur[i].dead = 1;
+                    size += made - 1;
+                }
+                newPrev = prevCount;
+            } else {
+                // careful phase: largest first, stop as soon as size >= N (:703-765)
+                const int pc = sh_prevCount;
+                // prev[] is consumed from the back while new entries are appended from index 0 of
+                // a second region: reuse S-index space by writing new entries into prev after the
+                // loop; keep them in a small register-free way: stage in nxt (not yet used).
+                unsigned long long* stage = reinterpret_cast<unsigned long long*>(nxt);
+                for (int j = pc - 1; j >= 0; j--) {
+                    const int idx = (int)(prev[j] & 0xFFFFFF);
+                    const QtNode nd = cur[idx];
+                    const int made = qt_divide(keys, nd, S, sCount, stage, newPrev, seq, nExpand);
+                    cur[idx].dead = 1;
+                    size += made - 1;
+                    if (size >= N) break;
+                }
+                for (int j = 0; j < newPrev; j++) prev[j] = stage[j];
+            }
+            // rebuild: new list = reverse(S) ++ (cur minus dead)
+            int m = 0;
+            for (int j = sCount - 1; j >= 0; j--) nxt[m++] = S[j];
+            for (int i = 0; i < size0; i++)
+                if (!cur[i].dead) nxt[m++] = cur[i];
+            // S-index j now sits at list position sCount-1-j
+            for (int j = 0; j < newPrev; j++) {
+                const unsigned long long e = prev[j];
+                prev[j] = (e & ~0xFFFFFFull) | (unsigned long long)(sCount - 1 - (int)(e & 0xFFFFFF));
+            }
+            sh_size = size;
+            sh_prevCount = newPrev;
+            sh_listInB ^= 1;
+            sh_sCount = sCount;
+            if (size >= N || size == size0) sh_state = 2;
+            else if (state == 0 && size + 3 * nExpand > N) sh_state = 1;
+        }
+        __syncthreads();
+    }
+
+    // ---- keep the best key of every node, in list order (:770-789)
+    const QtNode* fin = sh_listInB ? B : A;
+    const int size = sh_size;
+    if (size > L.kpCap) {
+        if (tid == 0) { atomicOr(&errFlags[f], 2); *outCount = 0; }
+        return;
+    }
+    uint32_t* out = kpl + (size_t)f * G.kpSlab + L.kpBase;
+    for (int i = tid; i < size; i += blockDim.x) {
+        const QtNode nd = fin[i];
+        unsigned long long bestKey = 0;
+        for (int k = nd.lo; k < nd.hi; k++) {
+            // max response; among equals the candidate the reference appended first: smallest (ci,cj,y,x)
+            const unsigned long long key = keys[k];
+            const unsigned resp = (unsigned)(key & 0xFF), ord = (unsigned)(key >> 8) & 0x3FFFFFFu;
+            const unsigned bresp = (unsigned)(bestKey & 0xFF), bord = (unsigned)(bestKey >> 8) & 0x3FFFFFFu;
+            if (k == nd.lo || resp > bresp || (resp == bresp && ord < bord)) bestKey = key;
+        }
+        const int ci = (int)(bestKey >> 27) & 0x7F, cj = (int)(bestKey >> 20) & 0x7F;
+        const int yin = (int)(bestKey >> 14) & 0x3F, xin = (int)(bestKey >> 8) & 0x3F;
+        const int x = xin + cj * L.wCell + 16, y = yin + ci * L.hCell + 16;     // + minBorder (:892-893)
+        out[i] = ((uint32_t)x << 20) | ((uint32_t)y << 8) | (uint32_t)(bestKey & 0xFF);
+    }
+    if (tid == 0) *outCount = size;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Orientation + steered BRIEF, fused per keypoint.  One wave64 per keypoint slot.
+// The 43x43 source patch (radius 15 for IC_Angle, 18 for the pattern, +3 for the 7-tap blur) is
+// staged in LDS with BORDER_REFLECT_101 resolved at load time; the horizontal blur pass is done
+// once for the patch (u16, max 255*257 fits), the vertical pass only at the 512 sampled points.
+// The blurred level is never written to HBM.
+#define PR 21
+#define PW 43
+#define PP 44
+#define HW 37
+__device__ __forceinline__ int reflect101(int i, int n)
+{
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * n - 2 - i;
+    return i;
+}
+
+__device__ __forceinline__ float fast_atan2_deg(float y, float x)
+{
+    // cv::fastAtan2; constants are the float products p_k * (float)(180/pi)
+    const float p1 = __uint_as_float(0x4265226fu), p3 = __uint_as_float(0xc19556eeu);
+    const float p5 = __uint_as_float(0x410e9fbfu), p7 = __uint_as_float(0xc0228ad9u);
+    const float eps = 2.2204460492503131e-16f;
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = __fdiv_rn(ay, __fadd_rn(ax, eps));
+        c2 = __fmul_rn(c, c);
+        a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+    } else {
+        c = __fdiv_rn(ax, __fadd_rn(ay, eps));
+        c2 = __fmul_rn(c, c);
+        a = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
+    }
+    if (x < 0) a = __fsub_rn(180.f, a);
+    if (y < 0) a = __fsub_rn(360.f, a);
+    return a;
+}
+
+__device__ __forceinline__ int wave_sum(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ __launch_bounds__(WAVE) void k_orient_desc(const OrbGeom G, const uint8_t* __restrict__ pyr,
+                                                      size_t pyrSlab, const uint32_t* __restrict__ kpl,
+                                                      const int* __restrict__ kpCount,
+                                                      const int8_t* __restrict__ pattern,
+                                                      orb_keypoint* __restrict__ kpsOut,
+                                                      uint8_t* __restrict__ descOut, int cap,
+                                                      int32_t* __restrict__ countsOut, int* __restrict__ errFlags)
+{
+    __shared__ uint8_t P[PW * PP];
+    __shared__ uint16_t H[PW * (HW + 1)];
+    const int lane = threadIdx.x;
+    const int slot = blockIdx.x, f = blockIdx.y;
+    int level = 0;
+    while (level + 1 < G.nlevels && slot >= G.L[level + 1].kpBase) level++;
+    const OrbLevelGeom& L = G.L[level];
+    const int k = slot - L.kpBase;
+    const int* cnt = kpCount + f * ORB_MAX_LEVELS;
+    int off = 0;
+    for (int l = 0; l < level; l++) off += cnt[l];
+    if (slot == 0) {
+        int tot = 0;
+        for (int l = 0; l < G.nlevels; l++) tot += cnt[l];
+        if (lane == 0) {
+            countsOut[f] = min(tot, cap);
+            if (tot > cap) atomicOr(&errFlags[f], 4);
+        }
+    }
+    if (k >= cnt[level] || off + k >= cap) return;
+
+    const uint32_t packed = kpl[(size_t)f * G.kpSlab + slot];
+    const int x0 = (int)(packed >> 20), y0 = (int)(packed >> 8) & 0xFFF;
+    const int resp = (int)(packed & 0xFF);
+    const uint8_t* img = pyr + (size_t)f * pyrSlab + L.pyrOff;
+
+    // ---- stage the patch (lanes over columns)
+    if (lane < PW) {
+        const int gx = reflect101(x0 - PR + lane, L.w);
+        for (int r = 0; r < PW; r++) {
+            const int gy = reflect101(y0 - PR + r, L.h);
+            P[r * PP + lane] = img[(size_t)gy * L.pitch + gx];
+        }
+    }
+    __syncthreads();
+
+    // ---- IC_Angle (:78-105): lane v handles patch row v-15
+    int m10 = 0, m01 = 0;
+    if (lane < 31) {
+        const int v = lane - 15;
+        const int d = (int)(G.umaxPacked >> (4 * (v < 0 ? -v : v))) & 15;
+        const uint8_t* row = P + (PR + v) * PP + PR;
+        int s0 = 0, s1 = 0;
+        for (int u = -d; u <= d; u++) {
+            const int val = row[u];
+            s0 += val;
+            s1 += u * val;
+        }
+        m10 = s1;
+        m01 = v * s0;
+    }
+    m10 = wave_sum(m10);
+    m01 = wave_sum(m01);
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+
+    // ---- horizontal 7-tap pass (8.8 fixed point taps 18,34,49,55,49,34,18)
+    for (int idx = lane; idx < PW * HW; idx += WAVE) {
+        const int r = idx / HW, c = idx - r * HW;
+        const uint8_t* s = P + r * PP + c;
+        const int acc = 18 * (s[0] + s[6]) + 34 * (s[1] + s[5]) + 49 * (s[2] + s[4]) + 55 * s[3];
+        H[r * (HW + 1) + c] = (uint16_t)acc;
+    }
+    __syncthreads();
+
+    // ---- steered BRIEF (:120-161): lane handles pairs lane, lane+64, lane+128, lane+192
+    const float rad = __fmul_rn(angle, __uint_as_float(0x3c8efa35u));       // (float)(CV_PI/180.f)
+    float a, b;
+    orb_sincos(rad, &a, &b);
+    // blurred sample at pattern point (px,py) rotated by the keypoint angle (GET_VALUE, :132-134)
+    auto sample = [&](int pxi, int pyi) -> int {
+        const float px = (float)pxi, py = (float)pyi;
+        const float fr = __fadd_rn(__fmul_rn(px, b), __fmul_rn(py, a));
+        const float fc = __fsub_rn(__fmul_rn(px, a), __fmul_rn(py, b));
+        const int ir = __float2int_rn(fr), ic = __float2int_rn(fc);
+        const uint16_t* h = H + (PR + ir - 3) * (HW + 1) + (PR + ic - 3);
+        const int acc = 18 * (h[0] + h[6 * (HW + 1)]) + 34 * (h[HW + 1] + h[5 * (HW + 1)]) +
+                        49 * (h[2 * (HW + 1)] + h[4 * (HW + 1)]) + 55 * h[3 * (HW + 1)];
+        return min(255, (acc + 32768) >> 16);
+    };
+    const char4* pat4 = reinterpret_cast<const char4*>(pattern);
+    const char4 q0 = pat4[lane], q1 = pat4[64 + lane], q2 = pat4[128 + lane], q3 = pat4[192 + lane];
+    const unsigned long long w0 = __ballot(sample(q0.x, q0.y) < sample(q0.z, q0.w));
+    const unsigned long long w1 = __ballot(sample(q1.x, q1.y) < sample(q1.z, q1.w));
+    const unsigned long long w2 = __ballot(sample(q2.x, q2.y) < sample(q2.z, q2.w));
+    const unsigned long long w3 = __ballot(sample(q3.x, q3.y) < sample(q3.z, q3.w));
+
+    if (lane < 4) {
+        const unsigned long long w = lane == 0 ? w0 : lane == 1 ? w1 : lane == 2 ? w2 : w3;
+        reinterpret_cast<unsigned long long*>(descOut + ((size_t)f * cap + off + k) * ORB_DESC_BYTES)[lane] = w;
+    }
+    if (lane == 0) {
+        orb_keypoint kp;
+        kp.x = (float)x0;
+        kp.y = (float)y0;
+        if (level != 0) {                               // :1140-1146
+            kp.x = __fmul_rn(kp.x, L.scale);
+            kp.y = __fmul_rn(kp.y, L.scale);
+        }
+        kp.size = L.sizeField;
+        kp.angle = angle;
+        kp.response = (float)resp;
+        kp.octave = level;
+        kp.class_id = -1;
+        kpsOut[(size_t)f * cap + off + k] = kp;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch wrappers (keep <<<>>> syntax inside this translation unit)
+void orb_launch_copy_level0(hipStream_t st, const uint8_t* src, size_t rowStride, size_t frameStride,
+                            uint8_t* pyr, size_t pyrSlab, int w, int h, int pitch, int nFrames)
+{
+    const int vec16 = ((reinterpret_cast<uintptr_t>(src) | rowStride | frameStride) & 15) == 0;
+    const int x16 = (w + 15) / 16;
+    dim3 grid((x16 + 255) / 256, h, nFrames);
+    hipLaunchKernelGGL(k_copy_level0, grid, dim3(256), 0, st, src, rowStride, frameStride, pyr, pyrSlab, w, h, pitch, vec16);
+}
+
+void orb_launch_resize(hipStream_t st, uint8_t* pyr, size_t pyrSlab, const OrbLevelGeom& src,
+                       const OrbLevelGeom& dst, const int2* xtab, const int2* ytab, int nFrames)
+{
+    const int x4 = (dst.w + 3) / 4;
+    dim3 grid((x4 + 63) / 64, (dst.h + 3) / 4, nFrames);
+    hipLaunchKernelGGL(k_resize_level, grid, dim3(64, 4), 0, st, pyr, pyrSlab, src.pyrOff, src.pitch,
+                       dst.pyrOff, dst.pitch, dst.w, dst.h, xtab, ytab);
+}
+
+void orb_launch_fast_cells(hipStream_t st, const OrbGeom& G, const uint8_t* pyr, size_t pyrSlab,
+                           const OrbCell* cells, int nCells, unsigned long long* cand, size_t candSlab,
+                           int* candCount, int* errFlags, int iniTh, int minTh, int nFrames)
+{
+    if (nCells == 0) return;
+    hipLaunchKernelGGL(k_fast_cells, dim3(nCells, nFrames), dim3(WAVE), 0, st, G, pyr, pyrSlab, cells, cand,
+                       candSlab, candCount, errFlags, iniTh, minTh);
+}
+
+size_t orb_quadtree_lds_bytes(int sortCap, int nodeCap)
+{
+    return (size_t)sortCap * 8 + (size_t)nodeCap * 8 + 3 * (size_t)nodeCap * sizeof(QtNode);
+}
+
+void orb_launch_quadtree(hipStream_t st, const OrbGeom& G, unsigned long long* cand, size_t candSlab,
+                         const int* candCount, uint32_t* kpl, int* kpCount, int* errFlags, int sortCap,
+                         int nodeCap, int nFrames)
+{
+    const size_t lds = orb_quadtree_lds_bytes(sortCap, nodeCap);
+    hipLaunchKernelGGL(k_quadtree, dim3(G.nlevels, nFrames), dim3(256), lds, st, G, cand, candSlab, candCount,
+                       kpl, kpCount, errFlags, sortCap, nodeCap);
+}
+
+void orb_launch_orient_desc(hipStream_t st, const OrbGeom& G, const uint8_t* pyr, size_t pyrSlab,
+                            const uint32_t* kpl, const int* kpCount, const int8_t* pattern,
+                            orb_keypoint* kps, uint8_t* desc, int cap, int32_t* counts, int* errFlags,
+                            int nFrames)
+{
+    hipLaunchKernelGGL(k_orient_desc, dim3(G.kpSlab, nFrames), dim3(WAVE), 0, st, G, pyr, pyrSlab, kpl, kpCount,
+                       pattern, kps, desc, cap, counts, errFlags);
+}

@@ -1,0 +1,555 @@
+// orb_extractor.hip -- host side of the extractor half of include/orb_hip.h:
+// handle life cycle, the constructor tables of reference src/ORBextractor.cc:498-559, level / cell
+// geometry (:805-849), resize coefficient tables (cv::resize set-up), scratch slabs in HBM and
+// the launch sequence of one batch.  All device work of a handle goes to its own HIP stream.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/orb_brief_pattern.h"
+#include "orb_kernels.h"
+
+#pragma clang fp contract(off)
+
+// ------------------------------------------------------------------ error string
+static thread_local char g_err[512] = "";
+void orb_set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* orb_last_error(void) { return g_err; }
+extern "C" const char* orb_version(void) { return "orbhip 0.1 (gfx950)"; }
+
+static inline int cv_round_f(float v) { return (int)lrintf(v); }      // round-half-even
+static inline int cv_round_d(double v) { return (int)lrint(v); }
+static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need)
+    {
+        if (need <= bytes) return ORB_OK;
+        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+        ORB_HIP_TRY(hipMalloc(&p, need));
+        bytes = need;
+        return ORB_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
+struct orb_extractor {
+    orb_extractor_params prm;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool profiling = false, profiled = false;
+
+    // constructor tables (reference :503-558)
+    std::vector<float> scale, invScale, sigma2, invSigma2;
+    std::vector<int> quota;
+    int umax[16];
+
+    // geometry for the current image size
+    int rows = 0, cols = 0;
+    OrbGeom G;
+    std::vector<OrbCell> cells;
+    size_t pyrSlab = 0, candSlab = 0;
+    int sortCap = 4096, nodeCap = 0, maxKp = 0;
+
+    // device memory
+    DevBuf dPattern, dCells, dXtab, dYtab;      // constants
+    std::vector<size_t> xtabOff, ytabOff;       // per level offsets (in int2 units)
+    DevBuf dPyr, dCand, dKpl, dCandCount, dKpCount, dErr;   // per-batch scratch
+    DevBuf dImgs, dKps, dDesc, dCounts;         // staging for the host-buffer API
+    const int8_t* patternPtr = nullptr;         // device pointer in use (own copy or caller's)
+    int framesCap = 0, lastFrames = 0;
+    std::vector<int> hErr;
+};
+
+// ------------------------------------------------------------------ ctor tables (A.1)
+static void build_tables(orb_extractor* h)
+{
+    const int nl = h->prm.nlevels;
+    const double scaleFactor = (double)h->prm.scale_factor;            // member is double (:99 of the header)
+    h->scale.assign(nl, 1.0f);
+    h->sigma2.assign(nl, 1.0f);
+    for (int i = 1; i < nl; i++) {
+        h->scale[i] = (float)(h->scale[i - 1] * scaleFactor);
+        h->sigma2[i] = h->scale[i] * h->scale[i];
+    }
+    h->invScale.resize(nl);
+    h->invSigma2.resize(nl);
+    for (int i = 0; i < nl; i++) {
+        h->invScale[i] = 1.0f / h->scale[i];
+        h->invSigma2[i] = 1.0f / h->sigma2[i];
+    }
+    h->quota.resize(nl);
+    const float factor = (float)(1.0f / scaleFactor);
+    float nDesired = h->prm.nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)nl));
+    int sum = 0;
+    for (int l = 0; l < nl - 1; l++) {
+        h->quota[l] = cv_round_f(nDesired);
+        sum += h->quota[l];
+        nDesired *= factor;
+    }
+    h->quota[nl - 1] = std::max(h->prm.nfeatures - sum, 0);
+
+    // umax (:544-558)
+    const int HP = 15;
+    int v, v0;
+    const int vmax = (int)std::floor(HP * std::sqrt(2.f) / 2 + 1);
+    const int vmin = (int)std::ceil(HP * std::sqrt(2.f) / 2);
+    const double hp2 = HP * HP;
+    for (v = 0; v <= vmax; ++v) h->umax[v] = cv_round_d(std::sqrt(hp2 - v * v));
+    for (v = HP, v0 = 0; v >= vmin; --v) {
+        while (h->umax[v0] == h->umax[v0 + 1]) ++v0;
+        h->umax[v] = v0;
+        ++v0;
+    }
+}
+
+// cv::resize INTER_LINEAR coefficient set-up for one axis
+static void axis_table(int srcLen, int dstLen, bool isX, std::vector<int2>& out)
+{
+    out.resize(dstLen);
+    const double invScale = (double)dstLen / srcLen;
+    const double scale = 1.0 / invScale;
+    for (int d = 0; d < dstLen; d++) {
+        float fr = (float)((d + 0.5) * scale - 0.5);
+        int s = (int)std::floor(fr);
+        fr -= s;
+        if (isX) {
+            if (s < 0) { fr = 0; s = 0; }
+            if (s >= srcLen - 1) { fr = 0; s = srcLen - 1; }
+        }
+        int c0 = cv_round_f((1.f - fr) * 2048.f), c1 = cv_round_f(fr * 2048.f);
+        c0 = std::min(32767, std::max(-32768, c0));
+        c1 = std::min(32767, std::max(-32768, c1));
+        if (isX) {
+            out[d] = make_int2(s, (c0 & 0xffff) | (c1 << 16));
+        } else {
+            const int s0 = std::min(std::max(s, 0), srcLen - 1), s1 = std::min(std::max(s + 1, 0), srcLen - 1);
+            out[d] = make_int2(s0 | (s1 << 16), (c0 & 0xffff) | (c1 << 16));
+        }
+    }
+}
+
+// level sizes, FAST cell list, quadtree boxes, slab layout for a rows x cols input
+static int build_geometry(orb_extractor* h, int rows, int cols)
+{
+    const int nl = h->prm.nlevels;
+    OrbGeom& G = h->G;
+    std::memset(&G, 0, sizeof(G));
+    G.nlevels = nl;
+    for (int i = 0; i < 16; i++) G.umaxPacked |= (unsigned long long)(h->umax[i] & 15) << (4 * i);
+    h->cells.clear();
+    size_t pyrOff = 0;
+    size_t candOff = 0;
+    int kpOff = 0, nodeCap = 0;
+    for (int l = 0; l < nl; l++) {
+        OrbLevelGeom& L = G.L[l];
+        L.w = cv_round_f((float)cols * h->invScale[l]);                 // :1158
+        L.h = cv_round_f((float)rows * h->invScale[l]);
+        if (L.w < 1 || L.h < 1 || L.w > 4095 || L.h > 4095) {
+            orb_set_error("level %d of a %dx%d image is %dx%d: outside the supported 1..4095 px", l, cols, rows, L.w, L.h);
+            return ORB_ERR_UNSUPPORTED;
+        }
+        L.pitch = align_up(L.w, 64);
+        L.pyrOff = (int)pyrOff;
+        pyrOff += (size_t)L.pitch * L.h;
+        if (pyrOff > 0x7fffffffu) return ORB_ERR_UNSUPPORTED;
+        L.quota = h->quota[l];
+        L.scale = h->scale[l];
+        L.sizeField = (float)(int)(31 * h->scale[l]);                  // :886, :895
+
+        // FAST cell grid (:805-849)
+        const int minB = 16, maxBX = L.w - 16, maxBY = L.h - 16;
+        const float width = (float)(maxBX - minB), height = (float)(maxBY - minB);
+        const int nCols = (int)(width / 30.f), nRows = (int)(height / 30.f);
+        int candCap = 0;
+        if (nCols > 0 && nRows > 0) {
+            const int wCell = (int)std::ceil(width / nCols), hCell = (int)std::ceil(height / nRows);
+            if (wCell > 60 || hCell > 60 || nCols > 128 || nRows > 128) {
+                orb_set_error("FAST cell grid %dx%d cells of %dx%d px unsupported", nCols, nRows, wCell, hCell);
+                return ORB_ERR_UNSUPPORTED;
+            }
+            L.nCols = nCols; L.nRows = nRows; L.wCell = wCell; L.hCell = hCell;
+            for (int i = 0; i < nRows; i++) {
+                const float iniY = (float)(minB + i * hCell);
+                float maxY = iniY + hCell + 6;
+                if (iniY >= maxBY - 3) continue;
+                if (maxY > maxBY) maxY = (float)maxBY;
+                for (int j = 0; j < nCols; j++) {
+                    const float iniX = (float)(minB + j * wCell);
+                    float maxX = iniX + wCell + 6;
+                    if (iniX >= maxBX - 6) continue;
+                    if (maxX > maxBX) maxX = (float)maxBX;
+                    OrbCell c;
+                    c.x0 = (short)iniX; c.y0 = (short)iniY;
+                    c.w = (short)((int)maxX - (int)iniX); c.h = (short)((int)maxY - (int)iniY);
+                    c.level = (unsigned char)l; c.ci = (unsigned char)i; c.cj = (unsigned char)j; c.pad = 0;
+                    if (c.w < 7 || c.h < 7) continue;                    // cv::FAST finds nothing in such a ROI
+                    h->cells.push_back(c);
+                    candCap += ((c.w - 6 + 1) / 2) * ((c.h - 6 + 1) / 2);   // 3x3 strict NMS bound
+                }
+            }
+        }
+        L.candBase = (int)candOff;
+        L.candCap = candCap;
+        candOff += (size_t)align_up(std::max(candCap, 1), 2);
+
+        // quadtree roots (:567-568)
+        L.boxW = maxBX - minB;
+        L.boxH = maxBY - minB;
+        int nIni = 0;
+        if (L.boxW > 0 && L.boxH > 0) nIni = (int)std::round((float)L.boxW / L.boxH);
+        if (nIni > 15) { orb_set_error("aspect ratio %d:1 unsupported", nIni); return ORB_ERR_UNSUPPORTED; }
+        if (std::max(nIni > 0 ? L.boxW / std::max(nIni, 1) : 0, L.boxH) > 2048) {
+            orb_set_error("quadtree box %dx%d needs more than %d path levels", L.boxW, L.boxH, ORB_KEY_PATH_LEVELS);
+            return ORB_ERR_UNSUPPORTED;
+        }
+        if (nIni <= 0) {
+            // reference divides by zero here (portrait images): defined as "no keypoints"
+            L.nIni = 0; L.hX = 1.f; L.candCap = 0;
+            while (!h->cells.empty() && h->cells.back().level == l) h->cells.pop_back();
+        } else {
+            L.nIni = nIni;
+            L.hX = (float)L.boxW / nIni;
+        }
+        L.kpBase = kpOff;
+        L.kpCap = std::max(L.quota + 3, 4 * std::max(nIni, 1)) + 5;
+        kpOff += L.kpCap;
+        nodeCap = std::max(nodeCap, L.kpCap);
+    }
+    G.kpSlab = kpOff;
+    h->pyrSlab = (size_t)align_up((int)pyrOff, 256);
+    h->candSlab = candOff;
+    h->nodeCap = nodeCap;
+    h->maxKp = kpOff;
+    h->sortCap = 4096;
+    while (h->sortCap > 256 && orb_quadtree_lds_bytes(h->sortCap, nodeCap) > 60 * 1024) h->sortCap >>= 1;
+    if (orb_quadtree_lds_bytes(h->sortCap, nodeCap) > 64 * 1024) {
+        orb_set_error("nfeatures too large for the quadtree kernel's LDS budget");
+        return ORB_ERR_UNSUPPORTED;
+    }
+    h->rows = rows;
+    h->cols = cols;
+
+    // upload constants for this geometry
+    int rc;
+    if (!h->cells.empty()) {
+        if ((rc = h->dCells.ensure(h->cells.size() * sizeof(OrbCell))) != ORB_OK) return rc;
+        ORB_HIP_TRY(hipMemcpyAsync(h->dCells.p, h->cells.data(), h->cells.size() * sizeof(OrbCell),
+                                   hipMemcpyHostToDevice, h->stream));
+    }
+    std::vector<int2> xt, yt, t;
+    h->xtabOff.assign(nl, 0);
+    h->ytabOff.assign(nl, 0);
+    for (int l = 1; l < nl; l++) {
+        axis_table(G.L[l - 1].w, G.L[l].w, true, t);
+        h->xtabOff[l] = xt.size();
+        xt.insert(xt.end(), t.begin(), t.end());
+        axis_table(G.L[l - 1].h, G.L[l].h, false, t);
+        h->ytabOff[l] = yt.size();
+        yt.insert(yt.end(), t.begin(), t.end());
+    }
+    if (!xt.empty()) {
+        if ((rc = h->dXtab.ensure(xt.size() * sizeof(int2))) != ORB_OK) return rc;
+        if ((rc = h->dYtab.ensure(yt.size() * sizeof(int2))) != ORB_OK) return rc;
+        ORB_HIP_TRY(hipMemcpyAsync(h->dXtab.p, xt.data(), xt.size() * sizeof(int2), hipMemcpyHostToDevice, h->stream));
+        ORB_HIP_TRY(hipMemcpyAsync(h->dYtab.p, yt.data(), yt.size() * sizeof(int2), hipMemcpyHostToDevice, h->stream));
+    }
+    ORB_HIP_TRY(hipStreamSynchronize(h->stream));     // host vectors go out of scope
+    h->framesCap = 0;                                  // slabs changed size: re-allocate lazily
+    return ORB_OK;
+}
+
+static int ensure_scratch(orb_extractor* h, int nFrames)
+{
+    if (nFrames <= h->framesCap) return ORB_OK;
+    int rc;
+    if ((rc = h->dPyr.ensure(h->pyrSlab * nFrames)) != ORB_OK) return rc;
+    if ((rc = h->dCand.ensure(h->candSlab * 8 * nFrames)) != ORB_OK) return rc;
+    if ((rc = h->dKpl.ensure((size_t)h->G.kpSlab * 4 * nFrames)) != ORB_OK) return rc;
+    if ((rc = h->dCandCount.ensure((size_t)ORB_MAX_LEVELS * 4 * nFrames)) != ORB_OK) return rc;
+    if ((rc = h->dKpCount.ensure((size_t)ORB_MAX_LEVELS * 4 * nFrames)) != ORB_OK) return rc;
+    if ((rc = h->dErr.ensure((size_t)4 * nFrames)) != ORB_OK) return rc;
+    h->framesCap = nFrames;
+    return ORB_OK;
+}
+
+// ------------------------------------------------------------------ C ABI
+extern "C" int orb_builtin_pattern(int8_t* out)
+{
+    if (!out) return ORB_ERR_INVALID;
+    std::memcpy(out, ORB_BRIEF_PATTERN_XY, 1024);
+    return ORB_OK;
+}
+
+extern "C" int orb_extractor_create(const orb_extractor_params* p, int device_id, orb_extractor** out)
+{
+    if (!p || !out) return ORB_ERR_INVALID;
+    *out = nullptr;
+    if (p->nlevels < 1 || p->nlevels > ORB_MAX_LEVELS || p->nfeatures < 0 || !(p->scale_factor > 1.0f) ||
+        p->ini_th_fast < 0 || p->min_th_fast < 0 || p->ini_th_fast > 255 || p->min_th_fast > 255) {
+        orb_set_error("invalid extractor parameters");
+        return ORB_ERR_INVALID;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        orb_set_error("no HIP device: liborbhip has no CPU fallback");
+        return ORB_ERR_NO_DEVICE;
+    }
+    if (device_id < 0 || device_id >= ndev) return ORB_ERR_INVALID;
+    ORB_HIP_TRY(hipSetDevice(device_id));
+    orb_extractor* h = new (std::nothrow) orb_extractor();
+    if (!h) return ORB_ERR_INTERNAL;
+    h->prm = *p;
+    h->device = device_id;
+    build_tables(h);
+    hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete h; orb_set_error("hipStreamCreate: %s", hipGetErrorString(e)); return ORB_ERR_HIP; }
+    for (int i = 0; i < 5; i++) (void)hipEventCreate(&h->ev[i]);
+    int rc = h->dPattern.ensure(1024);
+    if (rc == ORB_OK) {
+        if (hipMemcpy(h->dPattern.p, ORB_BRIEF_PATTERN_XY, 1024, hipMemcpyHostToDevice) != hipSuccess) rc = ORB_ERR_HIP;
+    }
+    if (rc != ORB_OK) { orb_extractor_destroy(h); return rc; }
+    h->patternPtr = (const int8_t*)h->dPattern.p;
+    *out = h;
+    return ORB_OK;
+}
+
+extern "C" void orb_extractor_destroy(orb_extractor* h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    DevBuf* bufs[] = {&h->dPattern, &h->dCells, &h->dXtab, &h->dYtab, &h->dPyr, &h->dCand, &h->dKpl,
+                      &h->dCandCount, &h->dKpCount, &h->dErr, &h->dImgs, &h->dKps, &h->dDesc, &h->dCounts};
+    for (DevBuf* b : bufs) b->release();
+    for (int i = 0; i < 5; i++)
+        if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+extern "C" int orb_extractor_get_tables(const orb_extractor* h, float* scale, float* inv, float* s2, float* is2,
+                                        int32_t* fpl)
+{
+    if (!h) return ORB_ERR_INVALID;
+    for (int i = 0; i < h->prm.nlevels; i++) {
+        if (scale) scale[i] = h->scale[i];
+        if (inv) inv[i] = h->invScale[i];
+        if (s2) s2[i] = h->sigma2[i];
+        if (is2) is2[i] = h->invSigma2[i];
+        if (fpl) fpl[i] = h->quota[i];
+    }
+    return ORB_OK;
+}
+
+extern "C" int orb_extractor_max_keypoints(const orb_extractor* h)
+{
+    if (!h) return ORB_ERR_INVALID;
+    int tot = 0;
+    for (int l = 0; l < h->prm.nlevels; l++) tot += std::max(h->quota[l] + 3, 4 * 15) + 5;
+    return tot;
+}
+
+extern "C" int orb_extractor_set_pattern(orb_extractor* h, const int8_t* pat)
+{
+    if (!h || !pat) return ORB_ERR_INVALID;
+    ORB_HIP_TRY(hipSetDevice(h->device));
+    ORB_HIP_TRY(hipMemcpyAsync(h->dPattern.p, pat, 1024, hipMemcpyHostToDevice, h->stream));
+    ORB_HIP_TRY(hipStreamSynchronize(h->stream));
+    h->patternPtr = (const int8_t*)h->dPattern.p;
+    return ORB_OK;
+}
+
+extern "C" int orb_extractor_set_pattern_device(orb_extractor* h, const int8_t* dpat)
+{
+    if (!h || !dpat) return ORB_ERR_INVALID;
+    ORB_HIP_TRY(hipSetDevice(h->device));
+    ORB_HIP_TRY(hipMemcpyAsync(h->dPattern.p, dpat, 1024, hipMemcpyDeviceToDevice, h->stream));
+    ORB_HIP_TRY(hipStreamSynchronize(h->stream));
+    h->patternPtr = (const int8_t*)h->dPattern.p;
+    return ORB_OK;
+}
+
+extern "C" int orb_extractor_set_profiling(orb_extractor* h, int enable)
+{
+    if (!h) return ORB_ERR_INVALID;
+    h->profiling = enable != 0;
+    h->profiled = false;
+    return ORB_OK;
+}
+
+extern "C" int orb_extractor_get_stage_ms(orb_extractor* h, float* ms5)
+{
+    if (!h || !ms5) return ORB_ERR_INVALID;
+    if (!h->profiled) { orb_set_error("no profiled batch"); return ORB_ERR_INVALID; }
+    ORB_HIP_TRY(hipEventSynchronize(h->ev[4]));
+    for (int i = 0; i < 4; i++) ORB_HIP_TRY(hipEventElapsedTime(&ms5[i], h->ev[i], h->ev[i + 1]));
+    ORB_HIP_TRY(hipEventElapsedTime(&ms5[4], h->ev[0], h->ev[4]));
+    return ORB_OK;
+}
+
+extern "C" void* orb_extractor_stream(orb_extractor* h) { return h ? (void*)h->stream : nullptr; }
+
+extern "C" int orb_extract_batch_device(orb_extractor* h, const uint8_t* d_imgs, int nFrames, int rows, int cols,
+                                        size_t rowStride, size_t frameStride, orb_keypoint* d_kps,
+                                        uint8_t* d_desc, int cap, int32_t* d_counts)
+{
+    if (!h || nFrames < 0 || cap < 0 || !d_counts) return ORB_ERR_INVALID;
+    if (nFrames == 0) return ORB_OK;
+    if (nFrames > 65535) { orb_set_error("at most 65535 frames per batch"); return ORB_ERR_UNSUPPORTED; }
+    ORB_HIP_TRY(hipSetDevice(h->device));
+    if (!d_imgs || rows <= 0 || cols <= 0) {                   // reference :1087-1088: silent return
+        ORB_HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t)nFrames * 4, h->stream));
+        h->lastFrames = 0;
+        return ORB_OK;
+    }
+    if (!d_kps || !d_desc || rowStride < (size_t)cols) return ORB_ERR_INVALID;
+    int rc;
+    if (rows != h->rows || cols != h->cols)
+        if ((rc = build_geometry(h, rows, cols)) != ORB_OK) return rc;
+    if ((rc = ensure_scratch(h, nFrames)) != ORB_OK) return rc;
+    const OrbGeom& G = h->G;
+    hipStream_t st = h->stream;
+    uint8_t* pyr = (uint8_t*)h->dPyr.p;
+
+    ORB_HIP_TRY(hipMemsetAsync(h->dCandCount.p, 0, (size_t)ORB_MAX_LEVELS * 4 * nFrames, st));
+    ORB_HIP_TRY(hipMemsetAsync(h->dErr.p, 0, (size_t)4 * nFrames, st));
+    if (h->profiling) ORB_HIP_TRY(hipEventRecord(h->ev[0], st));
+    orb_launch_copy_level0(st, d_imgs, rowStride, frameStride, pyr, h->pyrSlab, G.L[0].w, G.L[0].h, G.L[0].pitch, nFrames);
+    for (int l = 1; l < G.nlevels; l++)
+        orb_launch_resize(st, pyr, h->pyrSlab, G.L[l - 1], G.L[l], (const int2*)h->dXtab.p + h->xtabOff[l],
+                          (const int2*)h->dYtab.p + h->ytabOff[l], nFrames);
+    if (h->profiling) ORB_HIP_TRY(hipEventRecord(h->ev[1], st));
+    orb_launch_fast_cells(st, G, pyr, h->pyrSlab, (const OrbCell*)h->dCells.p, (int)h->cells.size(),
+                          (unsigned long long*)h->dCand.p, h->candSlab, (int*)h->dCandCount.p, (int*)h->dErr.p,
+                          h->prm.ini_th_fast, h->prm.min_th_fast, nFrames);
+    if (h->profiling) ORB_HIP_TRY(hipEventRecord(h->ev[2], st));
+    orb_launch_quadtree(st, G, (unsigned long long*)h->dCand.p, h->candSlab, (const int*)h->dCandCount.p,
+                        (uint32_t*)h->dKpl.p, (int*)h->dKpCount.p, (int*)h->dErr.p, h->sortCap, h->nodeCap, nFrames);
+    if (h->profiling) ORB_HIP_TRY(hipEventRecord(h->ev[3], st));
+    orb_launch_orient_desc(st, G, pyr, h->pyrSlab, (const uint32_t*)h->dKpl.p, (const int*)h->dKpCount.p,
+                           h->patternPtr, d_kps, d_desc, cap, d_counts, (int*)h->dErr.p, nFrames);
+    if (h->profiling) {
+        ORB_HIP_TRY(hipEventRecord(h->ev[4], st));
+        h->profiled = true;
+    }
+    ORB_HIP_TRY(hipGetLastError());
+    h->lastFrames = nFrames;
+    return ORB_OK;
+}
+
+extern "C" int orb_extractor_sync(orb_extractor* h)
+{
+    if (!h) return ORB_ERR_INVALID;
+    ORB_HIP_TRY(hipSetDevice(h->device));
+    ORB_HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->lastFrames > 0) {
+        h->hErr.resize(h->lastFrames);
+        ORB_HIP_TRY(hipMemcpy(h->hErr.data(), h->dErr.p, (size_t)4 * h->lastFrames, hipMemcpyDeviceToHost));
+        for (int f = 0; f < h->lastFrames; f++)
+            if (h->hErr[f]) {
+                orb_set_error("device-side overflow flag 0x%x on frame %d (1 candidates, 2 nodes, 4 output cap)", h->hErr[f], f);
+                return (h->hErr[f] & 4) ? ORB_ERR_CAPACITY : ORB_ERR_INTERNAL;
+            }
+    }
+    return ORB_OK;
+}
+
+extern "C" int orb_extract_batch(orb_extractor* h, const uint8_t* imgs, int nFrames, int rows, int cols,
+                                 size_t rowStride, size_t frameStride, orb_keypoint* kps, uint8_t* desc, int cap,
+                                 int32_t* counts)
+{
+    if (!h || nFrames < 0 || !counts) return ORB_ERR_INVALID;
+    if (nFrames == 0) return ORB_OK;
+    if (!imgs || rows <= 0 || cols <= 0) {
+        for (int f = 0; f < nFrames; f++) counts[f] = 0;
+        return ORB_OK;
+    }
+    if (!kps || !desc || cap <= 0) return ORB_ERR_INVALID;
+    ORB_HIP_TRY(hipSetDevice(h->device));
+    int rc;
+    const size_t imgBytes = (size_t)rows * cols;
+    if ((rc = h->dImgs.ensure(imgBytes * nFrames)) != ORB_OK) return rc;
+    if ((rc = h->dKps.ensure(sizeof(orb_keypoint) * (size_t)cap * nFrames)) != ORB_OK) return rc;
+    if ((rc = h->dDesc.ensure((size_t)ORB_DESC_BYTES * cap * nFrames)) != ORB_OK) return rc;
+    if ((rc = h->dCounts.ensure((size_t)4 * nFrames)) != ORB_OK) return rc;
+    for (int f = 0; f < nFrames; f++)
+        ORB_HIP_TRY(hipMemcpy2DAsync((uint8_t*)h->dImgs.p + imgBytes * f, cols, imgs + frameStride * f, rowStride,
+                                     cols, rows, hipMemcpyHostToDevice, h->stream));
+    rc = orb_extract_batch_device(h, (const uint8_t*)h->dImgs.p, nFrames, rows, cols, cols, imgBytes,
+                                  (orb_keypoint*)h->dKps.p, (uint8_t*)h->dDesc.p, cap, (int32_t*)h->dCounts.p);
+    if (rc != ORB_OK) return rc;
+    ORB_HIP_TRY(hipMemcpyAsync(counts, h->dCounts.p, (size_t)4 * nFrames, hipMemcpyDeviceToHost, h->stream));
+    if ((rc = orb_extractor_sync(h)) != ORB_OK) return rc;
+    for (int f = 0; f < nFrames; f++) {
+        const int n = counts[f];
+        if (n <= 0) continue;
+        ORB_HIP_TRY(hipMemcpyAsync(kps + (size_t)cap * f, (orb_keypoint*)h->dKps.p + (size_t)cap * f,
+                                   sizeof(orb_keypoint) * n, hipMemcpyDeviceToHost, h->stream));
+        ORB_HIP_TRY(hipMemcpyAsync(desc + (size_t)ORB_DESC_BYTES * cap * f,
+                                   (uint8_t*)h->dDesc.p + (size_t)ORB_DESC_BYTES * cap * f,
+                                   (size_t)ORB_DESC_BYTES * n, hipMemcpyDeviceToHost, h->stream));
+    }
+    ORB_HIP_TRY(hipStreamSynchronize(h->stream));
+    return ORB_OK;
+}
+
+extern "C" int orb_extract(orb_extractor* h, const uint8_t* img, int rows, int cols, size_t stride,
+                           orb_keypoint* kps, uint8_t* desc, int cap, int* n)
+{
+    if (!h || !n) return ORB_ERR_INVALID;
+    int32_t cnt = 0;
+    const int rc = orb_extract_batch(h, img, 1, rows, cols, stride, 0, kps, desc, cap, &cnt);
+    *n = cnt;
+    return rc;
+}
+
+extern "C" int orb_get_pyramid_level(orb_extractor* h, int frame, int level, uint8_t* dst, size_t dstStride,
+                                     int* rows, int* cols)
+{
+    if (!h || level < 0 || level >= h->prm.nlevels || h->rows == 0) return ORB_ERR_INVALID;
+    const OrbLevelGeom& L = h->G.L[level];
+    if (rows) *rows = L.h;
+    if (cols) *cols = L.w;
+    if (!dst) return ORB_OK;
+    if (frame < 0 || frame >= h->lastFrames || dstStride < (size_t)L.w) return ORB_ERR_INVALID;
+    ORB_HIP_TRY(hipSetDevice(h->device));
+    ORB_HIP_TRY(hipMemcpy2DAsync(dst, dstStride, (const uint8_t*)h->dPyr.p + h->pyrSlab * frame + L.pyrOff, L.pitch,
+                                 L.w, L.h, hipMemcpyDeviceToHost, h->stream));
+    ORB_HIP_TRY(hipStreamSynchronize(h->stream));
+    return ORB_OK;
+}
+
+extern "C" int orb_get_level_counts(orb_extractor* h, int frame, int32_t* kept, int32_t* cands)
+{
+    if (!h || frame < 0 || frame >= h->lastFrames) return ORB_ERR_INVALID;
+    ORB_HIP_TRY(hipSetDevice(h->device));
+    ORB_HIP_TRY(hipStreamSynchronize(h->stream));
+    int32_t buf[ORB_MAX_LEVELS];
+    if (kept) {
+        ORB_HIP_TRY(hipMemcpy(buf, (const int*)h->dKpCount.p + (size_t)ORB_MAX_LEVELS * frame, sizeof(buf), hipMemcpyDeviceToHost));
+        for (int l = 0; l < h->prm.nlevels; l++) kept[l] = buf[l];
+    }
+    if (cands) {
+        ORB_HIP_TRY(hipMemcpy(buf, (const int*)h->dCandCount.p + (size_t)ORB_MAX_LEVELS * frame, sizeof(buf), hipMemcpyDeviceToHost));
+        for (int l = 0; l < h->prm.nlevels; l++) cands[l] = buf[l];
+    }
+    return ORB_OK;
+}

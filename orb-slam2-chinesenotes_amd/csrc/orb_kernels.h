@@ -1,0 +1,19 @@
+// orb_kernels.h -- launch wrappers of the gfx950 kernels (defined in the *.hip translation units).
+#pragma once
+#include "orb_common.h"
+
+void orb_launch_copy_level0(hipStream_t st, const uint8_t* src, size_t rowStride, size_t frameStride,
+                            uint8_t* pyr, size_t pyrSlab, int w, int h, int pitch, int nFrames);
+void orb_launch_resize(hipStream_t st, uint8_t* pyr, size_t pyrSlab, const OrbLevelGeom& src,
+                       const OrbLevelGeom& dst, const int2* xtab, const int2* ytab, int nFrames);
+void orb_launch_fast_cells(hipStream_t st, const OrbGeom& G, const uint8_t* pyr, size_t pyrSlab,
+                           const OrbCell* cells, int nCells, unsigned long long* cand, size_t candSlab,
+                           int* candCount, int* errFlags, int iniTh, int minTh, int nFrames);
+size_t orb_quadtree_lds_bytes(int sortCap, int nodeCap);
+void orb_launch_quadtree(hipStream_t st, const OrbGeom& G, unsigned long long* cand, size_t candSlab,
+                         const int* candCount, uint32_t* kpl, int* kpCount, int* errFlags, int sortCap,
+                         int nodeCap, int nFrames);
+void orb_launch_orient_desc(hipStream_t st, const OrbGeom& G, const uint8_t* pyr, size_t pyrSlab,
+                            const uint32_t* kpl, const int* kpCount, const int8_t* pattern,
+                            orb_keypoint* kps, uint8_t* desc, int cap, int32_t* counts, int* errFlags,
+                            int nFrames);

@@ -1,0 +1,541 @@
+// orb_matcher.hip -- matcher half of include/orb_hip.h on gfx950.
+//
+//   orb_hamming / orb_three_maxima      host restatements of the two tiny static helpers
+//                                       (reference src/ORBmatcher.cc:46-63, :1663-1707)
+//   k_bow_assign                        synthetic 2-level vocabulary descent
+//   k_match_bow<KK>                     SearchByBoW(KF,F) / SearchByBoW(KF,KF)  (:552-687, :690-832)
+//   k_init_candidates / k_init_resolve  SearchForInitialization + Frame grid     (:1055-1180; Frame.cc:348-422)
+//
+// SearchByBoW: one 256-thread workgroup per (keyframe, frame) pair.  Both feature vectors are
+// rebuilt in LDS as CSR from a per-feature vocabulary-node array; vocabulary nodes are independent
+// (a Frame feature belongs to exactly one node), so the four waves take nodes round-robin.  Inside a
+// node the keyframe loop is serial (greedy "already matched" rule, :607); the lanes of the wave hold
+// the Frame-side descriptors of the node and find best / second-best Hamming distance with popcount
+// + cross-lane min.  Rotation histogram, ComputeThreeMaxima and the top-3 filter run in the same launch.
+#include <algorithm>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "orb_common.h"
+
+#pragma clang fp contract(off)
+
+#define WAVE 64
+#define TH_LOW 50
+#define HISTO_LENGTH 30
+#define MAX_NODES 1024
+#define NODE_NONE 0xFFFFu
+
+// ------------------------------------------------------------------ host helpers
+extern "C" int orb_hamming(const uint8_t* a, const uint8_t* b)
+{
+    int dist = 0;
+    for (int i = 0; i < 8; i++) {
+        uint32_t x, y;
+        std::memcpy(&x, a + 4 * i, 4);
+        std::memcpy(&y, b + 4 * i, 4);
+        dist += __builtin_popcount(x ^ y);
+    }
+    return dist;
+}
+
+static inline void three_maxima(const int* counts, int& ind1, int& ind2, int& ind3)
+{
+    int max1 = 0, max2 = 0, max3 = 0;
+    ind1 = ind2 = ind3 = -1;
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+        const int s = counts[i];
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+        else if (s > max3) { max3 = s; ind3 = i; }
+    }
+    if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+    else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+}
+
+extern "C" void orb_three_maxima(const int32_t* counts30, int32_t* ind3)
+{
+    int a, b, c;
+    three_maxima(counts30, a, b, c);
+    ind3[0] = a; ind3[1] = b; ind3[2] = c;
+}
+
+// ------------------------------------------------------------------ device helpers
+__device__ __forceinline__ int hamming8(const uint32_t* a, const uint32_t* b)
+{
+    int d = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) d += __popc(a[i] ^ b[i]);
+    return d;
+}
+
+__device__ __forceinline__ void load_desc(const uint8_t* p, uint32_t v[8])
+{
+    const uint4 lo = reinterpret_cast<const uint4*>(p)[0], hi = reinterpret_cast<const uint4*>(p)[1];
+    v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w;
+    v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+}
+
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, (unsigned)__shfl_xor((int)v, o));
+    return v;
+}
+
+// rotation-histogram bin (reference :634-641): factor is 1/HISTO_LENGTH, so only bins 0..12 occur
+__device__ __forceinline__ int rot_bin(float angA, float angB)
+{
+    float rot = __fsub_rn(angA, angB);
+    if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+    int bin = (int)roundf(__fmul_rn(rot, 1.0f / HISTO_LENGTH));
+    if (bin == HISTO_LENGTH) bin = 0;
+    return bin;
+}
+
+__device__ void three_maxima_dev(const int* counts, int& ind1, int& ind2, int& ind3)
+{
+    int max1 = 0, max2 = 0, max3 = 0;
+    ind1 = ind2 = ind3 = -1;
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+        const int s = counts[i];
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+        else if (s > max3) { max3 = s; ind3 = i; }
+    }
+    if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
+    else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { ind3 = -1; }
+}
+
+// ------------------------------------------------------------------ vocabulary stand-in
+__global__ __launch_bounds__(256) void k_bow_assign(const uint8_t* __restrict__ desc, const int32_t* __restrict__ counts,
+                                                    int cap, const uint8_t* __restrict__ cent,
+                                                    uint16_t* __restrict__ nodeOf)
+{
+    __shared__ uint32_t c[110 * 8];
+    for (int i = threadIdx.x; i < 110 * 8; i += blockDim.x) c[i] = reinterpret_cast<const uint32_t*>(cent)[i];
+    __syncthreads();
+    const int f = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cap) return;
+    const size_t row = (size_t)f * cap + i;
+    if (i >= counts[f]) { nodeOf[row] = NODE_NONE; return; }
+    uint32_t d[8];
+    load_desc(desc + row * 32, d);
+    int c1 = 0, b1 = 257;
+    for (int k = 0; k < 10; k++) {
+        const int h = hamming8(d, c + 8 * k);
+        if (h < b1) { b1 = h; c1 = k; }                 // first minimum wins
+    }
+    int c2 = 0, b2 = 257;
+    for (int k = 0; k < 10; k++) {
+        const int h = hamming8(d, c + 8 * (10 + 10 * c1 + k));
+        if (h < b2) { b2 = h; c2 = k; }
+    }
+    nodeOf[row] = (uint16_t)(11 + 10 * c1 + c2);
+}
+
+// ------------------------------------------------------------------ SearchByBoW
+struct BowSide {
+    const uint8_t* desc;      // [n][32]
+    const float* angle;       // angle of feature i at angle[i*angleStride]
+    int angleStride;
+    const uint8_t* valid;     // or nullptr
+    const uint16_t* nodeOf;   // vocabulary node per feature, NODE_NONE = not in the feature vector
+    int n;
+};
+
+// Build offsets/indices of one side in LDS: thread t owns node t and scans the features in
+// ascending index order (the order DBoW2 pushes them), so lists come out exactly as the map holds them.
+__device__ void build_csr(const uint16_t* nodeLds, int n, int nNodes, uint16_t* offs, uint16_t* idx, int* cnt)
+{
+    for (int t = threadIdx.x; t < nNodes; t += blockDim.x) {
+        int c = 0;
+        for (int i = 0; i < n; i++) c += (nodeLds[i] == t);
+        cnt[t] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int t = 0; t < nNodes; t++) { offs[t] = (uint16_t)run; run += cnt[t]; }
+        offs[nNodes] = (uint16_t)run;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < nNodes; t += blockDim.x) {
+        int w = offs[t];
+        for (int i = 0; i < n; i++)
+            if (nodeLds[i] == t) idx[w++] = (uint16_t)i;
+    }
+    __syncthreads();
+}
+
+// KK == false: SearchByBoW(KeyFrame*, Frame&)   -> out[iB] = iA   (B = Frame, A = KeyFrame)
+// KK == true : SearchByBoW(KeyFrame*, KeyFrame*) -> out[iA] = iB  (A = KF1, B = KF2), B needs valid, strict <
+template <bool KK>
+__global__ __launch_bounds__(256) void k_match_bow(const BowSide* __restrict__ sidesA, const BowSide* __restrict__ sidesB,
+                                                   int nNodes, int capLds, float ratio, int checkOri,
+                                                   int32_t* __restrict__ match, int matchStride,
+                                                   int32_t* __restrict__ nmatchesOut)
+{
+    extern __shared__ uint16_t msm[];
+    // carve-up (u16 units): nodeA[cap] nodeB[cap] idxA[cap] idxB[cap] offsA[nNodes+1] offsB[nNodes+1]
+    //                       res[cap] (i16 match) bin[cap] (u8 pairs packed in u16 slots) taken[cap]
+    uint16_t* nodeA = msm;
+    uint16_t* nodeB = nodeA + capLds;
+    uint16_t* idxA = nodeB + capLds;
+    uint16_t* idxB = idxA + capLds;
+    uint16_t* offsA = idxB + capLds;
+    uint16_t* offsB = offsA + (nNodes + 2);
+    int16_t* res = reinterpret_cast<int16_t*>(offsB + (nNodes + 2));
+    uint16_t* bin = reinterpret_cast<uint16_t*>(res + capLds);
+    uint16_t* taken = bin + capLds;
+    int* cnt = reinterpret_cast<int*>(taken + capLds + (capLds & 1));   // [nNodes] scratch, 4-byte aligned
+    __shared__ int hist[HISTO_LENGTH];
+    __shared__ int keepBins[3];
+    __shared__ int nm;
+
+    const BowSide A = sidesA[blockIdx.x], B = sidesB[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nWaves = blockDim.x >> 6;
+    const int nRes = KK ? A.n : B.n;
+    for (int i = tid; i < A.n; i += blockDim.x) nodeA[i] = A.nodeOf[i];
+    for (int i = tid; i < B.n; i += blockDim.x) {
+        nodeB[i] = B.nodeOf[i];
+        taken[i] = (KK && B.valid && !B.valid[i]) ? 1 : 0;     // :750 "!pMP2 || isBad" folded into the taken flag
+    }
+    for (int i = tid; i < nRes; i += blockDim.x) { res[i] = -1; bin[i] = 0xFF; }
+    if (tid < HISTO_LENGTH) hist[tid] = 0;
+    if (tid == 0) nm = 0;
+    __syncthreads();
+    build_csr(nodeA, A.n, nNodes, offsA, idxA, cnt);
+    build_csr(nodeB, B.n, nNodes, offsB, idxB, cnt);
+
+    for (int node = wave; node < nNodes; node += nWaves) {
+        const int a0 = offsA[node], a1 = offsA[node + 1];
+        const int b0 = offsB[node], b1 = offsB[node + 1];
+        if (a0 == a1 || b0 == b1) continue;
+        const int nb = b1 - b0;
+        // fast path: the node's B features fit one wave -> keep their descriptors in registers
+        uint32_t dB[8];
+        int iB = -1;
+        if (lane < nb) {
+            iB = idxB[b0 + lane];
+            load_desc(B.desc + (size_t)iB * 32, dB);
+        }
+        for (int p = a0; p < a1; p++) {
+            const int iA = idxA[p];
+            if (A.valid && !A.valid[iA]) continue;                       // :590-595
+            uint32_t dA[8];
+            load_desc(A.desc + (size_t)iA * 32, dA);
+            unsigned best = (256u << 16) | 0xFFFFu;                      // (dist, position) packed
+            unsigned second = 256u;
+            for (int base = 0; base < nb; base += WAVE) {
+                const int q = base + lane;
+                unsigned d = 256u;
+                if (q < nb) {
+                    int j;
+                    if (base == 0) j = iB;
+                    else { j = idxB[b0 + q]; load_desc(B.desc + (size_t)j * 32, dB); }
+                    if (!taken[j]) d = (unsigned)hamming8(dA, dB);       // :607 / :750
+                }
+                const unsigned mine = (d << 16) | (unsigned)q;
+                const unsigned m1 = wave_min_u32(mine);
+                const unsigned m2 = wave_min_u32(mine == m1 ? 0xFFFFFFFFu : mine);
+                // merge chunk (m1, m2) into running (best, second) with sequential-scan semantics
+                const unsigned d1 = m1 >> 16, d2 = (m2 == 0xFFFFFFFFu) ? 256u : (m2 >> 16);
+                if (d1 < (best >> 16)) {
+                    second = min(best >> 16, d2);
+                    best = m1;
+                } else {
+                    second = min(second, d1);
+                }
+            }
+            if (nb > WAVE && lane < nb) {                                // restore chunk 0 for the next KF feature
+                iB = idxB[b0 + lane];
+                load_desc(B.desc + (size_t)iB * 32, dB);
+            }
+            const int best1 = (int)(best >> 16), best2 = (int)second;
+            const bool pass = KK ? (best1 < TH_LOW) : (best1 <= TH_LOW);  // :772 vs :625
+            if (pass && (float)best1 < __fmul_rn(ratio, (float)best2)) {
+                const int jB = idxB[b0 + (int)(best & 0xFFFFu)];
+                if (lane == 0) {
+                    taken[jB] = 1;
+                    const int rIdx = KK ? iA : jB;
+                    res[rIdx] = (int16_t)(KK ? jB : iA);
+                    if (checkOri)
+                        bin[rIdx] = (uint16_t)rot_bin(A.angle[(size_t)iA * A.angleStride], B.angle[(size_t)jB * B.angleStride]);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
+        }
+    }
+    __syncthreads();
+
+    // ---- rotation histogram + top-3 filter (:663-684)
+    int local = 0;
+    for (int i = tid; i < nRes; i += blockDim.x)
+        if (res[i] >= 0) {
+            local++;
+            if (checkOri) atomicAdd(&hist[bin[i]], 1);
+        }
+    atomicAdd(&nm, local);
+    __syncthreads();
+    if (checkOri) {
+        if (tid == 0) {
+            int i1, i2, i3;
+            three_maxima_dev(hist, i1, i2, i3);
+            keepBins[0] = i1; keepBins[1] = i2; keepBins[2] = i3;
+        }
+        __syncthreads();
+        int dropped = 0;
+        for (int i = tid; i < nRes; i += blockDim.x)
+            if (res[i] >= 0) {
+                const int bb = bin[i];
+                if (bb != keepBins[0] && bb != keepBins[1] && bb != keepBins[2]) { res[i] = -1; dropped++; }
+            }
+        atomicSub(&nm, dropped);
+        __syncthreads();
+    }
+    int32_t* out = match + (size_t)blockIdx.x * matchStride;
+    for (int i = tid; i < nRes; i += blockDim.x) out[i] = res[i];
+    if (tid == 0) nmatchesOut[blockIdx.x] = nm;
+}
+
+// fills the BowSide descriptors of a batch of pairs from a feature store (device side, no host sync)
+__global__ void k_fill_sides(orb_featstore S, const int32_t* __restrict__ kfIndex, const int32_t* __restrict__ fIndex,
+                             int nPairs, BowSide* __restrict__ sidesA, BowSide* __restrict__ sidesB)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nPairs) return;
+    const int32_t idx[2] = {kfIndex[p], fIndex[p]};
+    BowSide* outs[2] = {sidesA + p, sidesB + p};
+    for (int s = 0; s < 2; s++) {
+        const size_t row = (size_t)idx[s] * S.cap;
+        BowSide b;
+        b.desc = S.desc + row * 32;
+        b.angle = &S.kps[row].angle;
+        b.angleStride = sizeof(orb_keypoint) / sizeof(float);
+        b.valid = (s == 0 && S.valid) ? S.valid + row : nullptr;
+        b.nodeOf = S.node_of + row;
+        b.n = S.counts[idx[s]];
+        *outs[s] = b;
+    }
+}
+
+// ------------------------------------------------------------------ host side
+struct MBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need)
+    {
+        if (need <= bytes) return ORB_OK;
+        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+        ORB_HIP_TRY(hipMalloc(&p, need));
+        bytes = need;
+        return ORB_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+
+struct orb_matcher {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    MBuf sidesA, sidesB;                 // BowSide arrays
+    MBuf stage[12];                      // host-API staging
+    MBuf out, nm;
+};
+
+static size_t match_lds_bytes(int capLds, int nNodes)
+{
+    size_t u16s = (size_t)capLds * 7 + (capLds & 1) + 2 * (size_t)(nNodes + 2);
+    return u16s * 2 + (size_t)nNodes * 4 + 8;
+}
+
+extern "C" int orb_matcher_create(int device_id, orb_matcher** out)
+{
+    if (!out) return ORB_ERR_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        orb_set_error("no HIP device: liborbhip has no CPU fallback");
+        return ORB_ERR_NO_DEVICE;
+    }
+    if (device_id < 0 || device_id >= ndev) return ORB_ERR_INVALID;
+    ORB_HIP_TRY(hipSetDevice(device_id));
+    orb_matcher* m = new (std::nothrow) orb_matcher();
+    if (!m) return ORB_ERR_INTERNAL;
+    m->device = device_id;
+    hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete m; orb_set_error("hipStreamCreate: %s", hipGetErrorString(e)); return ORB_ERR_HIP; }
+    *out = m;
+    return ORB_OK;
+}
+
+extern "C" void orb_matcher_destroy(orb_matcher* m)
+{
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    m->sidesA.release(); m->sidesB.release(); m->out.release(); m->nm.release();
+    for (auto& b : m->stage) b.release();
+    if (m->stream) (void)hipStreamDestroy(m->stream);
+    delete m;
+}
+
+extern "C" int orb_matcher_sync(orb_matcher* m)
+{
+    if (!m) return ORB_ERR_INVALID;
+    ORB_HIP_TRY(hipSetDevice(m->device));
+    ORB_HIP_TRY(hipStreamSynchronize(m->stream));
+    return ORB_OK;
+}
+
+extern "C" void* orb_matcher_stream(orb_matcher* m) { return m ? (void*)m->stream : nullptr; }
+
+extern "C" int orb_bow_assign_device(orb_matcher* m, const uint8_t* d_desc, const int32_t* d_counts, int nFrames,
+                                     int cap, const uint8_t* d_cent, uint16_t* d_nodeOf)
+{
+    if (!m || !d_desc || !d_counts || !d_cent || !d_nodeOf || nFrames < 0 || cap <= 0) return ORB_ERR_INVALID;
+    if (nFrames == 0) return ORB_OK;
+    ORB_HIP_TRY(hipSetDevice(m->device));
+    hipLaunchKernelGGL(k_bow_assign, dim3((cap + 255) / 256, nFrames), dim3(256), 0, m->stream, d_desc, d_counts, cap,
+                       d_cent, d_nodeOf);
+    ORB_HIP_TRY(hipGetLastError());
+    return ORB_OK;
+}
+
+static int launch_match(orb_matcher* m, bool kk, const BowSide* dA, const BowSide* dB, int nPairs, int nNodes,
+                        int capLds, float ratio, int checkOri, int32_t* dMatch, int matchStride, int32_t* dNm)
+{
+    const size_t lds = match_lds_bytes(capLds, nNodes);
+    if (lds > 64 * 1024) {
+        orb_set_error("feature capacity %d x %d nodes exceeds the match kernel's LDS budget", capLds, nNodes);
+        return ORB_ERR_UNSUPPORTED;
+    }
+    if (kk)
+        hipLaunchKernelGGL(k_match_bow<true>, dim3(nPairs), dim3(256), lds, m->stream, dA, dB, nNodes, capLds, ratio,
+                           checkOri, dMatch, matchStride, dNm);
+    else
+        hipLaunchKernelGGL(k_match_bow<false>, dim3(nPairs), dim3(256), lds, m->stream, dA, dB, nNodes, capLds, ratio,
+                           checkOri, dMatch, matchStride, dNm);
+    ORB_HIP_TRY(hipGetLastError());
+    return ORB_OK;
+}
+
+extern "C" int orb_match_bow_batch_device(orb_matcher* m, const orb_featstore* store, const int32_t* d_kf,
+                                          const int32_t* d_f, int nPairs, float ratio, int checkOri,
+                                          int32_t* d_match, int32_t* d_nm)
+{
+    if (!m || !store || !d_kf || !d_f || !d_match || !d_nm || nPairs < 0) return ORB_ERR_INVALID;
+    if (nPairs == 0) return ORB_OK;
+    if (store->cap <= 0 || store->cap > 4096) { orb_set_error("featstore cap must be 1..4096"); return ORB_ERR_UNSUPPORTED; }
+    ORB_HIP_TRY(hipSetDevice(m->device));
+    int rc;
+    if ((rc = m->sidesA.ensure(sizeof(BowSide) * (size_t)nPairs)) != ORB_OK) return rc;
+    if ((rc = m->sidesB.ensure(sizeof(BowSide) * (size_t)nPairs)) != ORB_OK) return rc;
+    hipLaunchKernelGGL(k_fill_sides, dim3((nPairs + 255) / 256), dim3(256), 0, m->stream, *store, d_kf, d_f, nPairs,
+                       (BowSide*)m->sidesA.p, (BowSide*)m->sidesB.p);
+    return launch_match(m, false, (const BowSide*)m->sidesA.p, (const BowSide*)m->sidesB.p, nPairs, 128, store->cap,
+                        ratio, checkOri, d_match, store->cap, d_nm);
+}
+
+// CSR feature vectors of both sides -> per-feature compact node index over the COMMON node ids
+// (the merge-walk of :578-659 only ever pairs equal ids).  Requires ascending indices inside a node,
+// which is what DBoW2's transform() produces (fv[node].push_back(i) for ascending i).
+static int csr_to_nodeof(const orb_featvec* fa, int na, const orb_featvec* fb, int nb,
+                         std::vector<uint16_t>& nodeA, std::vector<uint16_t>& nodeB, int& nCommon)
+{
+    nodeA.assign(std::max(na, 1), NODE_NONE);
+    nodeB.assign(std::max(nb, 1), NODE_NONE);
+    nCommon = 0;
+    int a = 0, b = 0;
+    auto check = [](const orb_featvec* fv, int k, int n) -> bool {
+        for (int p = fv->offsets[k]; p < fv->offsets[k + 1]; p++) {
+            if (fv->indices[p] < 0 || fv->indices[p] >= n) return false;
+            if (p > fv->offsets[k] && fv->indices[p] <= fv->indices[p - 1]) return false;
+        }
+        return true;
+    };
+    while (a < fa->n_nodes && b < fb->n_nodes) {
+        if (a > 0 && fa->node_ids[a] <= fa->node_ids[a - 1]) return ORB_ERR_INVALID;
+        if (b > 0 && fb->node_ids[b] <= fb->node_ids[b - 1]) return ORB_ERR_INVALID;
+        if (fa->node_ids[a] == fb->node_ids[b]) {
+            if (nCommon >= MAX_NODES) { orb_set_error("more than %d common vocabulary nodes", MAX_NODES); return ORB_ERR_UNSUPPORTED; }
+            if (!check(fa, a, na) || !check(fb, b, nb)) {
+                orb_set_error("feature-vector indices must be in range and ascending inside a node");
+                return ORB_ERR_UNSUPPORTED;
+            }
+            for (int p = fa->offsets[a]; p < fa->offsets[a + 1]; p++) nodeA[fa->indices[p]] = (uint16_t)nCommon;
+            for (int p = fb->offsets[b]; p < fb->offsets[b + 1]; p++) nodeB[fb->indices[p]] = (uint16_t)nCommon;
+            nCommon++; a++; b++;
+        } else if (fa->node_ids[a] < fb->node_ids[b]) a++;
+        else b++;
+    }
+    return ORB_OK;
+}
+
+static int match_host(orb_matcher* m, bool kk,
+                      const uint8_t* descA, const float* angA, const uint8_t* validA, int nA, const orb_featvec* fvA,
+                      const uint8_t* descB, const float* angB, const uint8_t* validB, int nB, const orb_featvec* fvB,
+                      float ratio, int checkOri, int32_t* matchOut, int* nmatches)
+{
+    if (!m || nA < 0 || nB < 0 || !fvA || !fvB || !nmatches) return ORB_ERR_INVALID;
+    const int nRes = kk ? nA : nB;
+    *nmatches = 0;
+    if (nRes > 0 && !matchOut) return ORB_ERR_INVALID;
+    for (int i = 0; i < nRes; i++) matchOut[i] = -1;
+    if (nA == 0 || nB == 0) return ORB_OK;
+    if (!descA || !descB || !angA || !angB) return ORB_ERR_INVALID;
+    if (nA > 32767 || nB > 32767) return ORB_ERR_UNSUPPORTED;
+    std::vector<uint16_t> nodeA, nodeB;
+    int nCommon = 0, rc;
+    if ((rc = csr_to_nodeof(fvA, nA, fvB, nB, nodeA, nodeB, nCommon)) != ORB_OK) return rc;
+    if (nCommon == 0) return ORB_OK;
+    ORB_HIP_TRY(hipSetDevice(m->device));
+    hipStream_t st = m->stream;
+    const size_t sz[10] = {(size_t)nA * 32, (size_t)nA * 4, (size_t)nA, (size_t)nA * 2,
+                           (size_t)nB * 32, (size_t)nB * 4, (size_t)nB, (size_t)nB * 2,
+                           sizeof(BowSide) * 2, (size_t)nRes * 4 + 4};
+    const void* src[8] = {descA, angA, validA, nodeA.data(), descB, angB, validB, nodeB.data()};
+    for (int i = 0; i < 10; i++)
+        if ((rc = m->stage[i].ensure(sz[i])) != ORB_OK) return rc;
+    for (int i = 0; i < 8; i++)
+        if (src[i]) ORB_HIP_TRY(hipMemcpyAsync(m->stage[i].p, src[i], sz[i], hipMemcpyHostToDevice, st));
+    BowSide sides[2];
+    sides[0] = {(const uint8_t*)m->stage[0].p, (const float*)m->stage[1].p, 1,
+                validA ? (const uint8_t*)m->stage[2].p : nullptr, (const uint16_t*)m->stage[3].p, nA};
+    sides[1] = {(const uint8_t*)m->stage[4].p, (const float*)m->stage[5].p, 1,
+                validB ? (const uint8_t*)m->stage[6].p : nullptr, (const uint16_t*)m->stage[7].p, nB};
+    ORB_HIP_TRY(hipMemcpyAsync(m->stage[8].p, sides, sizeof(sides), hipMemcpyHostToDevice, st));
+    int32_t* dOut = (int32_t*)m->stage[9].p;
+    const int capLds = std::max(nA, nB);
+    rc = launch_match(m, kk, (const BowSide*)m->stage[8].p, (const BowSide*)m->stage[8].p + 1, 1, nCommon, capLds, ratio,
+                      checkOri, dOut, nRes, dOut + nRes);
+    if (rc != ORB_OK) return rc;
+    std::vector<int32_t> host((size_t)nRes + 1);
+    ORB_HIP_TRY(hipMemcpyAsync(host.data(), dOut, ((size_t)nRes + 1) * 4, hipMemcpyDeviceToHost, st));
+    ORB_HIP_TRY(hipStreamSynchronize(st));
+    std::memcpy(matchOut, host.data(), (size_t)nRes * 4);
+    *nmatches = host[nRes];
+    return ORB_OK;
+}
+
+extern "C" int orb_match_bow(orb_matcher* m, const uint8_t* desc_kf, const float* angle_kf, const uint8_t* valid_kf,
+                             int n_kf, const orb_featvec* fv_kf, const uint8_t* desc_f, const float* angle_f, int n_f,
+                             const orb_featvec* fv_f, float ratio, int check_ori, int32_t* match_f, int* nmatches)
+{
+    return match_host(m, false, desc_kf, angle_kf, valid_kf, n_kf, fv_kf, desc_f, angle_f, nullptr, n_f, fv_f, ratio,
+                      check_ori, match_f, nmatches);
+}
+
+extern "C" int orb_match_bow_kk(orb_matcher* m, const uint8_t* desc1, const float* angle1, const uint8_t* valid1, int n1,
+                                const orb_featvec* fv1, const uint8_t* desc2, const float* angle2, const uint8_t* valid2,
+                                int n2, const orb_featvec* fv2, float ratio, int check_ori, int32_t* match_12,
+                                int* nmatches)
+{
+    return match_host(m, true, desc1, angle1, valid1, n1, fv1, desc2, angle2, valid2, n2, fv2, ratio, check_ori,
+                      match_12, nmatches);
+}
+
+// SearchForInitialization: implemented in orb_matcher_init.hip

@@ -1,0 +1,326 @@
+"""ctypes binding of liborbhip.so (include/orb_hip.h) -- thin plumbing used by tests and bench.py.
+
+The product is the C-ABI shared library; this module only marshals numpy arrays / raw device
+pointers into it.  It fails loudly when the library is missing or no GPU is usable: there is no
+CPU fallback anywhere on the product path.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # orb-slam2-chinesenotes_amd/
+LIB_PATH = os.path.join(PKG_DIR, "liborbhip.so")
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+
+ORB_OK = 0
+STATUS = {0: "ORB_OK", -1: "ORB_ERR_INVALID", -2: "ORB_ERR_HIP", -3: "ORB_ERR_NO_DEVICE",
+          -4: "ORB_ERR_CAPACITY", -5: "ORB_ERR_UNSUPPORTED", -6: "ORB_ERR_INTERNAL"}
+
+
+class OrbError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s (%d): %s" % (STATUS.get(code, "?"), code, msg))
+        self.code = code
+
+
+class Params(C.Structure):
+    _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32),
+                ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32)]
+
+
+class FeatVecC(C.Structure):
+    _fields_ = [("node_ids", C.c_void_p), ("offsets", C.c_void_p), ("indices", C.c_void_p), ("n_nodes", C.c_int32)]
+
+
+class FeatStoreC(C.Structure):
+    _fields_ = [("desc", C.c_void_p), ("kps", C.c_void_p), ("valid", C.c_void_p), ("counts", C.c_void_p),
+                ("node_of", C.c_void_p), ("cap", C.c_int32), ("n_frames", C.c_int32)]
+
+
+def build_library(force=False):
+    """hipcc cross-compiles for gfx950 without a GPU; output stays in-tree."""
+    args = ["make", "-C", PKG_DIR, "-j4", "liborbhip.so"]
+    if force:
+        subprocess.check_call(["make", "-C", PKG_DIR, "clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+# every symbol include/orb_hip.h declares
+SYMBOLS = [
+    "orb_extractor_create", "orb_extractor_destroy", "orb_extractor_get_tables", "orb_extractor_max_keypoints",
+    "orb_extractor_set_pattern", "orb_extractor_set_pattern_device", "orb_builtin_pattern", "orb_extract",
+    "orb_extract_batch", "orb_extract_batch_device", "orb_extractor_sync", "orb_get_pyramid_level",
+    "orb_get_level_counts", "orb_extractor_set_profiling", "orb_extractor_get_stage_ms", "orb_extractor_stream",
+    "orb_hamming", "orb_three_maxima", "orb_matcher_create", "orb_matcher_destroy", "orb_matcher_sync",
+    "orb_match_bow", "orb_match_bow_kk", "orb_match_init", "orb_bow_assign_device", "orb_match_bow_batch_device",
+    "orb_matcher_stream", "orb_last_error", "orb_version",
+]
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OrbError(-3, "liborbhip.so is not built (run __graft_entry__.build()); no CPU fallback exists")
+    try:                       # one HIP runtime per process: let torch's copy win if torch is around
+        import torch  # noqa: F401
+    except Exception:
+        pass
+    L = C.CDLL(LIB_PATH)
+    vp, ci, cf, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+    L.orb_extractor_create.argtypes = [C.POINTER(Params), ci, C.POINTER(vp)]
+    L.orb_extractor_destroy.argtypes = [vp]
+    L.orb_extractor_destroy.restype = None
+    L.orb_extractor_get_tables.argtypes = [vp] * 6
+    L.orb_extractor_max_keypoints.argtypes = [vp]
+    L.orb_extractor_set_pattern.argtypes = [vp, vp]
+    L.orb_extractor_set_pattern_device.argtypes = [vp, vp]
+    L.orb_builtin_pattern.argtypes = [vp]
+    L.orb_extract.argtypes = [vp, vp, ci, ci, sz, vp, vp, ci, C.POINTER(ci)]
+    L.orb_extract_batch.argtypes = [vp, vp, ci, ci, ci, sz, sz, vp, vp, ci, vp]
+    L.orb_extract_batch_device.argtypes = [vp, vp, ci, ci, ci, sz, sz, vp, vp, ci, vp]
+    L.orb_extractor_sync.argtypes = [vp]
+    L.orb_get_pyramid_level.argtypes = [vp, ci, ci, vp, sz, C.POINTER(ci), C.POINTER(ci)]
+    L.orb_get_level_counts.argtypes = [vp, ci, vp, vp]
+    L.orb_extractor_set_profiling.argtypes = [vp, ci]
+    L.orb_extractor_get_stage_ms.argtypes = [vp, vp]
+    L.orb_extractor_stream.argtypes = [vp]
+    L.orb_extractor_stream.restype = vp
+    L.orb_hamming.argtypes = [vp, vp]
+    L.orb_three_maxima.argtypes = [vp, vp]
+    L.orb_three_maxima.restype = None
+    L.orb_matcher_create.argtypes = [ci, C.POINTER(vp)]
+    L.orb_matcher_destroy.argtypes = [vp]
+    L.orb_matcher_destroy.restype = None
+    L.orb_matcher_sync.argtypes = [vp]
+    L.orb_match_bow.argtypes = [vp, vp, vp, vp, ci, C.POINTER(FeatVecC), vp, vp, ci, C.POINTER(FeatVecC), cf, ci, vp,
+                                C.POINTER(ci)]
+    L.orb_match_bow_kk.argtypes = [vp, vp, vp, vp, ci, C.POINTER(FeatVecC), vp, vp, vp, ci, C.POINTER(FeatVecC), cf, ci,
+                                   vp, C.POINTER(ci)]
+    L.orb_match_init.argtypes = [vp, vp, vp, ci, vp, vp, ci, vp, vp, ci, cf, ci, vp, C.POINTER(ci)]
+    L.orb_bow_assign_device.argtypes = [vp, vp, vp, ci, ci, vp, vp]
+    L.orb_match_bow_batch_device.argtypes = [vp, C.POINTER(FeatStoreC), vp, vp, ci, cf, ci, vp, vp]
+    L.orb_matcher_stream.argtypes = [vp]
+    L.orb_matcher_stream.restype = vp
+    L.orb_last_error.restype = C.c_char_p
+    L.orb_version.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != ORB_OK:
+        raise OrbError(rc, lib().orb_last_error().decode(errors="replace"))
+
+
+def _p(a):
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def builtin_pattern():
+    out = np.zeros(1024, np.int8)
+    _check(lib().orb_builtin_pattern(_p(out)))
+    return out
+
+
+def hamming(a, b):
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    return lib().orb_hamming(_p(a), _p(b))
+
+
+def three_maxima(counts):
+    counts = np.ascontiguousarray(counts, np.int32)
+    out = np.zeros(3, np.int32)
+    lib().orb_three_maxima(_p(counts), _p(out))
+    return tuple(int(v) for v in out)
+
+
+class Extractor:
+    """Mirror of ORB_SLAM2::ORBextractor (reference include/ORBextractor.h:46-112) over the C ABI."""
+
+    def __init__(self, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7, device=0):
+        self.L = lib()
+        self.h = C.c_void_p()
+        self.nlevels = nlevels
+        prm = Params(nfeatures, scale_factor, nlevels, ini_th, min_th)
+        _check(self.L.orb_extractor_create(C.byref(prm), device, C.byref(self.h)))
+        self.max_keypoints = self.L.orb_extractor_max_keypoints(self.h)
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.L.orb_extractor_destroy(self.h)
+            self.h = C.c_void_p()
+
+    __del__ = close
+
+    def tables(self):
+        n = self.nlevels
+        sc, inv, s2, is2 = (np.zeros(n, np.float32) for _ in range(4))
+        quota = np.zeros(n, np.int32)
+        _check(self.L.orb_extractor_get_tables(self.h, _p(sc), _p(inv), _p(s2), _p(is2), _p(quota)))
+        return dict(scale=sc, inv_scale=inv, sigma2=s2, inv_sigma2=is2, quota=quota)
+
+    def set_pattern(self, pattern):
+        pattern = np.ascontiguousarray(pattern, np.int8)
+        assert pattern.size == 1024
+        _check(self.L.orb_extractor_set_pattern(self.h, _p(pattern)))
+
+    def set_pattern_device(self, dptr):
+        _check(self.L.orb_extractor_set_pattern_device(self.h, C.c_void_p(dptr)))
+
+    def extract(self, img):
+        """== operator()(image, mask, keypoints, descriptors) on host buffers."""
+        img = np.asarray(img, dtype=np.uint8)
+        if img.size and img.strides[1] != 1:
+            img = np.ascontiguousarray(img)
+        cap = self.max_keypoints
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = C.c_int(0)
+        rows, cols = (img.shape if img.ndim == 2 else (0, 0))
+        stride = img.strides[0] if img.size else 0
+        _check(self.L.orb_extract(self.h, _p(img) if img.size else None, rows, cols, stride, _p(kps), _p(desc), cap,
+                                  C.byref(n)))
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def extract_batch(self, imgs):
+        imgs = np.ascontiguousarray(imgs, dtype=np.uint8)
+        f, rows, cols = imgs.shape
+        cap = self.max_keypoints
+        kps = np.zeros((f, cap), KP_DTYPE)
+        desc = np.zeros((f, cap, 32), np.uint8)
+        counts = np.zeros(f, np.int32)
+        _check(self.L.orb_extract_batch(self.h, _p(imgs), f, rows, cols, imgs.strides[1], imgs.strides[0], _p(kps),
+                                        _p(desc), cap, _p(counts)))
+        return [(kps[i, :counts[i]].copy(), desc[i, :counts[i]].copy()) for i in range(f)]
+
+    def extract_batch_device(self, d_imgs, n_frames, rows, cols, row_stride, frame_stride, d_kps, d_desc, cap, d_counts):
+        """Raw device pointers (ints); asynchronous on the handle's stream."""
+        _check(self.L.orb_extract_batch_device(self.h, C.c_void_p(d_imgs), n_frames, rows, cols, row_stride, frame_stride,
+                                               C.c_void_p(d_kps), C.c_void_p(d_desc), cap, C.c_void_p(d_counts)))
+
+    def sync(self):
+        _check(self.L.orb_extractor_sync(self.h))
+
+    def pyramid_level(self, frame, level):
+        r, c = C.c_int(), C.c_int()
+        _check(self.L.orb_get_pyramid_level(self.h, frame, level, None, 0, C.byref(r), C.byref(c)))
+        out = np.zeros((r.value, c.value), np.uint8)
+        _check(self.L.orb_get_pyramid_level(self.h, frame, level, _p(out), out.strides[0], C.byref(r), C.byref(c)))
+        return out
+
+    def level_counts(self, frame=0):
+        kept = np.zeros(self.nlevels, np.int32)
+        cands = np.zeros(self.nlevels, np.int32)
+        _check(self.L.orb_get_level_counts(self.h, frame, _p(kept), _p(cands)))
+        return kept, cands
+
+    def set_profiling(self, on=True):
+        _check(self.L.orb_extractor_set_profiling(self.h, int(on)))
+
+    def stage_ms(self):
+        ms = np.zeros(5, np.float32)
+        _check(self.L.orb_extractor_get_stage_ms(self.h, _p(ms)))
+        return ms
+
+    @property
+    def stream(self):
+        return self.L.orb_extractor_stream(self.h)
+
+
+def _fv(node_ids, offsets, indices):
+    node_ids = np.ascontiguousarray(node_ids, np.uint32)
+    offsets = np.ascontiguousarray(offsets, np.int32)
+    indices = np.ascontiguousarray(indices, np.int32)
+    s = FeatVecC(node_ids.ctypes.data, offsets.ctypes.data, indices.ctypes.data, node_ids.shape[0])
+    s._keep = (node_ids, offsets, indices)
+    return s
+
+
+class Matcher:
+    """Mirror of the descriptor-matching core of ORB_SLAM2::ORBmatcher (reference include/ORBmatcher.h:43-100)."""
+
+    TH_LOW, TH_HIGH, HISTO_LENGTH = 50, 100, 30
+
+    def __init__(self, nnratio=0.6, check_ori=True, device=0):
+        self.L = lib()
+        self.h = C.c_void_p()
+        self.nnratio = float(nnratio)
+        self.check_ori = bool(check_ori)
+        _check(self.L.orb_matcher_create(device, C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.L.orb_matcher_destroy(self.h)
+            self.h = C.c_void_p()
+
+    __del__ = close
+
+    def sync(self):
+        _check(self.L.orb_matcher_sync(self.h))
+
+    @property
+    def stream(self):
+        return self.L.orb_matcher_stream(self.h)
+
+    def search_by_bow(self, desc_kf, angle_kf, valid_kf, fv_kf, desc_f, angle_f, fv_f):
+        """fv_* = (node_ids, offsets, indices).  Returns (nmatches, match_f)."""
+        desc_kf = np.ascontiguousarray(desc_kf, np.uint8); desc_f = np.ascontiguousarray(desc_f, np.uint8)
+        angle_kf = np.ascontiguousarray(angle_kf, np.float32); angle_f = np.ascontiguousarray(angle_f, np.float32)
+        valid_kf = np.ascontiguousarray(valid_kf, np.uint8)
+        n_kf, n_f = desc_kf.shape[0], desc_f.shape[0]
+        out = np.full(max(n_f, 1), -1, np.int32)
+        nm = C.c_int(0)
+        a, b = _fv(*fv_kf), _fv(*fv_f)
+        _check(self.L.orb_match_bow(self.h, _p(desc_kf), _p(angle_kf), _p(valid_kf), n_kf, C.byref(a), _p(desc_f),
+                                    _p(angle_f), n_f, C.byref(b), self.nnratio, int(self.check_ori), _p(out), C.byref(nm)))
+        return nm.value, out[:n_f]
+
+    def search_by_bow_kk(self, d1, a1, v1, fv1, d2, a2, v2, fv2):
+        d1 = np.ascontiguousarray(d1, np.uint8); d2 = np.ascontiguousarray(d2, np.uint8)
+        a1 = np.ascontiguousarray(a1, np.float32); a2 = np.ascontiguousarray(a2, np.float32)
+        v1 = np.ascontiguousarray(v1, np.uint8); v2 = np.ascontiguousarray(v2, np.uint8)
+        n1, n2 = d1.shape[0], d2.shape[0]
+        out = np.full(max(n1, 1), -1, np.int32)
+        nm = C.c_int(0)
+        a, b = _fv(*fv1), _fv(*fv2)
+        _check(self.L.orb_match_bow_kk(self.h, _p(d1), _p(a1), _p(v1), n1, C.byref(a), _p(d2), _p(a2), _p(v2), n2,
+                                       C.byref(b), self.nnratio, int(self.check_ori), _p(out), C.byref(nm)))
+        return nm.value, out[:n1]
+
+    def search_for_initialization(self, k1, d1, k2, d2, grid, prev_xy, window=10):
+        k1 = np.ascontiguousarray(k1); k2 = np.ascontiguousarray(k2)
+        d1 = np.ascontiguousarray(d1, np.uint8); d2 = np.ascontiguousarray(d2, np.uint8)
+        grid = np.ascontiguousarray(grid, np.float32)
+        assert prev_xy.dtype == np.float32 and prev_xy.flags.c_contiguous
+        n1, n2 = k1.shape[0], k2.shape[0]
+        out = np.full(max(n1, 1), -1, np.int32)
+        nm = C.c_int(0)
+        _check(self.L.orb_match_init(self.h, _p(k1), _p(d1), n1, _p(k2), _p(d2), n2, _p(grid), _p(prev_xy), window,
+                                     self.nnratio, int(self.check_ori), _p(out), C.byref(nm)))
+        return nm.value, out[:n1]
+
+    def bow_assign_device(self, d_desc, d_counts, n_frames, cap, d_centroids, d_node_of):
+        _check(self.L.orb_bow_assign_device(self.h, C.c_void_p(d_desc), C.c_void_p(d_counts), n_frames, cap,
+                                            C.c_void_p(d_centroids), C.c_void_p(d_node_of)))
+
+    def match_bow_batch_device(self, store, d_kf_index, d_f_index, n_pairs, d_match, d_nmatches):
+        """store = dict(desc=, kps=, valid=, counts=, node_of=, cap=, n_frames=) of raw device pointers."""
+        s = FeatStoreC(store["desc"], store["kps"], store.get("valid") or None, store["counts"], store["node_of"],
+                       store["cap"], store["n_frames"])
+        _check(self.L.orb_match_bow_batch_device(self.h, C.byref(s), C.c_void_p(d_kf_index), C.c_void_p(d_f_index), n_pairs,
+                                                 self.nnratio, int(self.check_ori), C.c_void_p(d_match),
+                                                 C.c_void_p(d_nmatches)))

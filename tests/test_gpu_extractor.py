@@ -1,0 +1,119 @@
+"""GPU parity tests of the extractor: HIP path (through the C ABI) vs the CPU oracle, bit-exact."""
+import numpy as np
+import pytest
+
+import oracle
+from orbhip import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _cmp(img, nfeatures=1000, levels=8, ini=20, mn=7, sf=1.2):
+    ex = capi.Extractor(nfeatures, sf, levels, ini, mn)
+    ref = oracle.Extractor(nfeatures, sf, levels, ini, mn)
+    kps, desc = ex.extract(img)
+    rk, rd = ref.extract(img)
+    # stage by stage first, so a failure names the stage
+    for l in range(levels):
+        assert np.array_equal(ex.pyramid_level(0, l), ref.pyramid_level(l)), "pyramid level %d" % l
+    kept, cands = ex.level_counts(0)
+    rkept, rcands = ref.level_counts()
+    assert cands.tolist() == rcands.tolist(), "FAST candidates per level"
+    assert kept.tolist() == rkept.tolist(), "quadtree survivors per level"
+    assert len(kps) == len(rk)
+    for name in ("octave", "x", "y", "response", "size", "angle", "class_id"):
+        assert np.array_equal(kps[name], rk[name]), "keypoint field " + name
+    assert kps.tobytes() == rk.tobytes()
+    assert np.array_equal(desc, rd), "descriptors"
+    ex.close()
+    return len(kps)
+
+
+def test_tables_match_oracle():
+    ex = capi.Extractor()
+    t, r = ex.tables(), oracle.Extractor().tables()
+    for k in ("scale", "inv_scale", "sigma2", "inv_sigma2", "quota"):
+        assert np.array_equal(t[k], r[k]), k
+
+
+def test_frame0_640x480_bit_exact(frame0):
+    n = _cmp(frame0)
+    assert 990 <= n <= 1030
+
+
+@pytest.mark.parametrize("idx", [1, 2, 3, 7])
+def test_more_frames_640x480(idx):
+    _cmp(synth.synth_frame(idx))
+
+
+def test_kitti_size_1241x376_2000():
+    _cmp(synth.synth_frame(100, 1241, 376), nfeatures=2000)
+
+
+def test_euroc_size_752x480():
+    _cmp(synth.synth_frame(200, 752, 480))
+
+
+def test_small_and_odd_sizes():
+    _cmp(synth.synth_frame(5, 320, 240), nfeatures=500)
+    _cmp(synth.synth_frame(6, 333, 257), nfeatures=300)
+    _cmp(synth.synth_frame(8, 211, 157), nfeatures=200, levels=4)
+
+
+def test_flat_image_gives_no_keypoints():
+    img = np.full((480, 640), 90, np.uint8)
+    ex = capi.Extractor()
+    kps, desc = ex.extract(img)
+    assert len(kps) == 0 and desc.shape == (0, 32)
+
+
+def test_empty_image_is_silent_like_reference():
+    ex = capi.Extractor()
+    kps, desc = ex.extract(np.zeros((0, 0), np.uint8))
+    assert len(kps) == 0
+
+
+def test_noise_only_uses_min_threshold_fallback():
+    rng = np.random.default_rng(5)
+    img = (128 + rng.integers(-9, 10, (240, 320))).astype(np.uint8)
+    _cmp(img, nfeatures=500)
+
+
+def test_high_contrast_many_candidates():
+    rng = np.random.default_rng(7)
+    img = rng.integers(0, 256, (480, 640), dtype=np.uint8)      # > 4096 candidates on level 0: global-sort path
+    _cmp(img, nfeatures=1000)
+
+
+def test_strided_input_and_batch_equals_single():
+    base = synth.synth_batch(20, 3)
+    ex = capi.Extractor()
+    outs = ex.extract_batch(base)
+    ref = oracle.Extractor()
+    for i in range(3):
+        rk, rd = ref.extract(base[i])
+        assert outs[i][0].tobytes() == rk.tobytes() and np.array_equal(outs[i][1], rd)
+    wide = np.zeros((480, 700), np.uint8)
+    wide[:, :640] = base[1]
+    k2, d2 = ex.extract(wide[:, :640])                          # row stride 700
+    assert k2.tobytes() == outs[1][0].tobytes() and np.array_equal(d2, outs[1][1])
+
+
+def test_two_handles_two_threads():
+    # reference src/Frame.cc:82-85 runs the left/right extractors from two threads
+    import threading
+    imgs = [synth.synth_frame(30), synth.synth_frame(31)]
+    res = [None, None]
+
+    def work(i):
+        ex = capi.Extractor()
+        for _ in range(3):
+            res[i] = ex.extract(imgs[i])
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    ref = oracle.Extractor()
+    for i in range(2):
+        rk, rd = ref.extract(imgs[i])
+        assert res[i][0].tobytes() == rk.tobytes() and np.array_equal(res[i][1], rd)
