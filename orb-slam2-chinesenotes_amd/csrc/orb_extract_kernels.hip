@@ -158,47 +158,50 @@ __global__ __launch_bounds__(WAVE) void k_fast_cells(const OrbGeom G, const uint
         reinterpret_cast<uint32_t*>(smap)[idx] = 0;
     __syncthreads();
 
-    // ---- V for every zone pixel; count corners at iniTh
+    // ---- V for every zone pixel
     const uint8_t* tile = reinterpret_cast<const uint8_t*>(tileDw);
     const int npx = zw * zh;
     const unsigned invz = ((1u << 20) + zw - 1) / zw;
-    int nIni = 0;
     for (int base = 0; base < npx; base += WAVE) {
         const int idx = base + lane;
-        int S = 0;
         if (idx < npx) {
             const int py = (int)(((unsigned)idx * invz) >> 20);
             const int px = idx - py * zw;
-            S = max(fast_score_v(tile + (py + 3) * FAST_TP + xoff + px + 3, FAST_TP), 0);
+            const int S = max(fast_score_v(tile + (py + 3) * FAST_TP + xoff + px + 3, FAST_TP), 0);
             smap[(py + 1) * FAST_SP + px + 1] = (uint8_t)S;
         }
-        nIni += __popcll(__ballot(S > iniTh));
     }
-    const int th = (nIni > 0) ? iniTh : minTh;                     // reference :857-861
     __syncthreads();
 
-    // ---- cell-local 3x3 strict NMS on score = (V > th) ? V-1 : 0
+    // ---- cell-local 3x3 strict NMS on score = (V > th) ? V-1 : 0.  The reference re-runs cv::FAST
+    // with minThFAST when the iniThFAST call returns NO KEYPOINT (:857-861) -- i.e. after NMS, so a
+    // plateau of equal scores that suppresses itself also triggers the fallback.
     unsigned long long keep = 0;
     int total = 0, it = 0;
-    for (int base = 0; base < npx; base += WAVE, it++) {
-        const int idx = base + lane;
-        bool k = false;
-        if (idx < npx) {
-            const int py = (int)(((unsigned)idx * invz) >> 20);
-            const int px = idx - py * zw;
-            const uint8_t* s = smap + (py + 1) * FAST_SP + px + 1;
-            const int S = s[0];
-            if (S > th) {
-                const int sc = S - 1;
-                int m = 0;
+    for (int attempt = 0; attempt < 2 && total == 0; attempt++) {
+        const int th = attempt ? minTh : iniTh;
+        keep = 0;
+        it = 0;
+        for (int base = 0; base < npx; base += WAVE, it++) {
+            const int idx = base + lane;
+            bool k = false;
+            if (idx < npx) {
+                const int py = (int)(((unsigned)idx * invz) >> 20);
+                const int px = idx - py * zw;
+                const uint8_t* s = smap + (py + 1) * FAST_SP + px + 1;
+                const int S = s[0];
+                if (S > th) {
+                    const int sc = S - 1;
+                    int m = 0;
 #define NB(o) { const int v = s[o]; m = max(m, v > th ? v - 1 : 0); }
-                NB(-1) NB(1) NB(-FAST_SP - 1) NB(-FAST_SP) NB(-FAST_SP + 1) NB(FAST_SP - 1) NB(FAST_SP) NB(FAST_SP + 1)
+                    NB(-1) NB(1) NB(-FAST_SP - 1) NB(-FAST_SP) NB(-FAST_SP + 1) NB(FAST_SP - 1) NB(FAST_SP) NB(FAST_SP + 1)
 #undef NB
-                k = sc > m;
+                    k = sc > m;
+                }
             }
+            if (k) keep |= 1ull << it;
+            total += __popcll(__ballot(k));
         }
-        if (k) keep |= 1ull << it;
-        total += __popcll(__ballot(k));
     }
     if (total == 0) return;
 
