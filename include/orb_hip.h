@@ -114,15 +114,18 @@ int orb_get_pyramid_level(orb_extractor* h, int frame, int level, uint8_t* dst, 
  * of the last batch (nlevels entries each; either pointer may be NULL). */
 int orb_get_level_counts(orb_extractor* h, int frame, int32_t* kept, int32_t* candidates);
 
-/* Per-stage GPU time of the last batch in milliseconds (HIP events on the handle's stream),
- * stages: 0 pyramid, 1 FAST cells, 2 quadtree, 3 orientation+descriptors, 4 total.
- * Profiling must have been enabled before the batch was issued. */
+/* Per-stage GPU time in milliseconds (HIP events on the handle's stream), averaged over the
+ * batches issued since profiling was enabled (ring of the 64 most recent):
+ * stages: 0 pyramid, 1 FAST cells, 2 quadtree, 3 orientation+descriptors, 4 total. */
 int orb_extractor_set_profiling(orb_extractor* h, int enable);
 int orb_extractor_get_stage_ms(orb_extractor* h, float* ms5);
 
 /* The HIP stream (hipStream_t) the handle launches on, for callers that need to order their own
- * device work against it. */
+ * device work against it; and the reverse: make the handle's stream wait (on the device, no host
+ * sync) for everything already enqueued on another hipStream_t, e.g. the stream that uploaded the
+ * images or the extractor stream whose output the matcher consumes. */
 void* orb_extractor_stream(orb_extractor* h);
+int orb_extractor_wait_for(orb_extractor* h, void* hip_stream);
 
 /* ---------------------------------------------------------------- matcher ------------------
  * replaces: static int ORBmatcher::DescriptorDistance(const cv::Mat&, const cv::Mat&),
@@ -207,6 +210,7 @@ int orb_match_bow_batch_device(orb_matcher* m, const orb_featstore* store,
                                float ratio, int check_ori, int32_t* d_match, int32_t* d_nmatches);
 
 void* orb_matcher_stream(orb_matcher* m);
+int orb_matcher_wait_for(orb_matcher* m, void* hip_stream);
 
 /* ---------------------------------------------------------------- misc ---------------------*/
 const char* orb_last_error(void);   /* thread-local description of the last failure */

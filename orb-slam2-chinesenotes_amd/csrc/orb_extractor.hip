@@ -52,8 +52,11 @@ struct orb_extractor {
     orb_extractor_params prm;
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    bool profiling = false, profiled = false;
+    static const int kProfSlots = 64;
+    hipEvent_t ev[kProfSlots][5];           // ring of per-batch stage boundaries
+    hipEvent_t waitEv = nullptr;
+    bool profiling = false;
+    int profCount = 0;                      // batches recorded since profiling was (re)enabled
 
     // constructor tables (reference :503-558)
     std::vector<float> scale, invScale, sigma2, invSigma2;
@@ -320,7 +323,9 @@ extern "C" int orb_extractor_create(const orb_extractor_params* p, int device_id
     build_tables(h);
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete h; orb_set_error("hipStreamCreate: %s", hipGetErrorString(e)); return ORB_ERR_HIP; }
-    for (int i = 0; i < 5; i++) (void)hipEventCreate(&h->ev[i]);
+    for (int k = 0; k < orb_extractor::kProfSlots; k++)
+        for (int i = 0; i < 5; i++) (void)hipEventCreate(&h->ev[k][i]);
+    (void)hipEventCreateWithFlags(&h->waitEv, hipEventDisableTiming);
     int rc = h->dPattern.ensure(1024);
     if (rc == ORB_OK) {
         if (hipMemcpy(h->dPattern.p, ORB_BRIEF_PATTERN_XY, 1024, hipMemcpyHostToDevice) != hipSuccess) rc = ORB_ERR_HIP;
@@ -339,8 +344,10 @@ extern "C" void orb_extractor_destroy(orb_extractor* h)
     DevBuf* bufs[] = {&h->dPattern, &h->dCells, &h->dXtab, &h->dYtab, &h->dPyr, &h->dCand, &h->dKpl,
                       &h->dCandCount, &h->dKpCount, &h->dErr, &h->dImgs, &h->dKps, &h->dDesc, &h->dCounts};
     for (DevBuf* b : bufs) b->release();
-    for (int i = 0; i < 5; i++)
-        if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+    for (int k = 0; k < orb_extractor::kProfSlots; k++)
+        for (int i = 0; i < 5; i++)
+            if (h->ev[k][i]) (void)hipEventDestroy(h->ev[k][i]);
+    if (h->waitEv) (void)hipEventDestroy(h->waitEv);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -391,17 +398,40 @@ extern "C" int orb_extractor_set_profiling(orb_extractor* h, int enable)
 {
     if (!h) return ORB_ERR_INVALID;
     h->profiling = enable != 0;
-    h->profiled = false;
+    h->profCount = 0;
     return ORB_OK;
 }
 
+// average per-batch stage times over the (at most kProfSlots most recent) profiled batches
 extern "C" int orb_extractor_get_stage_ms(orb_extractor* h, float* ms5)
 {
     if (!h || !ms5) return ORB_ERR_INVALID;
-    if (!h->profiled) { orb_set_error("no profiled batch"); return ORB_ERR_INVALID; }
-    ORB_HIP_TRY(hipEventSynchronize(h->ev[4]));
-    for (int i = 0; i < 4; i++) ORB_HIP_TRY(hipEventElapsedTime(&ms5[i], h->ev[i], h->ev[i + 1]));
-    ORB_HIP_TRY(hipEventElapsedTime(&ms5[4], h->ev[0], h->ev[4]));
+    if (h->profCount == 0) { orb_set_error("no profiled batch"); return ORB_ERR_INVALID; }
+    ORB_HIP_TRY(hipSetDevice(h->device));
+    ORB_HIP_TRY(hipStreamSynchronize(h->stream));
+    const int n = std::min(h->profCount, (int)orb_extractor::kProfSlots);
+    double acc[5] = {0, 0, 0, 0, 0};
+    for (int k = 0; k < n; k++) {
+        const int slot = (h->profCount - 1 - k) % orb_extractor::kProfSlots;
+        float t;
+        for (int i = 0; i < 4; i++) {
+            ORB_HIP_TRY(hipEventElapsedTime(&t, h->ev[slot][i], h->ev[slot][i + 1]));
+            acc[i] += t;
+        }
+        ORB_HIP_TRY(hipEventElapsedTime(&t, h->ev[slot][0], h->ev[slot][4]));
+        acc[4] += t;
+    }
+    for (int i = 0; i < 5; i++) ms5[i] = (float)(acc[i] / n);
+    return ORB_OK;
+}
+
+// make this handle's stream wait for everything already enqueued on `other_stream` (hipStream_t)
+extern "C" int orb_extractor_wait_for(orb_extractor* h, void* other_stream)
+{
+    if (!h) return ORB_ERR_INVALID;
+    ORB_HIP_TRY(hipSetDevice(h->device));
+    ORB_HIP_TRY(hipEventRecord(h->waitEv, (hipStream_t)other_stream));
+    ORB_HIP_TRY(hipStreamWaitEvent(h->stream, h->waitEv, 0));
     return ORB_OK;
 }
 
@@ -431,24 +461,25 @@ extern "C" int orb_extract_batch_device(orb_extractor* h, const uint8_t* d_imgs,
 
     ORB_HIP_TRY(hipMemsetAsync(h->dCandCount.p, 0, (size_t)ORB_MAX_LEVELS * 4 * nFrames, st));
     ORB_HIP_TRY(hipMemsetAsync(h->dErr.p, 0, (size_t)4 * nFrames, st));
-    if (h->profiling) ORB_HIP_TRY(hipEventRecord(h->ev[0], st));
+    hipEvent_t* pe = h->ev[h->profCount % orb_extractor::kProfSlots];
+    if (h->profiling) ORB_HIP_TRY(hipEventRecord(pe[0], st));
     orb_launch_copy_level0(st, d_imgs, rowStride, frameStride, pyr, h->pyrSlab, G.L[0].w, G.L[0].h, G.L[0].pitch, nFrames);
     for (int l = 1; l < G.nlevels; l++)
         orb_launch_resize(st, pyr, h->pyrSlab, G.L[l - 1], G.L[l], (const int2*)h->dXtab.p + h->xtabOff[l],
                           (const int2*)h->dYtab.p + h->ytabOff[l], nFrames);
-    if (h->profiling) ORB_HIP_TRY(hipEventRecord(h->ev[1], st));
+    if (h->profiling) ORB_HIP_TRY(hipEventRecord(pe[1], st));
     orb_launch_fast_cells(st, G, pyr, h->pyrSlab, (const OrbCell*)h->dCells.p, (int)h->cells.size(),
                           (unsigned long long*)h->dCand.p, h->candSlab, (int*)h->dCandCount.p, (int*)h->dErr.p,
                           h->prm.ini_th_fast, h->prm.min_th_fast, nFrames);
-    if (h->profiling) ORB_HIP_TRY(hipEventRecord(h->ev[2], st));
+    if (h->profiling) ORB_HIP_TRY(hipEventRecord(pe[2], st));
     orb_launch_quadtree(st, G, (unsigned long long*)h->dCand.p, h->candSlab, (const int*)h->dCandCount.p,
                         (uint32_t*)h->dKpl.p, (int*)h->dKpCount.p, (int*)h->dErr.p, h->sortCap, h->nodeCap, nFrames);
-    if (h->profiling) ORB_HIP_TRY(hipEventRecord(h->ev[3], st));
+    if (h->profiling) ORB_HIP_TRY(hipEventRecord(pe[3], st));
     orb_launch_orient_desc(st, G, pyr, h->pyrSlab, (const uint32_t*)h->dKpl.p, (const int*)h->dKpCount.p,
                            h->patternPtr, d_kps, d_desc, cap, d_counts, (int*)h->dErr.p, nFrames);
     if (h->profiling) {
-        ORB_HIP_TRY(hipEventRecord(h->ev[4], st));
-        h->profiled = true;
+        ORB_HIP_TRY(hipEventRecord(pe[4], st));
+        h->profCount++;
     }
     ORB_HIP_TRY(hipGetLastError());
     h->lastFrames = nFrames;

@@ -344,6 +344,7 @@ struct orb_matcher {
     MBuf sidesA, sidesB;                 // BowSide arrays
     MBuf stage[12];                      // host-API staging
     MBuf out, nm;
+    hipEvent_t waitEv = nullptr;
 };
 
 static size_t match_lds_bytes(int capLds, int nNodes)
@@ -368,7 +369,17 @@ extern "C" int orb_matcher_create(int device_id, orb_matcher** out)
     m->device = device_id;
     hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete m; orb_set_error("hipStreamCreate: %s", hipGetErrorString(e)); return ORB_ERR_HIP; }
+    (void)hipEventCreateWithFlags(&m->waitEv, hipEventDisableTiming);
     *out = m;
+    return ORB_OK;
+}
+
+extern "C" int orb_matcher_wait_for(orb_matcher* m, void* other_stream)
+{
+    if (!m) return ORB_ERR_INVALID;
+    ORB_HIP_TRY(hipSetDevice(m->device));
+    ORB_HIP_TRY(hipEventRecord(m->waitEv, (hipStream_t)other_stream));
+    ORB_HIP_TRY(hipStreamWaitEvent(m->stream, m->waitEv, 0));
     return ORB_OK;
 }
 
@@ -379,6 +390,7 @@ extern "C" void orb_matcher_destroy(orb_matcher* m)
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     m->sidesA.release(); m->sidesB.release(); m->out.release(); m->nm.release();
     for (auto& b : m->stage) b.release();
+    if (m->waitEv) (void)hipEventDestroy(m->waitEv);
     if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
 }

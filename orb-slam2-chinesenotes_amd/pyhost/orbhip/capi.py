@@ -60,7 +60,7 @@ SYMBOLS = [
     "orb_get_level_counts", "orb_extractor_set_profiling", "orb_extractor_get_stage_ms", "orb_extractor_stream",
     "orb_hamming", "orb_three_maxima", "orb_matcher_create", "orb_matcher_destroy", "orb_matcher_sync",
     "orb_match_bow", "orb_match_bow_kk", "orb_match_init", "orb_bow_assign_device", "orb_match_bow_batch_device",
-    "orb_matcher_stream", "orb_last_error", "orb_version",
+    "orb_matcher_stream", "orb_extractor_wait_for", "orb_matcher_wait_for", "orb_last_error", "orb_version",
 ]
 
 
@@ -110,6 +110,8 @@ def lib():
     L.orb_match_bow_batch_device.argtypes = [vp, C.POINTER(FeatStoreC), vp, vp, ci, cf, ci, vp, vp]
     L.orb_matcher_stream.argtypes = [vp]
     L.orb_matcher_stream.restype = vp
+    L.orb_extractor_wait_for.argtypes = [vp, vp]
+    L.orb_matcher_wait_for.argtypes = [vp, vp]
     L.orb_last_error.restype = C.c_char_p
     L.orb_version.restype = C.c_char_p
     _lib = L
@@ -240,6 +242,9 @@ class Extractor:
     def stream(self):
         return self.L.orb_extractor_stream(self.h)
 
+    def wait_for(self, hip_stream):
+        _check(self.L.orb_extractor_wait_for(self.h, C.c_void_p(hip_stream)))
+
 
 def _fv(node_ids, offsets, indices):
     node_ids = np.ascontiguousarray(node_ids, np.uint32)
@@ -275,6 +280,9 @@ class Matcher:
     @property
     def stream(self):
         return self.L.orb_matcher_stream(self.h)
+
+    def wait_for(self, hip_stream):
+        _check(self.L.orb_matcher_wait_for(self.h, C.c_void_p(hip_stream)))
 
     def search_by_bow(self, desc_kf, angle_kf, valid_kf, fv_kf, desc_f, angle_f, fv_f):
         """fv_* = (node_ids, offsets, indices).  Returns (nmatches, match_f)."""

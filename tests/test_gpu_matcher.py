@@ -1,0 +1,101 @@
+"""GPU parity tests of the matcher: HIP kernels through the C ABI vs the CPU oracle, bit-exact
+match indices and counts."""
+import numpy as np
+import pytest
+
+import oracle
+from orbhip import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def feats():
+    """Features of a few related frames (oracle-extracted: the matcher tests must not depend on the
+    extractor kernels being right).  Frame k+100 is frame k with fresh noise -> many true matches."""
+    ref = oracle.Extractor()
+    out = []
+    base = synth.synth_frame(0, noise=0).astype(np.int16)
+    for s in range(4):
+        nz = (synth.splitmix64(1234 + s, 0, base.size) % np.uint64(13)).astype(np.int16).reshape(base.shape) - 6
+        img = np.clip(base + nz, 0, 255).astype(np.uint8)
+        if s == 3:
+            img = np.roll(img, 7, axis=1)
+        out.append(ref.extract(img))
+    return out
+
+
+def _fv(desc):
+    fv = oracle.bow_transform(desc, synth.synth_vocabulary())
+    return fv, (fv.node_ids, fv.offsets, fv.indices)
+
+
+@pytest.mark.parametrize("ratio,ori", [(0.7, True), (0.75, True), (0.9, False), (0.6, True)])
+def test_search_by_bow_kf_frame(feats, ratio, ori):
+    m = capi.Matcher(ratio, ori)
+    for a, b in [(0, 1), (1, 2), (2, 3), (3, 0)]:
+        (ka, da), (kb, db) = feats[a], feats[b]
+        fva, ta = _fv(da)
+        fvb, tb = _fv(db)
+        valid = synth.synth_valid_flags(len(ka), a)
+        want_n, want = oracle.search_by_bow(da, ka["angle"], valid, fva, db, kb["angle"], fvb, ratio, ori)
+        got_n, got = m.search_by_bow(da, ka["angle"], valid, ta, db, kb["angle"], tb)
+        assert want_n > 50
+        assert got_n == want_n
+        assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("ratio,ori", [(0.75, True), (0.8, False)])
+def test_search_by_bow_kf_kf(feats, ratio, ori):
+    m = capi.Matcher(ratio, ori)
+    for a, b in [(0, 1), (2, 1), (3, 2)]:
+        (ka, da), (kb, db) = feats[a], feats[b]
+        fva, ta = _fv(da)
+        fvb, tb = _fv(db)
+        va = synth.synth_valid_flags(len(ka), 10 + a)
+        vb = synth.synth_valid_flags(len(kb), 20 + b)
+        want_n, want = oracle.search_by_bow_kk(da, ka["angle"], va, fva, db, kb["angle"], vb, fvb, ratio, ori)
+        got_n, got = m.search_by_bow_kk(da, ka["angle"], va, ta, db, kb["angle"], vb, tb)
+        assert want_n > 30
+        assert got_n == want_n
+        assert np.array_equal(got, want)
+
+
+def test_bow_edge_cases(feats):
+    m = capi.Matcher(0.7, True)
+    (ka, da), (kb, db) = feats[0], feats[1]
+    fva, ta = _fv(da)
+    fvb, tb = _fv(db)
+    # nothing valid on the keyframe side -> no matches
+    n, out = m.search_by_bow(da, ka["angle"], np.zeros(len(ka), np.uint8), ta, db, kb["angle"], tb)
+    assert n == 0 and np.all(out == -1)
+    # empty frame
+    e = (np.zeros(0, np.uint32), np.zeros(1, np.int32), np.zeros(0, np.int32))
+    n, out = m.search_by_bow(da, ka["angle"], np.ones(len(ka), np.uint8), ta, np.zeros((0, 32), np.uint8),
+                             np.zeros(0, np.float32), e)
+    assert n == 0 and len(out) == 0
+    # disjoint vocabularies -> the merge walk never meets
+    tb2 = (tb[0] + 1000, tb[1], tb[2])
+    n, out = m.search_by_bow(da, ka["angle"], np.ones(len(ka), np.uint8), ta, db, kb["angle"], tb2)
+    assert n == 0 and np.all(out == -1)
+    # identical frames: every valid feature whose node-mates are not too similar matches itself
+    valid = np.ones(len(ka), np.uint8)
+    want_n, want = oracle.search_by_bow(da, ka["angle"], valid, fva, da, ka["angle"], fva, 0.7, True)
+    n, out = m.search_by_bow(da, ka["angle"], valid, ta, da, ka["angle"], ta)
+    assert n == want_n and np.array_equal(out, want)
+    assert np.all(out[out >= 0] == np.nonzero(out >= 0)[0])
+
+
+def test_one_big_node_more_than_64_features(feats):
+    # all features in one vocabulary node: exercises the > 64-lane chunk loop and the greedy order
+    m = capi.Matcher(0.8, True)
+    (ka, da), (kb, db) = feats[0], feats[1]
+    na, nb = 300, 333
+    fa = (np.array([7], np.uint32), np.array([0, na], np.int32), np.arange(na, dtype=np.int32))
+    fb = (np.array([7], np.uint32), np.array([0, nb], np.int32), np.arange(nb, dtype=np.int32))
+    valid = synth.synth_valid_flags(na, 3)
+    want_n, want = oracle.search_by_bow(da[:na], ka["angle"][:na], valid, oracle.FeatVec(*fa), db[:nb],
+                                        kb["angle"][:nb], oracle.FeatVec(*fb), 0.8, True)
+    n, out = m.search_by_bow(da[:na], ka["angle"][:na], valid, fa, db[:nb], kb["angle"][:nb], fb)
+    assert want_n > 20
+    assert n == want_n and np.array_equal(out, want)
