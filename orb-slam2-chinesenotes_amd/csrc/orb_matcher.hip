@@ -17,7 +17,7 @@
 #include <new>
 #include <vector>
 
-#include "orb_common.h"
+#include "orb_matcher_internal.h"
 
 #pragma clang fp contract(off)
 
@@ -324,29 +324,6 @@ __global__ void k_fill_sides(orb_featstore S, const int32_t* __restrict__ kfInde
 }
 
 // ------------------------------------------------------------------ host side
-struct MBuf {
-    void* p = nullptr;
-    size_t bytes = 0;
-    int ensure(size_t need)
-    {
-        if (need <= bytes) return ORB_OK;
-        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
-        ORB_HIP_TRY(hipMalloc(&p, need));
-        bytes = need;
-        return ORB_OK;
-    }
-    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
-};
-
-struct orb_matcher {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    MBuf sidesA, sidesB;                 // BowSide arrays
-    MBuf stage[12];                      // host-API staging
-    MBuf out, nm;
-    hipEvent_t waitEv = nullptr;
-};
-
 static size_t match_lds_bytes(int capLds, int nNodes)
 {
     size_t u16s = (size_t)capLds * 7 + (capLds & 1) + 2 * (size_t)(nNodes + 2);
@@ -390,6 +367,7 @@ extern "C" void orb_matcher_destroy(orb_matcher* m)
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     m->sidesA.release(); m->sidesB.release(); m->out.release(); m->nm.release();
     for (auto& b : m->stage) b.release();
+    for (auto& b : m->init) b.release();
     if (m->waitEv) (void)hipEventDestroy(m->waitEv);
     if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;

@@ -1,0 +1,27 @@
+// orb_matcher_internal.h -- the matcher handle, shared by orb_matcher.hip and orb_matcher_init.hip.
+#pragma once
+#include "orb_common.h"
+
+struct MBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need)
+    {
+        if (need <= bytes) return ORB_OK;
+        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+        ORB_HIP_TRY(hipMalloc(&p, need));
+        bytes = need;
+        return ORB_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+
+struct orb_matcher {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    MBuf sidesA, sidesB;                 // BowSide arrays of a batch
+    MBuf stage[12];                      // host-API staging (SearchByBoW)
+    MBuf init[12];                       // host-API staging + scratch (SearchForInitialization)
+    MBuf out, nm;
+    hipEvent_t waitEv = nullptr;
+};

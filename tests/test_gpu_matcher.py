@@ -99,3 +99,58 @@ def test_one_big_node_more_than_64_features(feats):
     n, out = m.search_by_bow(da[:na], ka["angle"][:na], valid, fa, db[:nb], kb["angle"][:nb], fb)
     assert want_n > 20
     assert n == want_n and np.array_equal(out, want)
+
+
+@pytest.fixture(scope="module")
+def feats2000():
+    ref = oracle.Extractor(2000, 1.2, 8, 20, 7)         # Tracking.cc:121 builds the init extractor with 2x features
+    base = synth.synth_frame(40, noise=0).astype(np.int16)
+    out = []
+    for s, shift in [(0, 0), (1, 5), (2, 23)]:
+        nz = (synth.splitmix64(777 + s, 0, base.size) % np.uint64(13)).astype(np.int16).reshape(base.shape) - 6
+        img = np.clip(np.roll(base, shift, axis=1) + nz, 0, 255).astype(np.uint8)
+        out.append(ref.extract(img))
+    return out
+
+
+GRID_640 = (0.0, 0.0, 64.0 / 640.0, 48.0 / 480.0)
+
+
+@pytest.mark.parametrize("window,ratio,ori", [(100, 0.9, True), (30, 0.9, True), (100, 0.8, False), (10, 0.9, True)])
+def test_search_for_initialization(feats2000, window, ratio, ori):
+    m = capi.Matcher(ratio, ori)
+    for a, b in [(0, 1), (0, 2), (1, 0)]:
+        (k1, d1), (k2, d2) = feats2000[a], feats2000[b]
+        prev_ref = np.ascontiguousarray(np.stack([k1["x"], k1["y"]], axis=1), dtype=np.float32)
+        prev_gpu = prev_ref.copy()
+        want_n, want = oracle.search_for_init(k1, d1, k2, d2, GRID_640, prev_ref, window, ratio, ori)
+        got_n, got = m.search_for_initialization(k1, d1, k2, d2, GRID_640, prev_gpu, window)
+        assert got_n == want_n
+        assert np.array_equal(got, want)
+        assert prev_gpu.tobytes() == prev_ref.tobytes()
+        if window >= 30:
+            assert want_n > 40
+        # second call with the updated vbPrevMatched, as MonocularInitialization does on the next frame
+        want_n2, want2 = oracle.search_for_init(k1, d1, k2, d2, GRID_640, prev_ref, window, ratio, ori)
+        got_n2, got2 = m.search_for_initialization(k1, d1, k2, d2, GRID_640, prev_gpu, window)
+        assert got_n2 == want_n2 and np.array_equal(got2, want2) and prev_gpu.tobytes() == prev_ref.tobytes()
+
+
+def test_search_for_initialization_edges(feats2000):
+    m = capi.Matcher(0.9, True)
+    (k1, d1), (k2, d2) = feats2000[0], feats2000[1]
+    prev = np.ascontiguousarray(np.stack([k1["x"], k1["y"]], axis=1), dtype=np.float32)
+    n, out = m.search_for_initialization(k1, d1, k2[:0], d2[:0], GRID_640, prev.copy(), 100)
+    assert n == 0 and np.all(out == -1)
+    # windows entirely outside the grid
+    far = prev.copy() + 5000
+    p2 = far.copy()
+    wn, w = oracle.search_for_init(k1, d1, k2, d2, GRID_640, far, 100, 0.9, True)
+    n, out = m.search_for_initialization(k1, d1, k2, d2, GRID_640, p2, 100)
+    assert n == wn == 0 and np.array_equal(out, w)
+    # a grid with an offset / different cell size (undistorted image bounds, Frame.cc:108-109)
+    g = (-12.5, -7.25, 64.0 / 670.0, 48.0 / 495.0)
+    pr, pg = prev.copy(), prev.copy()
+    wn, w = oracle.search_for_init(k1, d1, k2, d2, g, pr, 60, 0.9, True)
+    n, out = m.search_for_initialization(k1, d1, k2, d2, g, pg, 60)
+    assert n == wn and np.array_equal(out, w) and pg.tobytes() == pr.tobytes()
