@@ -25,7 +25,7 @@ sys.path.insert(0, os.path.join(ROOT, "orb-slam2-chinesenotes_amd", "pyhost"))
 import numpy as np
 import torch
 
-from orbhip import capi, synth
+from orbhip import capi, shard, synth
 
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 
@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames-per-gpu", type=int, default=64)
+    ap.add_argument("--frames-per-gpu", type=int, default=512)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--nfeatures", type=int, default=1000)
@@ -71,13 +71,13 @@ def main():
     pat = torch.zeros(1024, dtype=torch.int8, device=dev)
     if rank == 0:
         pat.copy_(torch.from_numpy(capi.builtin_pattern()))
-    if dist is not None:
-        dist.broadcast(pat, src=0)
+    shard.broadcast_pattern(dist, pat, 0)
     torch.cuda.synchronize()
     ex.set_pattern_device(pat.data_ptr())
 
     # ---- synthetic inputs, resident in HBM before the timed region
-    frames_np = synth.synth_batch(rank * B, B, W, H)
+    first, _ = shard.weak_range(B, rank)            # weak scaling: every rank owns B frames of its own
+    frames_np = synth.synth_batch(first, B, W, H)
     d_imgs = torch.from_numpy(frames_np).to(dev)
     d_kps = torch.zeros(B * cap * 28, dtype=torch.uint8, device=dev)
     d_desc = torch.zeros(B * cap * 32, dtype=torch.uint8, device=dev)
@@ -122,10 +122,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = shard.max_over_ranks(dist, elapsed, dev)
+    frames_done = shard.sum_over_ranks(dist, B * args.steps, dev)
 
     stage_ms = ex.stage_ms()                       # HIP events on the extractor's own stream
     ex.set_profiling(False)
@@ -139,7 +137,7 @@ def main():
             dist.destroy_process_group()
         return
 
-    total_frames = B * args.steps * world
+    total_frames = frames_done
     fps = total_frames / elapsed
     names = ["pyramid(k_copy_level0+7x k_resize_level)", "k_fast_cells", "k_quadtree", "k_orient_desc"]
     dom = int(np.argmax(stage_ms[:4]))

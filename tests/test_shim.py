@@ -1,0 +1,97 @@
+"""The C++ drop-in shims (orb-slam2-chinesenotes_amd/host/: ORBextractor with the reference's class
+signature, four ORBmatcher member functions) built against test doubles of the cv:: / SLAM types.
+CPU: they compile and link against liborbhip.so.  GPU: driven the way Frame.cc / Tracking.cc drive the
+reference classes, results bit-exact vs the CPU oracle."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle
+from orbhip import capi, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SUP = os.path.join(ROOT, "tests", "support")
+DRIVER = os.path.join(SUP, "shim_driver")
+PKG = os.path.join(ROOT, "orb-slam2-chinesenotes_amd")
+
+
+def build_driver():
+    capi.build_library()
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-I" + SUP, "-I" + os.path.join(SUP, "mini_slam"),
+           "-I" + os.path.join(PKG, "host"), "-I" + os.path.join(ROOT, "include"),
+           os.path.join(SUP, "shim_driver.cpp"), os.path.join(PKG, "host", "ORBextractor.cc"),
+           os.path.join(PKG, "host", "ORBmatcherHip.cc"), "-L" + PKG, "-lorbhip", "-Wl,-rpath," + PKG, "-o", DRIVER]
+    subprocess.check_call(cmd)
+    return DRIVER
+
+
+def test_shims_compile_and_link():
+    assert os.path.exists(build_driver())
+
+
+@pytest.mark.gpu
+def test_extractor_shim_matches_oracle(tmp_path):
+    build_driver()
+    img = synth.synth_frame(11)
+    wide = np.zeros((480, 704), np.uint8)
+    wide[:, :640] = img
+    raw = tmp_path / "in.raw"
+    wide.tofile(raw)
+    out = str(tmp_path / "o")
+    subprocess.check_call([DRIVER, "extract", str(raw), "640", "480", "704", "1000", out])
+    kps = np.fromfile(out + ".kps", dtype=oracle.KP_DTYPE)
+    desc = np.fromfile(out + ".desc", dtype=np.uint8).reshape(-1, 32)
+    ref = oracle.Extractor()
+    rk, rd = ref.extract(img)
+    assert kps.tobytes() == rk.tobytes() and np.array_equal(desc, rd)
+    pyr = np.fromfile(out + ".pyr", dtype=np.uint8)
+    want = np.concatenate([ref.pyramid_level(l).ravel() for l in range(8)])
+    assert np.array_equal(pyr, want)                       # mvImagePyramid as Frame::ComputeStereoMatches reads it
+
+
+@pytest.mark.gpu
+def test_matcher_shim_matches_oracle(tmp_path):
+    build_driver()
+    ref = oracle.Extractor(2000, 1.2, 8, 20, 7)
+    base = synth.synth_frame(50, noise=0).astype(np.int16)
+    feats = []
+    for s in range(2):
+        nz = (synth.splitmix64(99 + s, 0, base.size) % np.uint64(13)).astype(np.int16).reshape(base.shape) - 6
+        feats.append(ref.extract(np.clip(np.roll(base, 4 * s, axis=1) + nz, 0, 255).astype(np.uint8)))
+    (k1, d1), (k2, d2) = feats
+    cent = synth.synth_vocabulary()
+    fv1, fv2 = oracle.bow_transform(d1, cent), oracle.bow_transform(d2, cent)
+
+    def node_of(fv, n):
+        out = np.full(n, -1, np.int32)
+        for k, nid in enumerate(fv.node_ids):
+            out[fv.indices[fv.offsets[k]:fv.offsets[k + 1]]] = nid
+        return out
+
+    # valid: 0 = no MapPoint, 1 = good MapPoint, 2 = MapPoint with isBad()
+    rng = np.random.default_rng(4)
+    v1 = rng.choice([0, 1, 1, 1, 2], len(k1)).astype(np.uint8)
+    v2 = rng.choice([0, 1, 1, 1, 2], len(k2)).astype(np.uint8)
+    ratio, ori, window = 0.8, 1, 100
+    grid = (0.0, 0.0, 64.0 / 640.0, 48.0 / 480.0)
+    blob = struct.pack("<iifii4f", len(k1), len(k2), ratio, ori, window, *grid)
+    for k, d, v, fv in ((k1, d1, v1, fv1), (k2, d2, v2, fv2)):
+        blob += k.tobytes() + d.tobytes() + v.tobytes() + node_of(fv, len(k)).tobytes()
+    scene = tmp_path / "scene.bin"
+    scene.write_bytes(blob)
+    out = str(tmp_path / "m")
+    subprocess.check_call([DRIVER, "match", str(scene), out])
+    counts = np.fromfile(out + ".counts", dtype=np.int32)
+    na, ma = oracle.search_by_bow(d1, k1["angle"], v1 == 1, fv1, d2, k2["angle"], fv2, ratio, True)
+    nb, mb = oracle.search_by_bow_kk(d1, k1["angle"], v1 == 1, fv1, d2, k2["angle"], v2 == 1, fv2, ratio, True)
+    prev = np.ascontiguousarray(np.stack([k1["x"], k1["y"]], axis=1), dtype=np.float32)
+    nc, mc = oracle.search_for_init(k1, d1, k2, d2, grid, prev, window, ratio, True)
+    assert counts.tolist() == [na, nb, nc, oracle.hamming(d1[0], d2[0])]
+    assert na > 30 and nb > 20 and nc > 30
+    assert np.array_equal(np.fromfile(out + ".bowkf", dtype=np.int32), ma)
+    assert np.array_equal(np.fromfile(out + ".bowkk", dtype=np.int32), mb)
+    assert np.array_equal(np.fromfile(out + ".init", dtype=np.int32), mc)
+    assert np.fromfile(out + ".prev", dtype=np.float32).tobytes() == prev.tobytes()
