@@ -215,3 +215,31 @@ int orbref_features_in_area(const KeyPoint* k, int n, float minX, float minY, fl
 }
 
 }  // extern "C"
+
+// Pin of include/orb_sincos.h: walks the float bit patterns [loBits, hiBits] of the ANGLE IN DEGREES with
+// the given stride, converts to radians exactly as computeOrbDescriptor does (src/ORBextractor.cc:124), and
+// counts inputs where cos or sin differs from
+//   mode 0: the correctly rounded value, taken as (float)cos((double)rad) / (float)sin((double)rad)
+//   mode 1: the host libm's cosf/sinf (what the reference itself calls at :125; glibc documents <= 1 ulp,
+//           i.e. it is NOT always correctly rounded)
+#include <cmath>
+extern "C" long orbref_sincos_sweep(uint32_t loBits, uint32_t hiBits, uint32_t stride, int mode, uint32_t* firstBad)
+{
+    const float factorPI = (float)(3.14159265358979323846 / 180.f);
+    long bad = 0;
+    for (uint64_t b = loBits; b <= hiBits; b += stride) {
+        uint32_t bits = (uint32_t)b;
+        float deg;
+        std::memcpy(&deg, &bits, 4);
+        const float rad = deg * factorPI;
+        float c, s;
+        orb_sincos(rad, &c, &s);
+        const float rc = mode ? cosf(rad) : (float)cos((double)rad);
+        const float rs = mode ? sinf(rad) : (float)sin((double)rad);
+        if (c != rc || s != rs) {
+            if (bad == 0 && firstBad) *firstBad = bits;
+            bad++;
+        }
+    }
+    return bad;
+}
