@@ -4,7 +4,7 @@
 // Stage map (reference src/ORBextractor.cc):
 //   k_copy_level0 / k_resize_level   ComputePyramid            :1153-1180  (cv::resize INTER_LINEAR)
 //   k_fast_cells                     per-cell cv::FAST + fallback + NMS :795-875
-//   k_quadtree                       DistributeOctTree / DivideNode      :436-495, :562-792
+//   (k_quadtree lives in orb_quadtree.hip)
 //   k_orient_desc                    IC_Angle, GaussianBlur, computeOrbDescriptor, operator() tail
 //                                    :78-171, :1118-1148
 // Every kernel takes blockIdx.y (or .z) = frame: batched frames are independent.
@@ -235,244 +235,6 @@ __global__ __launch_bounds__(WAVE) void k_fast_cells(const OrbGeom G, const uint
 }
 
 // ------------------------------------------------------------------------------------------------
-// Quadtree keypoint distribution.  One 256-thread workgroup per (frame, level).
-//
-// The reference splits std::list nodes and copies key vectors (:436-495).  Here every candidate
-// carries its quadrant path, so after ONE sort by key every node of the tree -- at any depth --
-// is a contiguous range [lo,hi) of the sorted array and DivideNode is three binary searches on a
-// 2-bit digit.  The list evolution itself (push_front order, erase, the "expand the largest nodes
-// first" phase with its (size, creation-order) tie-break) is replayed exactly by one
-// thread on {lo,hi,depth} triples; the sort and the final per-node arg-max run on all threads.
-struct QtNode {
-    int lo, hi;
-    short depth;
-    short dead;
-    int seq;
-};
-
-__device__ __forceinline__ unsigned key_digit(unsigned long long k, int depth)
-{
-    return (unsigned)(k >> (ORB_KEY_PATH_SHIFT + 2 * (ORB_KEY_PATH_LEVELS - 1 - depth))) & 3u;
-}
-
-// first index in [lo,hi) whose digit at `depth` is >= q
-__device__ int lower_digit(const unsigned long long* keys, int lo, int hi, int depth, unsigned q)
-{
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (key_digit(keys[mid], depth) < q) lo = mid + 1; else hi = mid;
-    }
-    return lo;
-}
-
-// ascending bitonic sort of a[0..n) for arbitrary n (all merges ascending, virtual +inf padding)
-__device__ void block_sort_u64(unsigned long long* a, int n)
-{
-    int np2 = 1;
-    while (np2 < n) np2 <<= 1;
-    for (int k = 2; k <= np2; k <<= 1) {
-        for (int i = threadIdx.x; i < np2; i += blockDim.x) {
-            const int p = i ^ (k - 1);
-            if (p > i && p < n) {
-                const unsigned long long x = a[i], y = a[p];
-                if (x > y) { a[i] = y; a[p] = x; }
-            }
-        }
-        __syncthreads();
-        for (int j = k >> 2; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < np2; i += blockDim.x) {
-                const int p = i ^ j;
-                if (p > i && p < n) {
-                    const unsigned long long x = a[i], y = a[p];
-                    if (x > y) { a[i] = y; a[p] = x; }
-                }
-            }
-            __syncthreads();
-        }
-    }
-}
-
-// Divide node `nd` (reference DivideNode): append its non-empty children to S, register the
-// multi-key ones in `prev` as (size<<48 | seq<<24 | S-index).  Returns number of non-empty children.
-__device__ int qt_divide(const unsigned long long* keys, const QtNode nd, QtNode* S, int& sCount,
-                         unsigned long long* prev, int& prevCount, int& seq, int& nExpand)
-{
-    int cut[5];
-    cut[0] = nd.lo;
-    cut[4] = nd.hi;
-    if (nd.depth >= ORB_KEY_PATH_LEVELS) {        // unreachable inside the supported image envelope
-        cut[1] = cut[2] = cut[3] = nd.hi;
-    } else {
-        cut[2] = lower_digit(keys, nd.lo, nd.hi, nd.depth, 2);
-        cut[1] = lower_digit(keys, nd.lo, cut[2], nd.depth, 1);
-        cut[3] = lower_digit(keys, cut[2], nd.hi, nd.depth, 3);
-    }
-    int made = 0;
-    for (int q = 0; q < 4; q++) {
-        const int a = cut[q], b = cut[q + 1];
-        if (b <= a) continue;
-        QtNode c;
-        c.lo = a; c.hi = b; c.depth = (short)(nd.depth + 1); c.dead = 0; c.seq = seq++;
-        if (b - a > 1) {
-            nExpand++;
-            prev[prevCount++] = ((unsigned long long)(b - a) << 48) | ((unsigned long long)c.seq << 24) |
-                                (unsigned long long)sCount;
-        }
-        S[sCount++] = c;
-        made++;
-    }
-    return made;
-}
-
-__global__ __launch_bounds__(256) void k_quadtree(const OrbGeom G, unsigned long long* __restrict__ cand,
-                                                  size_t candSlab, const int* __restrict__ candCount,
-                                                  uint32_t* __restrict__ kpl, int* __restrict__ kpCount,
-                                                  int* __restrict__ errFlags, int sortCap, int nodeCap)
-{
-    extern __shared__ unsigned long long qsm[];
-    // LDS carve-up: keys[sortCap] | prev[nodeCap] | A[nodeCap] | B[nodeCap] | S[nodeCap]
-    unsigned long long* ldsKeys = qsm;
-    unsigned long long* prev = qsm + sortCap;
-    QtNode* A = reinterpret_cast<QtNode*>(prev + nodeCap);
-    QtNode* B = A + nodeCap;
-    QtNode* S = B + nodeCap;
-    __shared__ int sh_size, sh_prevCount, sh_state, sh_sCount;   // state: 0 main, 1 careful, 2 done
-    __shared__ int sh_listInB;
-
-    const int level = blockIdx.x, f = blockIdx.y;
-    const OrbLevelGeom& L = G.L[level];
-    const int tid = threadIdx.x;
-    int n = candCount[f * ORB_MAX_LEVELS + level];
-    if (n > L.candCap) n = L.candCap;
-    int* outCount = &kpCount[f * ORB_MAX_LEVELS + level];
-    if (n == 0) {
-        if (tid == 0) *outCount = 0;
-        return;
-    }
-    unsigned long long* gk = cand + (size_t)f * candSlab + L.candBase;
-    unsigned long long* keys;
-    if (n <= sortCap) {
-        for (int i = tid; i < n; i += blockDim.x) ldsKeys[i] = gk[i];
-        keys = ldsKeys;
-    } else {
-        keys = gk;                                   // rare: sort in place in global memory (L2)
-    }
-    __syncthreads();
-    block_sort_u64(keys, n);
-
-    const int N = L.quota;
-    // ---- roots (reference :575-612)
-    if (tid == 0) {
-        int cnt = 0, seq = 0;
-        int lo = 0;
-        for (int r = 0; r < L.nIni; r++) {
-            int a = lo, b = n;                      // first key with root > r
-            while (a < b) {
-                const int mid = (a + b) >> 1;
-                if ((int)(keys[mid] >> ORB_KEY_ROOT_SHIFT) <= r) a = mid + 1; else b = mid;
-            }
-            if (a > lo) {
-                QtNode nd;
-                nd.lo = lo; nd.hi = a; nd.depth = 0; nd.dead = 0; nd.seq = seq++;
-                A[cnt++] = nd;
-            }
-            lo = a;
-        }
-        sh_size = cnt;
-        sh_state = 0;
-        sh_listInB = 0;
-        sh_prevCount = 0;
-    }
-    __syncthreads();
-
-    int seq = L.nIni;                                // only thread 0's copy is used
-    while (true) {
-        const int state = sh_state;
-        if (state == 2) break;
-        QtNode* cur = sh_listInB ? B : A;
-        QtNode* nxt = sh_listInB ? A : B;
-        __syncthreads();                             // everyone has read the loop state before thread 0 rewrites it
-        if (state == 1) {                            // sort (size, seq) ascending (:711 with A.6 tie-break)
-            block_sort_u64(prev, sh_prevCount);
-        }
-        if (tid == 0) {
-            const int size0 = sh_size;
-            int size = size0, sCount = 0, newPrev = 0, nExpand = 0;
-            if (state == 0) {
-                // one full pass over the list (:631-691)
-                int prevCount = 0;
-                for (int i = 0; i < size0; i++) {
-                    const QtNode nd = cur[i];
-                    if (nd.hi - nd.lo == 1) continue;               // bNoMore
-                    const int made = qt_divide(keys, nd, S, sCount, prev, prevCount, seq, nExpand);
-                    cur[i].dead = 1;
-                    size += made - 1;
-                }
-                newPrev = prevCount;
-            } else {
-                // careful phase: largest first, stop as soon as size >= N (:703-765)
-                const int pc = sh_prevCount;
-                // prev[] is consumed from the back while new entries are appended from index 0 of
-                // a second region: reuse S-index space by writing new entries into prev after the
-                // loop; keep them in a small register-free way: stage in nxt (not yet used).
-                unsigned long long* stage = reinterpret_cast<unsigned long long*>(nxt);
-                for (int j = pc - 1; j >= 0; j--) {
-                    const int idx = (int)(prev[j] & 0xFFFFFF);
-                    const QtNode nd = cur[idx];
-                    const int made = qt_divide(keys, nd, S, sCount, stage, newPrev, seq, nExpand);
-                    cur[idx].dead = 1;
-                    size += made - 1;
-                    if (size >= N) break;
-                }
-                for (int j = 0; j < newPrev; j++) prev[j] = stage[j];
-            }
-            // rebuild: new list = reverse(S) ++ (cur minus dead)
-            int m = 0;
-            for (int j = sCount - 1; j >= 0; j--) nxt[m++] = S[j];
-            for (int i = 0; i < size0; i++)
-                if (!cur[i].dead) nxt[m++] = cur[i];
-            // S-index j now sits at list position sCount-1-j
-            for (int j = 0; j < newPrev; j++) {
-                const unsigned long long e = prev[j];
-                prev[j] = (e & ~0xFFFFFFull) | (unsigned long long)(sCount - 1 - (int)(e & 0xFFFFFF));
-            }
-            sh_size = size;
-            sh_prevCount = newPrev;
-            sh_listInB ^= 1;
-            sh_sCount = sCount;
-            if (size >= N || size == size0) sh_state = 2;
-            else if (state == 0 && size + 3 * nExpand > N) sh_state = 1;
-        }
-        __syncthreads();
-    }
-
-    // ---- keep the best key of every node, in list order (:770-789)
-    const QtNode* fin = sh_listInB ? B : A;
-    const int size = sh_size;
-    if (size > L.kpCap) {
-        if (tid == 0) { atomicOr(&errFlags[f], 2); *outCount = 0; }
-        return;
-    }
-    uint32_t* out = kpl + (size_t)f * G.kpSlab + L.kpBase;
-    for (int i = tid; i < size; i += blockDim.x) {
-        const QtNode nd = fin[i];
-        unsigned long long bestKey = 0;
-        for (int k = nd.lo; k < nd.hi; k++) {
-            // max response; among equals the candidate the reference appended first: smallest (ci,cj,y,x)
-            const unsigned long long key = keys[k];
-            const unsigned resp = (unsigned)(key & 0xFF), ord = (unsigned)(key >> 8) & 0x3FFFFFFu;
-            const unsigned bresp = (unsigned)(bestKey & 0xFF), bord = (unsigned)(bestKey >> 8) & 0x3FFFFFFu;
-            if (k == nd.lo || resp > bresp || (resp == bresp && ord < bord)) bestKey = key;
-        }
-        const int ci = (int)(bestKey >> 27) & 0x7F, cj = (int)(bestKey >> 20) & 0x7F;
-        const int yin = (int)(bestKey >> 14) & 0x3F, xin = (int)(bestKey >> 8) & 0x3F;
-        const int x = xin + cj * L.wCell + 16, y = yin + ci * L.hCell + 16;     // + minBorder (:892-893)
-        out[i] = ((uint32_t)x << 20) | ((uint32_t)y << 8) | (uint32_t)(bestKey & 0xFF);
-    }
-    if (tid == 0) *outCount = size;
-}
-
-// ------------------------------------------------------------------------------------------------
 // Orientation + steered BRIEF, fused per keypoint.  One wave64 per keypoint slot.
 // The 43x43 source patch (radius 15 for IC_Angle, 18 for the pattern, +3 for the 7-tap blur) is
 // staged in LDS with BORDER_REFLECT_101 resolved at load time; the horizontal blur pass is done
@@ -660,20 +422,6 @@ void orb_launch_fast_cells(hipStream_t st, const OrbGeom& G, const uint8_t* pyr,
     if (nCells == 0) return;
     hipLaunchKernelGGL(k_fast_cells, dim3(nCells, nFrames), dim3(WAVE), 0, st, G, pyr, pyrSlab, cells, cand,
                        candSlab, candCount, errFlags, iniTh, minTh);
-}
-
-size_t orb_quadtree_lds_bytes(int sortCap, int nodeCap)
-{
-    return (size_t)sortCap * 8 + (size_t)nodeCap * 8 + 3 * (size_t)nodeCap * sizeof(QtNode);
-}
-
-void orb_launch_quadtree(hipStream_t st, const OrbGeom& G, unsigned long long* cand, size_t candSlab,
-                         const int* candCount, uint32_t* kpl, int* kpCount, int* errFlags, int sortCap,
-                         int nodeCap, int nFrames)
-{
-    const size_t lds = orb_quadtree_lds_bytes(sortCap, nodeCap);
-    hipLaunchKernelGGL(k_quadtree, dim3(G.nlevels, nFrames), dim3(256), lds, st, G, cand, candSlab, candCount,
-                       kpl, kpCount, errFlags, sortCap, nodeCap);
 }
 
 void orb_launch_orient_desc(hipStream_t st, const OrbGeom& G, const uint8_t* pyr, size_t pyrSlab,

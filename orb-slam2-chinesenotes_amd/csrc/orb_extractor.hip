@@ -4,6 +4,7 @@
 // the launch sequence of one batch.  All device work of a handle goes to its own HIP stream.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -240,7 +241,9 @@ static int build_geometry(orb_extractor* h, int rows, int cols)
     h->candSlab = candOff;
     h->nodeCap = nodeCap;
     h->maxKp = kpOff;
-    h->sortCap = 4096;
+    // LDS sort capacity per (frame, level) instance; larger candidate sets are sorted in global memory.
+    h->sortCap = (h->prm.nfeatures <= 1500) ? 2048 : 4096;
+    if (const char* e = getenv("ORB_SORT_CAP")) h->sortCap = std::max(256, atoi(e));
     while (h->sortCap > 256 && orb_quadtree_lds_bytes(h->sortCap, nodeCap) > 60 * 1024) h->sortCap >>= 1;
     if (orb_quadtree_lds_bytes(h->sortCap, nodeCap) > 64 * 1024) {
         orb_set_error("nfeatures too large for the quadtree kernel's LDS budget");
