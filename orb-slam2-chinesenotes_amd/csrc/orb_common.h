@@ -27,6 +27,7 @@ struct OrbLevelGeom {
     int pyrOff;                 // byte offset of the level inside one frame's pyramid slab
     int nCols, nRows, wCell, hCell;   // FAST cell grid (reference src/ORBextractor.cc:820-823)
     int candBase, candCap;      // key slots inside one frame's candidate slab
+    int pathXOff, pathYOff;     // offsets of the level's quadtree path tables (u32 per x / per y)
     int quota;                  // mnFeaturesPerLevel[level]
     int kpBase, kpCap;          // slots inside one frame's per-level keypoint list
     int nIni;                   // quadtree roots (reference :567)

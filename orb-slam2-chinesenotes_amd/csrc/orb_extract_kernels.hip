@@ -3,7 +3,7 @@
 //
 // Stage map (reference src/ORBextractor.cc):
 //   k_copy_level0 / k_resize_level   ComputePyramid            :1153-1180  (cv::resize INTER_LINEAR)
-//   k_fast_cells                     per-cell cv::FAST + fallback + NMS :795-875
+//   (k_fast_cells lives in orb_fast.hip)
 //   (k_quadtree lives in orb_quadtree.hip)
 //   k_orient_desc                    IC_Angle, GaussianBlur, computeOrbDescriptor, operator() tail
 //                                    :78-171, :1118-1148
@@ -72,166 +72,6 @@ __global__ __launch_bounds__(256) void k_resize_level(uint8_t* __restrict__ pyr,
         }
     }
     *reinterpret_cast<uint32_t*>(dst + (size_t)y * dstPitch + (size_t)x4 * 4) = out;
-}
-
-// ------------------------------------------------------------------------------------------------
-// FAST-9/16 score V(p) = max over the 16 contiguous 9-arcs of min(+-(centre - ring)).
-// p points into an LDS byte tile with pitch P.  Result may be <= 0 (never a corner then).
-__device__ __forceinline__ int fast_score_v(const uint8_t* p, const int P)
-{
-    const int c = p[0];
-    int d[16];
-    d[0] = c - p[3 * P];        d[1] = c - p[3 * P + 1];   d[2] = c - p[2 * P + 2];   d[3] = c - p[P + 3];
-    d[4] = c - p[3];            d[5] = c - p[-P + 3];      d[6] = c - p[-2 * P + 2];  d[7] = c - p[-3 * P + 1];
-    d[8] = c - p[-3 * P];       d[9] = c - p[-3 * P - 1];  d[10] = c - p[-2 * P - 2]; d[11] = c - p[-P - 3];
-    d[12] = c - p[-3];          d[13] = c - p[P - 3];      d[14] = c - p[2 * P - 2];  d[15] = c - p[3 * P - 1];
-    int lo3[16], hi3[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        lo3[k] = min(min(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
-        hi3[k] = max(max(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
-    }
-    int a = -256, b = 256;
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const int lo9 = min(min(lo3[k], lo3[(k + 3) & 15]), lo3[(k + 6) & 15]);
-        const int hi9 = max(max(hi3[k], hi3[(k + 3) & 15]), hi3[(k + 6) & 15]);
-        a = max(a, lo9);
-        b = min(b, hi9);
-    }
-    return max(a, -b);
-}
-
-// quadrant path of a candidate inside the quadtree of reference DistributeOctTree/DivideNode
-// (:436-495, :567-593): root index + 12 two-bit digits (0 = n1 UL, 1 = n2 UR, 2 = n3 BL, 3 = n4 BR).
-__device__ __forceinline__ unsigned long long quadtree_path(int x, int y, const OrbLevelGeom& L)
-{
-    const int root = (int)((float)x / L.hX);                       // vpIniNodes[kp.pt.x/hX]  (:593)
-    int ulx = (int)(L.hX * (float)root), urx = (int)(L.hX * (float)(root + 1));   // (:578-579)
-    int uly = 0, bry = L.boxH;
-    unsigned path = 0;
-#pragma unroll
-    for (int d = 0; d < ORB_KEY_PATH_LEVELS; d++) {
-        const int midx = ulx + ((urx - ulx + 1) >> 1);            // UL.x + ceil((UR.x-UL.x)/2)
-        const int midy = uly + ((bry - uly + 1) >> 1);
-        const int right = !(x < midx), down = !(y < midy);
-        path = (path << 2) | (unsigned)(right + 2 * down);
-        if (right) ulx = midx; else urx = midx;
-        if (down) uly = midy; else bry = midy;
-    }
-    return ((unsigned long long)root << ORB_KEY_ROOT_SHIFT) | ((unsigned long long)path << ORB_KEY_PATH_SHIFT);
-}
-
-// One wave64 per FAST cell.  The cell ROI (<= 66x66 px) is staged in LDS with aligned dword loads,
-// V is computed for the whole detection zone, the iniTh -> minTh fallback is decided with a wave
-// ballot count, NMS is cell-local (neighbours outside the zone score 0), survivors are appended to
-// the (frame, level) candidate list with ONE atomic per cell.
-#define FAST_TP 72            // tile pitch in bytes (66 + 3 alignment slack -> 72)
-#define FAST_TH 66            // max ROI rows
-#define FAST_SP 64            // score-map pitch (zone width <= 60, +2 border)
-__global__ __launch_bounds__(WAVE) void k_fast_cells(const OrbGeom G, const uint8_t* __restrict__ pyr,
-                                                     size_t pyrSlab, const OrbCell* __restrict__ cells,
-                                                     unsigned long long* __restrict__ cand, size_t candSlab,
-                                                     int* __restrict__ candCount, int* __restrict__ errFlags,
-                                                     int iniTh, int minTh)
-{
-    __shared__ uint32_t tileDw[FAST_TH * FAST_TP / 4];
-    __shared__ uint8_t smap[(FAST_TH - 6 + 2) * FAST_SP];
-    const int lane = threadIdx.x;
-    const int f = blockIdx.y;
-    const OrbCell cell = cells[blockIdx.x];
-    const OrbLevelGeom& L = G.L[cell.level];
-    const uint8_t* img = pyr + (size_t)f * pyrSlab + L.pyrOff;
-
-    // ---- stage the ROI: aligned dwords, rows [y0, y0+h)
-    const int xa = cell.x0 & ~3, xoff = cell.x0 - xa;
-    const int ndw = (xoff + cell.w + 3) >> 2;                      // <= 18
-    const unsigned inv = ((1u << 20) + ndw - 1) / ndw;
-    for (int idx = lane; idx < ndw * cell.h; idx += WAVE) {
-        const int r = (int)(((unsigned)idx * inv) >> 20);
-        const int c = idx - r * ndw;
-        tileDw[r * (FAST_TP / 4) + c] =
-            *reinterpret_cast<const uint32_t*>(img + (size_t)(cell.y0 + r) * L.pitch + xa + 4 * c);
-    }
-    const int zw = cell.w - 6, zh = cell.h - 6;                    // detection zone
-    for (int idx = lane; idx < (zh + 2) * (FAST_SP / 4); idx += WAVE)
-        reinterpret_cast<uint32_t*>(smap)[idx] = 0;
-    __syncthreads();
-
-    // ---- V for every zone pixel
-    const uint8_t* tile = reinterpret_cast<const uint8_t*>(tileDw);
-    const int npx = zw * zh;
-    const unsigned invz = ((1u << 20) + zw - 1) / zw;
-    for (int base = 0; base < npx; base += WAVE) {
-        const int idx = base + lane;
-        if (idx < npx) {
-            const int py = (int)(((unsigned)idx * invz) >> 20);
-            const int px = idx - py * zw;
-            const int S = max(fast_score_v(tile + (py + 3) * FAST_TP + xoff + px + 3, FAST_TP), 0);
-            smap[(py + 1) * FAST_SP + px + 1] = (uint8_t)S;
-        }
-    }
-    __syncthreads();
-
-    // ---- cell-local 3x3 strict NMS on score = (V > th) ? V-1 : 0.  The reference re-runs cv::FAST
-    // with minThFAST when the iniThFAST call returns NO KEYPOINT (:857-861) -- i.e. after NMS, so a
-    // plateau of equal scores that suppresses itself also triggers the fallback.
-    unsigned long long keep = 0;
-    int total = 0, it = 0;
-    for (int attempt = 0; attempt < 2 && total == 0; attempt++) {
-        const int th = attempt ? minTh : iniTh;
-        keep = 0;
-        it = 0;
-        for (int base = 0; base < npx; base += WAVE, it++) {
-            const int idx = base + lane;
-            bool k = false;
-            if (idx < npx) {
-                const int py = (int)(((unsigned)idx * invz) >> 20);
-                const int px = idx - py * zw;
-                const uint8_t* s = smap + (py + 1) * FAST_SP + px + 1;
-                const int S = s[0];
-                if (S > th) {
-                    const int sc = S - 1;
-                    int m = 0;
-#define NB(o) { const int v = s[o]; m = max(m, v > th ? v - 1 : 0); }
-                    NB(-1) NB(1) NB(-FAST_SP - 1) NB(-FAST_SP) NB(-FAST_SP + 1) NB(FAST_SP - 1) NB(FAST_SP) NB(FAST_SP + 1)
-#undef NB
-                    k = sc > m;
-                }
-            }
-            if (k) keep |= 1ull << it;
-            total += __popcll(__ballot(k));
-        }
-    }
-    if (total == 0) return;
-
-    int base0 = 0;
-    if (lane == 0) base0 = atomicAdd(&candCount[f * ORB_MAX_LEVELS + cell.level], total);
-    base0 = __shfl(base0, 0);
-    if (base0 + total > L.candCap) {                               // cannot happen: candCap is the NMS bound
-        if (lane == 0) atomicOr(&errFlags[f], 1);
-        return;
-    }
-    unsigned long long* out = cand + (size_t)f * candSlab + L.candBase + base0;
-    int run = 0;
-    it = 0;
-    for (int base = 0; base < npx; base += WAVE, it++) {
-        const bool k = (keep >> it) & 1;
-        const unsigned long long b = __ballot(k);
-        if (k) {
-            const int idx = base + lane;
-            const int py = (int)(((unsigned)idx * invz) >> 20);
-            const int px = idx - py * zw;
-            const int xin = px + 3, yin = py + 3;                 // cv::FAST keypoint coords in the ROI
-            const int S = smap[(py + 1) * FAST_SP + px + 1];
-            const int cx = xin + cell.cj * L.wCell, cy = yin + cell.ci * L.hCell;   // :868-869
-            unsigned long long key = quadtree_path(cx, cy, L);
-            key |= ((unsigned long long)cell.ci << 27) | ((unsigned long long)cell.cj << 20) |
-                   ((unsigned long long)yin << 14) | ((unsigned long long)xin << 8) | (unsigned long long)(S - 1);
-            out[run + __popcll(b & ((1ull << lane) - 1))] = key;
-        }
-        run += __popcll(b);
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -413,15 +253,6 @@ void orb_launch_resize(hipStream_t st, uint8_t* pyr, size_t pyrSlab, const OrbLe
     dim3 grid((x4 + 63) / 64, (dst.h + 3) / 4, nFrames);
     hipLaunchKernelGGL(k_resize_level, grid, dim3(64, 4), 0, st, pyr, pyrSlab, src.pyrOff, src.pitch,
                        dst.pyrOff, dst.pitch, dst.w, dst.h, xtab, ytab);
-}
-
-void orb_launch_fast_cells(hipStream_t st, const OrbGeom& G, const uint8_t* pyr, size_t pyrSlab,
-                           const OrbCell* cells, int nCells, unsigned long long* cand, size_t candSlab,
-                           int* candCount, int* errFlags, int iniTh, int minTh, int nFrames)
-{
-    if (nCells == 0) return;
-    hipLaunchKernelGGL(k_fast_cells, dim3(nCells, nFrames), dim3(WAVE), 0, st, G, pyr, pyrSlab, cells, cand,
-                       candSlab, candCount, errFlags, iniTh, minTh);
 }
 
 void orb_launch_orient_desc(hipStream_t st, const OrbGeom& G, const uint8_t* pyr, size_t pyrSlab,

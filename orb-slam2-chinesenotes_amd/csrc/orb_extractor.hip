@@ -72,7 +72,7 @@ struct orb_extractor {
     int sortCap = 4096, nodeCap = 0, maxKp = 0;
 
     // device memory
-    DevBuf dPattern, dCells, dXtab, dYtab;      // constants
+    DevBuf dPattern, dCells, dXtab, dYtab, dPath;   // constants
     std::vector<size_t> xtabOff, ytabOff;       // per level offsets (in int2 units)
     DevBuf dPyr, dCand, dKpl, dCandCount, dKpCount, dErr;   // per-batch scratch
     DevBuf dImgs, dKps, dDesc, dCounts;         // staging for the host-buffer API
@@ -161,6 +161,7 @@ static int build_geometry(orb_extractor* h, int rows, int cols)
     size_t pyrOff = 0;
     size_t candOff = 0;
     int kpOff = 0, nodeCap = 0;
+    std::vector<uint32_t> pathTab;
     for (int l = 0; l < nl; l++) {
         OrbLevelGeom& L = G.L[l];
         L.w = cv_round_f((float)cols * h->invScale[l]);                 // :1158
@@ -204,6 +205,10 @@ static int build_geometry(orb_extractor* h, int rows, int cols)
                     c.w = (short)((int)maxX - (int)iniX); c.h = (short)((int)maxY - (int)iniY);
                     c.level = (unsigned char)l; c.ci = (unsigned char)i; c.cj = (unsigned char)j; c.pad = 0;
                     if (c.w < 7 || c.h < 7) continue;                    // cv::FAST finds nothing in such a ROI
+                    if (((c.w - 6 + 10) / 4 + 1) * (c.h - 6) > 1024) {     // k_fast_cells: <= 16 quad steps per lane
+                        orb_set_error("FAST cell %dx%d too large for the kernel", c.w, c.h);
+                        return ORB_ERR_UNSUPPORTED;
+                    }
                     h->cells.push_back(c);
                     candCap += ((c.w - 6 + 1) / 2) * ((c.h - 6 + 1) / 2);   // 3x3 strict NMS bound
                 }
@@ -230,6 +235,37 @@ static int build_geometry(orb_extractor* h, int rows, int cols)
         } else {
             L.nIni = nIni;
             L.hX = (float)L.boxW / nIni;
+        }
+        // quadtree path tables (DivideNode bisects x and y independently, :438-463): for every candidate
+        // coordinate the 12 x-decisions (even bits of the 24-bit path, + root << 24) and the 12 y-decisions
+        L.pathXOff = (int)pathTab.size();
+        for (int x = 0; x < std::max(L.boxW, 0); x++) {
+            uint32_t code = 0;
+            if (L.nIni > 0) {
+                int root = (int)((float)x / L.hX);                           // :593
+                if (root >= L.nIni) root = L.nIni - 1;                       // not reachable for candidate x
+                int ulx = (int)(L.hX * (float)root), urx = (int)(L.hX * (float)(root + 1));   // :578-579
+                for (int d = 0; d < ORB_KEY_PATH_LEVELS; d++) {
+                    const int mid = ulx + ((urx - ulx + 1) >> 1);            // UL.x + ceil((UR.x-UL.x)/2)
+                    const int right = !(x < mid);
+                    code |= (uint32_t)right << (2 * (ORB_KEY_PATH_LEVELS - 1 - d));
+                    if (right) ulx = mid; else urx = mid;
+                }
+                code |= (uint32_t)root << 24;
+            }
+            pathTab.push_back(code);
+        }
+        L.pathYOff = (int)pathTab.size();
+        for (int y = 0; y < std::max(L.boxH, 0); y++) {
+            uint32_t code = 0;
+            int uly = 0, bry = L.boxH;
+            for (int d = 0; d < ORB_KEY_PATH_LEVELS; d++) {
+                const int mid = uly + ((bry - uly + 1) >> 1);
+                const int down = !(y < mid);
+                code |= (uint32_t)down << (2 * (ORB_KEY_PATH_LEVELS - 1 - d) + 1);
+                if (down) uly = mid; else bry = mid;
+            }
+            pathTab.push_back(code);
         }
         L.kpBase = kpOff;
         L.kpCap = std::max(L.quota + 3, 4 * std::max(nIni, 1)) + 5;
@@ -258,6 +294,10 @@ static int build_geometry(orb_extractor* h, int rows, int cols)
         if ((rc = h->dCells.ensure(h->cells.size() * sizeof(OrbCell))) != ORB_OK) return rc;
         ORB_HIP_TRY(hipMemcpyAsync(h->dCells.p, h->cells.data(), h->cells.size() * sizeof(OrbCell),
                                    hipMemcpyHostToDevice, h->stream));
+    }
+    if (!pathTab.empty()) {
+        if ((rc = h->dPath.ensure(pathTab.size() * 4)) != ORB_OK) return rc;
+        ORB_HIP_TRY(hipMemcpyAsync(h->dPath.p, pathTab.data(), pathTab.size() * 4, hipMemcpyHostToDevice, h->stream));
     }
     std::vector<int2> xt, yt, t;
     h->xtabOff.assign(nl, 0);
@@ -344,7 +384,7 @@ extern "C" void orb_extractor_destroy(orb_extractor* h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    DevBuf* bufs[] = {&h->dPattern, &h->dCells, &h->dXtab, &h->dYtab, &h->dPyr, &h->dCand, &h->dKpl,
+    DevBuf* bufs[] = {&h->dPattern, &h->dCells, &h->dXtab, &h->dYtab, &h->dPath, &h->dPyr, &h->dCand, &h->dKpl,
                       &h->dCandCount, &h->dKpCount, &h->dErr, &h->dImgs, &h->dKps, &h->dDesc, &h->dCounts};
     for (DevBuf* b : bufs) b->release();
     for (int k = 0; k < orb_extractor::kProfSlots; k++)
@@ -472,7 +512,7 @@ extern "C" int orb_extract_batch_device(orb_extractor* h, const uint8_t* d_imgs,
                           (const int2*)h->dYtab.p + h->ytabOff[l], nFrames);
     if (h->profiling) ORB_HIP_TRY(hipEventRecord(pe[1], st));
     orb_launch_fast_cells(st, G, pyr, h->pyrSlab, (const OrbCell*)h->dCells.p, (int)h->cells.size(),
-                          (unsigned long long*)h->dCand.p, h->candSlab, (int*)h->dCandCount.p, (int*)h->dErr.p,
+                          (const uint32_t*)h->dPath.p, (unsigned long long*)h->dCand.p, h->candSlab, (int*)h->dCandCount.p, (int*)h->dErr.p,
                           h->prm.ini_th_fast, h->prm.min_th_fast, nFrames);
     if (h->profiling) ORB_HIP_TRY(hipEventRecord(pe[2], st));
     orb_launch_quadtree(st, G, (unsigned long long*)h->dCand.p, h->candSlab, (const int*)h->dCandCount.p,

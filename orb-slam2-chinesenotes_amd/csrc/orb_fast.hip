@@ -1,0 +1,290 @@
+// orb_fast.hip -- per-cell FAST-9/16 detection on gfx950.
+// Reference: the cell loop of ORBextractor::ComputeKeyPointsOctTree, src/ORBextractor.cc:795-875
+// (cv::FAST(cell ROI, iniThFAST, nonmax=true), fallback to minThFAST when it returns nothing).
+//
+// One wave64 per FAST cell (<= 66x66 px ROI).  What bounds this kernel is VALU issue (rocprofv3:
+// half of the wave-cycles are issue stalls on integer min/max), so the arithmetic is arranged for
+// the cheapest instruction mix CDNA4 offers:
+//   * the ROI is staged in LDS with aligned dword loads and read back as dwords: one lane computes
+//     FOUR horizontally adjacent pixels from a 7-row x 12-byte window (21 ds_read_b32);
+//   * V(p) = max(I_p - min_arcs max_arc ring, max_arcs min_arc ring - I_p) is evaluated on PAIRS of
+//     pixels with v_pk_maximum3_f16 / v_pk_minimum3_f16: a u8 stored in a 16-bit half is a positive
+//     f16 subnormal whose order is the integer order, so the packed 3-input float min/max is exact
+//     and moves 2 pixels x 3 operands per instruction (measured 2.1x the per-pixel rate of
+//     v_max3_i32; tools/ubench).  One v_perm_b32 builds each packed ring operand from the window;
+//   * V is threshold-free: both thresholds and the NMS read the same u8 score map;
+//   * only pixels with V > min(iniTh, minTh) can ever be keypoints: they are queued (the queue
+//     re-uses the image tile's LDS) and NMS + emission run over the queue, not over the zone;
+//   * the quadtree path of a candidate is two table look-ups (x and y bisect independently).
+#include "orb_kernels.h"
+
+#define WAVE 64
+#define FT_PITCH 72                    // tile / score-map pitch in bytes (18 dwords): 66 + 3 + slack
+#define FT_PDW (FT_PITCH / 4)
+#define FT_ROWS 66                     // max ROI rows
+#define FT_PAD 4                       // dwords of slack around the tile (edge quads read one dword outside)
+#define FT_QCAP (FT_ROWS * FT_PITCH / 2)   // candidate-queue capacity in u16 entries (aliases the tile)
+
+__device__ __forceinline__ unsigned pk_max3(unsigned a, unsigned b, unsigned c)
+{
+    unsigned d;
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ unsigned pk_min3(unsigned a, unsigned b, unsigned c)
+{
+    unsigned d;
+    asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ unsigned pk_max2(unsigned a, unsigned b)
+{
+    unsigned d;
+    asm("v_pk_max_f16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ unsigned pk_min2(unsigned a, unsigned b)
+{
+    unsigned d;
+    asm("v_pk_min_f16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ unsigned pk_sub_i16(unsigned a, unsigned b)
+{
+    unsigned d;
+    asm("v_pk_sub_i16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ unsigned pk_max_i16(unsigned a, unsigned b)
+{
+    unsigned d;
+    asm("v_pk_max_i16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
+// bytes I and I+1 of the 12-byte window (w0,w1,w2) as two zero-extended 16-bit halves
+template <int I>
+__device__ __forceinline__ unsigned pick2(unsigned w0, unsigned w1, unsigned w2)
+{
+    if constexpr (I + 1 <= 7)
+        return __builtin_amdgcn_perm(w1, w0, (unsigned)(I | 0x0c00 | ((I + 1) << 16) | 0x0c000000));
+    else
+        return __builtin_amdgcn_perm(w2, w1, (unsigned)((I - 4) | 0x0c00 | ((I - 3) << 16) | 0x0c000000));
+}
+
+// S = max(V, 0) for a pair of pixels whose window bytes are (C, C+1); W[r][0..2] are rows y-3..y+3.
+template <int C>
+__device__ __forceinline__ unsigned fast_pair(const unsigned (&W)[7][3])
+{
+    // ring k = 0..15: (dx,dy) = (0,3),(1,3),(2,2),(3,1),(3,0),(3,-1),(2,-2),(1,-3),(0,-3),(-1,-3),(-2,-2),
+    //                           (-3,-1),(-3,0),(-3,1),(-2,2),(-1,3)      
+    unsigned r[16];
+#define RING(k, dx, dy) r[k] = pick2<C + (dx)>(W[(dy) + 3][0], W[(dy) + 3][1], W[(dy) + 3][2]);
+    RING(0, 0, 3) RING(1, 1, 3) RING(2, 2, 2) RING(3, 3, 1) RING(4, 3, 0) RING(5, 3, -1) RING(6, 2, -2) RING(7, 1, -3)
+    RING(8, 0, -3) RING(9, -1, -3) RING(10, -2, -2) RING(11, -3, -1) RING(12, -3, 0) RING(13, -3, 1) RING(14, -2, 2)
+    RING(15, -1, 3)
+#undef RING
+    const unsigned c = pick2<C>(W[3][0], W[3][1], W[3][2]);
+    unsigned hi3[16], lo3[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        hi3[k] = pk_max3(r[k], r[(k + 1) & 15], r[(k + 2) & 15]);
+        lo3[k] = pk_min3(r[k], r[(k + 1) & 15], r[(k + 2) & 15]);
+    }
+    unsigned hi9[16], lo9[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        hi9[k] = pk_max3(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]);    // max of the 9-arc starting at k
+        lo9[k] = pk_min3(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]);
+    }
+    // M = min over arcs of the arc maximum, m = max over arcs of the arc minimum
+    unsigned M = pk_min3(pk_min3(hi9[0], hi9[1], hi9[2]), pk_min3(hi9[3], hi9[4], hi9[5]), pk_min3(hi9[6], hi9[7], hi9[8]));
+    M = pk_min3(M, pk_min3(hi9[9], hi9[10], hi9[11]), pk_min3(hi9[12], hi9[13], hi9[14]));
+    M = pk_min2(M, hi9[15]);
+    unsigned m = pk_max3(pk_max3(lo9[0], lo9[1], lo9[2]), pk_max3(lo9[3], lo9[4], lo9[5]), pk_max3(lo9[6], lo9[7], lo9[8]));
+    m = pk_max3(m, pk_max3(lo9[9], lo9[10], lo9[11]), pk_max3(lo9[12], lo9[13], lo9[14]));
+    m = pk_max2(m, lo9[15]);
+    // V = max(c - M, m - c) per 16-bit half (plain integers again), clamped at 0
+    const unsigned v = pk_max_i16(pk_sub_i16(c, M), pk_sub_i16(m, c));
+    return pk_max_i16(v, 0u);
+}
+
+__global__ __launch_bounds__(WAVE) void k_fast_cells(const OrbGeom G, const uint8_t* __restrict__ pyr,
+                                                     size_t pyrSlab, const OrbCell* __restrict__ cells,
+                                                     const uint32_t* __restrict__ pathTab,
+                                                     unsigned long long* __restrict__ cand, size_t candSlab,
+                                                     int* __restrict__ candCount, int* __restrict__ errFlags,
+                                                     int iniTh, int minTh)
+{
+    __shared__ uint32_t tileRaw[FT_PAD + FT_ROWS * FT_PDW + FT_PAD];
+    __shared__ uint32_t smapDw[FT_ROWS * FT_PDW];
+    uint32_t* tileDw = tileRaw + FT_PAD;
+    const int lane = threadIdx.x;
+    const int f = blockIdx.y;
+    const OrbCell cell = cells[blockIdx.x];
+    const OrbLevelGeom& L = G.L[cell.level];
+    const uint8_t* img = pyr + (size_t)f * pyrSlab + L.pyrOff;
+
+    // ---- stage the ROI rows [y0, y0+h) as aligned dwords; lane -> (row in pass, dword column)
+    const int xa = cell.x0 & ~3, xoff = cell.x0 - xa;
+    const int ndw = (xoff + cell.w + 3) >> 2;                      // <= 18
+    {
+        const unsigned inv = ((1u << 20) + ndw - 1) / ndw;
+        const int rp = (int)(((unsigned)lane * inv) >> 20), c = lane - rp * ndw;
+        const int rowsPerPass = WAVE / ndw;
+        if (rp < rowsPerPass) {
+            const uint8_t* src = img + (size_t)(cell.y0 + rp) * L.pitch + xa + 4 * c;
+            const size_t step = (size_t)rowsPerPass * L.pitch;
+            for (int r = rp; r < cell.h; r += rowsPerPass, src += step)
+                tileDw[r * FT_PDW + c] = *reinterpret_cast<const uint32_t*>(src);
+        }
+    }
+    const int zw = cell.w - 6, zh = cell.h - 6;                    // detection zone: tile rows [3,3+zh), cols [zLo,zHi)
+    const int zLo = xoff + 3, zHi = zLo + zw;
+    const int qLo = (zLo - 1) >> 2, qHi = (zHi >> 2) + 1;          // quads covering cols [zLo-1, zHi]
+    const int nq = qHi - qLo;
+    // rows just above / below the zone read as score 0 by the NMS
+    for (int i = lane; i < 2 * nq; i += WAVE) {
+        const int row = (i < nq) ? 2 : 3 + zh, q = qLo + (i < nq ? i : i - nq);
+        smapDw[row * FT_PDW + q] = 0;
+    }
+    __syncthreads();
+
+    // ---- V for the zone, 4 pixels per lane per step; remember which pixels exceed the lower threshold
+    const int lowTh = min(iniTh, minTh);
+    const int nItems = nq * zh;
+    const unsigned invq = ((1u << 20) + nq - 1) / nq;
+    unsigned long long cmask = 0;                                  // bit 4*step+j: pixel j of this lane's step-th quad
+    int step = 0;
+    for (int base = 0; base < nItems; base += WAVE, step++) {
+        const int item = base + lane;
+        if (item < nItems) {
+            const int ry = (int)(((unsigned)item * invq) >> 20);
+            const int q = qLo + item - ry * nq;
+            const int row = 3 + ry;
+            unsigned W[7][3];
+#pragma unroll
+            for (int r = 0; r < 7; r++) {
+                const uint32_t* p = tileDw + (row - 3 + r) * FT_PDW + q - 1;
+                W[r][0] = p[0]; W[r][1] = p[1]; W[r][2] = p[2];
+            }
+            const unsigned sA = fast_pair<4>(W);                   // pixels 4q, 4q+1
+            const unsigned sB = fast_pair<6>(W);                   // pixels 4q+2, 4q+3
+            unsigned s4 = __builtin_amdgcn_perm(sB, sA, 0x06040200u);
+            // pixels outside [zLo, zHi) belong to the neighbouring cell: score 0 here
+            const int c0 = 4 * q;
+            unsigned keep = 0;
+            if (c0 >= zLo && c0 < zHi) keep |= 0x000000ffu;
+            if (c0 + 1 >= zLo && c0 + 1 < zHi) keep |= 0x0000ff00u;
+            if (c0 + 2 >= zLo && c0 + 2 < zHi) keep |= 0x00ff0000u;
+            if (c0 + 3 >= zLo && c0 + 3 < zHi) keep |= 0xff000000u;
+            s4 &= keep;
+            smapDw[row * FT_PDW + q] = s4;
+            unsigned fl = 0;
+            if ((int)(s4 & 0xff) > lowTh) fl |= 1;
+            if ((int)((s4 >> 8) & 0xff) > lowTh) fl |= 2;
+            if ((int)((s4 >> 16) & 0xff) > lowTh) fl |= 4;
+            if ((int)(s4 >> 24) > lowTh) fl |= 8;
+            cmask |= (unsigned long long)fl << (4 * step);
+        }
+    }
+    __syncthreads();                                               // tile is dead from here on: it becomes the queue
+
+    // ---- queue of candidate pixels, entry = row << 8 | col (tile coordinates); order is irrelevant
+    uint16_t* queue = reinterpret_cast<uint16_t*>(tileDw);
+    const uint8_t* smap = reinterpret_cast<const uint8_t*>(smapDw);
+    const int mine = __popcll(cmask);
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    const int nCand = __shfl(incl, WAVE - 1);
+    if (nCand == 0) return;
+    if (nCand > FT_QCAP) {                                         // cannot happen: FT_QCAP >= 60*60/... guard anyway
+        if (lane == 0) atomicOr(&errFlags[f], 16);
+        return;
+    }
+    {
+        int w = incl - mine;
+        unsigned long long mm = cmask;
+        while (mm) {
+            const int bit = __ffsll((long long)mm) - 1;
+            mm &= mm - 1;
+            const int item = (bit >> 2) * WAVE + lane;
+            const int ry = (int)(((unsigned)item * invq) >> 20);
+            const int q = qLo + item - ry * nq;
+            queue[w++] = (uint16_t)(((3 + ry) << 8) | (4 * q + (bit & 3)));
+        }
+    }
+    __syncthreads();
+
+    // ---- cell-local 3x3 strict NMS on score = (V > th) ? V-1 : 0.  The reference re-runs cv::FAST with
+    // minThFAST when the iniThFAST call returns NO KEYPOINT (:857-861) -- i.e. after NMS, so a plateau of
+    // equal scores that suppresses itself also triggers the fallback.
+    unsigned long long keep = 0;
+    int total = 0;
+    for (int attempt = 0; attempt < 2 && total == 0; attempt++) {
+        const int th = attempt ? minTh : iniTh;
+        keep = 0;
+        int it = 0;
+        for (int base = 0; base < nCand; base += WAVE, it++) {
+            const int e = base + lane;
+            bool k = false;
+            if (e < nCand) {
+                const unsigned ent = queue[e];
+                const uint8_t* s = smap + (ent >> 8) * FT_PITCH + (ent & 0xff);
+                const int S = s[0];
+                if (S > th) {
+                    const int sc = S - 1;
+                    int m = 0;
+#define NB(o) { const int v = s[o]; m = max(m, v > th ? v - 1 : 0); }
+                    NB(-1) NB(1) NB(-FT_PITCH - 1) NB(-FT_PITCH) NB(-FT_PITCH + 1) NB(FT_PITCH - 1) NB(FT_PITCH) NB(FT_PITCH + 1)
+#undef NB
+                    k = sc > m;
+                }
+            }
+            if (k) keep |= 1ull << it;
+            total += __popcll(__ballot(k));
+        }
+    }
+    if (total == 0) return;
+
+    int base0 = 0;
+    if (lane == 0) base0 = atomicAdd(&candCount[f * ORB_MAX_LEVELS + cell.level], total);
+    base0 = __shfl(base0, 0);
+    if (base0 + total > L.candCap) {                               // cannot happen: candCap is the NMS bound
+        if (lane == 0) atomicOr(&errFlags[f], 1);
+        return;
+    }
+    unsigned long long* out = cand + (size_t)f * candSlab + L.candBase + base0;
+    const uint32_t* xtab = pathTab + L.pathXOff;
+    const uint32_t* ytab = pathTab + L.pathYOff;
+    int run = 0, it = 0;
+    for (int base = 0; base < nCand; base += WAVE, it++) {
+        const bool k = (keep >> it) & 1;
+        const unsigned long long b = __ballot(k);
+        if (k) {
+            const unsigned ent = queue[base + lane];
+            const int row = ent >> 8, col = ent & 0xff;
+            const int xin = col - xoff, yin = row;                 // cv::FAST keypoint coords inside the ROI
+            const int S = smap[row * FT_PITCH + col];
+            const int cx = xin + cell.cj * L.wCell, cy = yin + cell.ci * L.hCell;   // :868-869
+            unsigned long long key = (unsigned long long)(xtab[cx] | ytab[cy]) << ORB_KEY_PATH_SHIFT;
+            key |= ((unsigned long long)cell.ci << 27) | ((unsigned long long)cell.cj << 20) |
+                   ((unsigned long long)yin << 14) | ((unsigned long long)xin << 8) | (unsigned long long)(S - 1);
+            out[run + __popcll(b & ((1ull << lane) - 1))] = key;
+        }
+        run += __popcll(b);
+    }
+}
+
+void orb_launch_fast_cells(hipStream_t st, const OrbGeom& G, const uint8_t* pyr, size_t pyrSlab,
+                           const OrbCell* cells, int nCells, const uint32_t* pathTab, unsigned long long* cand,
+                           size_t candSlab, int* candCount, int* errFlags, int iniTh, int minTh, int nFrames)
+{
+    if (nCells == 0) return;
+    hipLaunchKernelGGL(k_fast_cells, dim3(nCells, nFrames), dim3(WAVE), 0, st, G, pyr, pyrSlab, cells, pathTab, cand,
+                       candSlab, candCount, errFlags, iniTh, minTh);
+}
