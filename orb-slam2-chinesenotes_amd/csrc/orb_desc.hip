@@ -1,0 +1,215 @@
+// orb_desc.hip -- orientation + steered BRIEF, fused per keypoint, on gfx950.
+// Reference: IC_Angle / computeOrientation src/ORBextractor.cc:78-115, GaussianBlur :1129-1130,
+// computeOrbDescriptor :120-161, the tail of operator() :1118-1148.
+//
+// One wave64 per keypoint slot.  The 43x43 source patch (radius 15 for IC_Angle, 18 for the pattern,
+// +3 for the 7-tap blur) is staged in LDS as aligned dwords (BORDER_REFLECT_101 resolved at load time
+// on the rare keypoints within 21 px of the image border); the horizontal blur pass runs once over
+// the patch with v_dot4_u32_u8 on funnel-shifted byte windows (8.8 fixed-point taps fit a byte), the
+// vertical pass only at the 512 sampled points.  The blurred level is never written to HBM.
+// Four __ballot()s of 64 comparisons ARE the 256-bit descriptor.
+#include "orb_kernels.h"
+
+#pragma clang fp contract(off)
+
+#include "../../include/orb_sincos.h"
+
+#define WAVE 64
+#define PR 21                  // patch radius
+#define PW 43                  // patch rows / useful columns
+#define PB 48                  // LDS row pitch in bytes (12 aligned dwords cover xoff + 43 <= 46 bytes)
+#define PDW (PB / 4)
+#define HP 48                  // pitch of the row-blurred patch (u16), indexed by LDS byte position
+
+__device__ __forceinline__ int reflect101(int i, int n)
+{
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * n - 2 - i;
+    return i;
+}
+
+__device__ __forceinline__ float fast_atan2_deg(float y, float x)
+{
+    // cv::fastAtan2; constants are the float products p_k * (float)(180/pi)
+    const float p1 = __uint_as_float(0x4265226fu), p3 = __uint_as_float(0xc19556eeu);
+    const float p5 = __uint_as_float(0x410e9fbfu), p7 = __uint_as_float(0xc0228ad9u);
+    const float eps = 2.2204460492503131e-16f;
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = __fdiv_rn(ay, __fadd_rn(ax, eps));
+        c2 = __fmul_rn(c, c);
+        a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+    } else {
+        c = __fdiv_rn(ax, __fadd_rn(ay, eps));
+        c2 = __fmul_rn(c, c);
+        a = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
+    }
+    if (x < 0) a = __fsub_rn(180.f, a);
+    if (y < 0) a = __fsub_rn(360.f, a);
+    return a;
+}
+
+__device__ __forceinline__ int wave_sum(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// 7-tap row blur at the 4 byte positions 4q..4q+3 of a row, from the 12-byte window (d0,d1,d2) =
+// bytes 4q-4 .. 4q+7.  Taps 18,34,49,55,49,34,18 (8.8 fixed point): two dot4 per output.
+__device__ __forceinline__ void hblur4(unsigned d0, unsigned d1, unsigned d2, unsigned out[4])
+{
+    const unsigned K0 = 18u | (34u << 8) | (49u << 16) | (55u << 24);   // bytes b-3 .. b
+    const unsigned K1 = 49u | (34u << 8) | (18u << 16);                 // bytes b+1 .. b+3
+    const unsigned lo0 = __builtin_amdgcn_alignbyte(d1, d0, 1), hi0 = __builtin_amdgcn_alignbyte(d2, d1, 1);
+    const unsigned lo1 = __builtin_amdgcn_alignbyte(d1, d0, 2), hi1 = __builtin_amdgcn_alignbyte(d2, d1, 2);
+    const unsigned lo2 = __builtin_amdgcn_alignbyte(d1, d0, 3), hi2 = __builtin_amdgcn_alignbyte(d2, d1, 3);
+    out[0] = __builtin_amdgcn_udot4(hi0, K1, __builtin_amdgcn_udot4(lo0, K0, 0u, false), false);
+    out[1] = __builtin_amdgcn_udot4(hi1, K1, __builtin_amdgcn_udot4(lo1, K0, 0u, false), false);
+    out[2] = __builtin_amdgcn_udot4(hi2, K1, __builtin_amdgcn_udot4(lo2, K0, 0u, false), false);
+    out[3] = __builtin_amdgcn_udot4(d2, K1, __builtin_amdgcn_udot4(d1, K0, 0u, false), false);
+}
+
+__global__ __launch_bounds__(WAVE) void k_orient_desc(const OrbGeom G, const uint8_t* __restrict__ pyr,
+                                                      size_t pyrSlab, const uint32_t* __restrict__ kpl,
+                                                      const int* __restrict__ kpCount,
+                                                      const int8_t* __restrict__ pattern,
+                                                      orb_keypoint* __restrict__ kpsOut,
+                                                      uint8_t* __restrict__ descOut, int cap,
+                                                      int32_t* __restrict__ countsOut, int* __restrict__ errFlags)
+{
+    __shared__ uint32_t Praw[1 + PW * PDW + 1];       // one dword of slack on both sides (edge quads)
+    __shared__ uint16_t H[PW * HP];
+    uint32_t* Pdw = Praw + 1;
+    const int lane = threadIdx.x;
+    const int slot = blockIdx.x, f = blockIdx.y;
+    int level = 0;
+    while (level + 1 < G.nlevels && slot >= G.L[level + 1].kpBase) level++;
+    const OrbLevelGeom& L = G.L[level];
+    const int k = slot - L.kpBase;
+    const int* cnt = kpCount + f * ORB_MAX_LEVELS;
+    int off = 0;
+    for (int l = 0; l < level; l++) off += cnt[l];
+    if (slot == 0) {
+        int tot = 0;
+        for (int l = 0; l < G.nlevels; l++) tot += cnt[l];
+        if (lane == 0) {
+            countsOut[f] = min(tot, cap);
+            if (tot > cap) atomicOr(&errFlags[f], 4);
+        }
+    }
+    if (k >= cnt[level] || off + k >= cap) return;
+
+    const uint32_t packed = kpl[(size_t)f * G.kpSlab + slot];
+    const int x0 = (int)(packed >> 20), y0 = (int)(packed >> 8) & 0xFFF;
+    const int resp = (int)(packed & 0xFF);
+    const uint8_t* img = pyr + (size_t)f * pyrSlab + L.pyrOff;
+
+    // ---- stage the patch: LDS row r = image row y0-21+r, LDS byte b = image column xa+b
+    const int xl = x0 - PR;                            // image column of patch column 0 (may be < 0)
+    const int xa = xl & ~3, xoff = xl - xa;            // (two's complement: floor to a multiple of 4)
+    const bool interior = xl >= 0 && x0 + PR < L.w && y0 - PR >= 0 && y0 + PR < L.h;
+    if (interior) {
+        const int rp = lane / PDW, c = lane - rp * PDW;     // 5 rows x 12 dwords per pass
+        if (rp < 5) {
+            const uint8_t* src = img + (size_t)(y0 - PR + rp) * L.pitch + xa + 4 * c;
+            for (int r = rp; r < PW; r += 5, src += (size_t)5 * L.pitch)
+                Pdw[r * PDW + c] = *reinterpret_cast<const uint32_t*>(src);
+        }
+    } else if (lane < PB) {                            // BORDER_REFLECT_101, byte by byte
+        uint8_t* Pb = reinterpret_cast<uint8_t*>(Pdw);
+        const int gx = reflect101(xa + lane, L.w);
+        for (int r = 0; r < PW; r++) {
+            const int gy = reflect101(y0 - PR + r, L.h);
+            Pb[r * PB + lane] = img[(size_t)gy * L.pitch + gx];
+        }
+    }
+    __syncthreads();
+    const uint8_t* P = reinterpret_cast<const uint8_t*>(Pdw) + xoff;     // P[r*PB + c] = patch (row r, column c)
+
+    // ---- IC_Angle (:78-105): two lanes per patch row (left / right half incl. centre on the left)
+    int m10 = 0, m01 = 0;
+    if (lane < 62) {
+        const int v = (lane >> 1) - 15;
+        const int d = (int)(G.umaxPacked >> (4 * (v < 0 ? -v : v))) & 15;
+        const uint8_t* row = P + (PR + v) * PB + PR;
+        const int ub = (lane & 1) ? 1 : -d, ue = (lane & 1) ? d : 0;
+        int s0 = 0, s1 = 0;
+        for (int u = ub; u <= ue; u++) {
+            const int val = row[u];
+            s0 += val;
+            s1 += u * val;
+        }
+        m10 = s1;
+        m01 = v * s0;
+    }
+    m10 = wave_sum(m10);
+    m01 = wave_sum(m01);
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+
+    // ---- horizontal 7-tap pass: H[r][b] for LDS byte positions b = 0..43 (patch column b - xoff)
+    for (int idx = lane; idx < PW * 11; idx += WAVE) {
+        const int r = idx / 11, q = idx - r * 11;
+        const uint32_t* p = Pdw + r * PDW + q - 1;
+        unsigned o[4];
+        hblur4(p[0], p[1], p[2], o);
+        uint2 w;
+        w.x = o[0] | (o[1] << 16);
+        w.y = o[2] | (o[3] << 16);
+        *reinterpret_cast<uint2*>(&H[r * HP + 4 * q]) = w;
+    }
+    __syncthreads();
+
+    // ---- steered BRIEF (:120-161): lane handles pairs lane, lane+64, lane+128, lane+192
+    const float rad = __fmul_rn(angle, __uint_as_float(0x3c8efa35u));       // (float)(CV_PI/180.f)
+    float a, b;
+    orb_sincos(rad, &a, &b);
+    // blurred sample at pattern point (px,py) rotated by the keypoint angle (GET_VALUE, :132-134)
+    const uint16_t* Hc = H + xoff + PR;                // Hc[row*HP + ic] = row-blurred patch at column 21+ic
+    auto sample = [&](int pxi, int pyi) -> int {
+        const float px = (float)pxi, py = (float)pyi;
+        const float fr = __fadd_rn(__fmul_rn(px, b), __fmul_rn(py, a));
+        const float fc = __fsub_rn(__fmul_rn(px, a), __fmul_rn(py, b));
+        const int ir = __float2int_rn(fr), ic = __float2int_rn(fc);
+        const uint16_t* h = Hc + (PR + ir - 3) * HP + ic;
+        const int acc = 18 * (h[0] + h[6 * HP]) + 34 * (h[HP] + h[5 * HP]) + 49 * (h[2 * HP] + h[4 * HP]) + 55 * h[3 * HP];
+        return min(255, (acc + 32768) >> 16);
+    };
+    const char4* pat4 = reinterpret_cast<const char4*>(pattern);
+    const char4 q0 = pat4[lane], q1 = pat4[64 + lane], q2 = pat4[128 + lane], q3 = pat4[192 + lane];
+    const unsigned long long w0 = __ballot(sample(q0.x, q0.y) < sample(q0.z, q0.w));
+    const unsigned long long w1 = __ballot(sample(q1.x, q1.y) < sample(q1.z, q1.w));
+    const unsigned long long w2 = __ballot(sample(q2.x, q2.y) < sample(q2.z, q2.w));
+    const unsigned long long w3 = __ballot(sample(q3.x, q3.y) < sample(q3.z, q3.w));
+
+    if (lane < 4) {
+        const unsigned long long w = lane == 0 ? w0 : lane == 1 ? w1 : lane == 2 ? w2 : w3;
+        reinterpret_cast<unsigned long long*>(descOut + ((size_t)f * cap + off + k) * ORB_DESC_BYTES)[lane] = w;
+    }
+    if (lane == 0) {
+        orb_keypoint kp;
+        kp.x = (float)x0;
+        kp.y = (float)y0;
+        if (level != 0) {                               // :1140-1146
+            kp.x = __fmul_rn(kp.x, L.scale);
+            kp.y = __fmul_rn(kp.y, L.scale);
+        }
+        kp.size = L.sizeField;
+        kp.angle = angle;
+        kp.response = (float)resp;
+        kp.octave = level;
+        kp.class_id = -1;
+        kpsOut[(size_t)f * cap + off + k] = kp;
+    }
+}
+
+void orb_launch_orient_desc(hipStream_t st, const OrbGeom& G, const uint8_t* pyr, size_t pyrSlab,
+                            const uint32_t* kpl, const int* kpCount, const int8_t* pattern,
+                            orb_keypoint* kps, uint8_t* desc, int cap, int32_t* counts, int* errFlags,
+                            int nFrames)
+{
+    hipLaunchKernelGGL(k_orient_desc, dim3(G.kpSlab, nFrames), dim3(WAVE), 0, st, G, pyr, pyrSlab, kpl, kpCount,
+                       pattern, kps, desc, cap, counts, errFlags);
+}

@@ -304,7 +304,8 @@ static int build_geometry(orb_extractor* h, int rows, int cols)
     h->ytabOff.assign(nl, 0);
     for (int l = 1; l < nl; l++) {
         axis_table(G.L[l - 1].w, G.L[l].w, true, t);
-        h->xtabOff[l] = xt.size();
+        while (t.size() % 4) t.push_back(t.back());           // k_resize_level4 reads four entries at a time
+        h->xtabOff[l] = xt.size();                             // stays a multiple of 4 -> 32-byte aligned
         xt.insert(xt.end(), t.begin(), t.end());
         axis_table(G.L[l - 1].h, G.L[l].h, false, t);
         h->ytabOff[l] = yt.size();
@@ -325,7 +326,7 @@ static int ensure_scratch(orb_extractor* h, int nFrames)
 {
     if (nFrames <= h->framesCap) return ORB_OK;
     int rc;
-    if ((rc = h->dPyr.ensure(h->pyrSlab * nFrames)) != ORB_OK) return rc;
+    if ((rc = h->dPyr.ensure(h->pyrSlab * nFrames + 256)) != ORB_OK) return rc;   // + slack: window loads overrun a row by <= 11 B
     if ((rc = h->dCand.ensure(h->candSlab * 8 * nFrames)) != ORB_OK) return rc;
     if ((rc = h->dKpl.ensure((size_t)h->G.kpSlab * 4 * nFrames)) != ORB_OK) return rc;
     if ((rc = h->dCandCount.ensure((size_t)ORB_MAX_LEVELS * 4 * nFrames)) != ORB_OK) return rc;
