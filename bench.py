@@ -125,7 +125,8 @@ def main():
     elapsed = shard.max_over_ranks(dist, elapsed, dev)
     frames_done = shard.sum_over_ranks(dist, B * args.steps, dev)
 
-    stage_ms = ex.stage_ms()                       # HIP events on the extractor's own stream
+    stage_ms = ex.stage_ms()                       # HIP events on the stream the kernels were launched on
+    launch_frames = ex.profiled_frames()           # frames per timed launch (sub-batch 0)
     ex.set_profiling(False)
     counts = d_counts.cpu().numpy()
     nm = d_nm.cpu().numpy()
@@ -142,7 +143,7 @@ def main():
     names = ["pyramid(k_copy_level0+7x k_resize_level)", "k_fast_cells", "k_quadtree", "k_orient_desc"]
     dom = int(np.argmax(stage_ms[:4]))
     bytes_frame = algorithmic_bytes_per_frame(W, H, pyr_px, mean_kp)
-    achieved = bytes_frame * B / (float(stage_ms[dom]) * 1e-3) / 1e9
+    achieved = bytes_frame * launch_frames / (float(stage_ms[dom]) * 1e-3) / 1e9
     out = {
         "metric": "frames/sec ORB extract+match, 640x480 8-level 1000-feat; HBM GB/s vs peak",
         "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -153,10 +154,11 @@ def main():
                                % (B, W, H, args.nfeatures),
                    "frames_per_gpu": B, "match": not args.no_match, "mean_keypoints": round(mean_kp, 1),
                    "mean_bow_matches": round(float(nm.mean()), 1),
-                   "stage_ms_per_batch": {n: round(float(v), 4) for n, v in zip(names + ["extract_total"], stage_ms)}},
+                   "frames_per_launch": launch_frames,
+                   "stage_ms_per_launch": {n: round(float(v), 4) for n, v in zip(names + ["extract_total"], stage_ms)}},
         "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                     "algorithmic_bytes_per_frame": int(bytes_frame), "frames_per_launch": B,
+                     "algorithmic_bytes_per_frame": int(bytes_frame), "frames_per_launch": launch_frames,
                      "kernel_ms_per_launch": round(float(stage_ms[dom]), 4)},
     }
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")     # filled by tools/pmc_summary.py from rocprofv3 --pmc runs
@@ -164,7 +166,7 @@ def main():
         try:
             tr = json.load(open(pmc))
             key = names[dom].split("(")[0]
-            if tr.get("frames_per_launch") == B and key in tr.get("bytes_per_launch", {}):
+            if tr.get("frames_per_launch") == launch_frames and key in tr.get("bytes_per_launch", {}):
                 out["roofline"]["traffic"] = tr["bytes_per_launch"][key]
         except Exception:
             pass

@@ -119,6 +119,9 @@ int orb_get_level_counts(orb_extractor* h, int frame, int32_t* kept, int32_t* ca
  * stages: 0 pyramid, 1 FAST cells, 2 quadtree, 3 orientation+descriptors, 4 total. */
 int orb_extractor_set_profiling(orb_extractor* h, int enable);
 int orb_extractor_get_stage_ms(orb_extractor* h, float* ms5);
+/* Large batches are cut into sub-batches that run the kernel chain on separate streams; the stage
+ * times above are those of sub-batch 0.  This returns how many frames each timed launch covered. */
+int orb_extractor_profiled_frames(const orb_extractor* h);
 
 /* The HIP stream (hipStream_t) the handle launches on, for callers that need to order their own
  * device work against it; and the reverse: make the handle's stream wait (on the device, no host

@@ -55,7 +55,11 @@ struct orb_extractor {
     hipStream_t stream = nullptr;
     static const int kProfSlots = 64;
     hipEvent_t ev[kProfSlots][5];           // ring of per-batch stage boundaries
-    hipEvent_t waitEv = nullptr;
+    hipEvent_t waitEv = nullptr, forkEv = nullptr;
+    static const int kMaxSub = 8;
+    hipStream_t sub[kMaxSub] = {};
+    hipEvent_t joinEv[kMaxSub] = {};
+    int maxSub = 1, minSubFrames = 32, profFrames = 0;   // sub-batching measured: no gain on MI355X (kernels already fill the chip)
     bool profiling = false;
     int profCount = 0;                      // batches recorded since profiling was (re)enabled
 
@@ -370,6 +374,13 @@ extern "C" int orb_extractor_create(const orb_extractor_params* p, int device_id
     for (int k = 0; k < orb_extractor::kProfSlots; k++)
         for (int i = 0; i < 5; i++) (void)hipEventCreate(&h->ev[k][i]);
     (void)hipEventCreateWithFlags(&h->waitEv, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&h->forkEv, hipEventDisableTiming);
+    for (int i = 0; i < orb_extractor::kMaxSub; i++) {
+        (void)hipStreamCreateWithFlags(&h->sub[i], hipStreamNonBlocking);
+        (void)hipEventCreateWithFlags(&h->joinEv[i], hipEventDisableTiming);
+    }
+    if (const char* e = getenv("ORB_SUBBATCHES")) h->maxSub = std::max(1, std::min((int)orb_extractor::kMaxSub, atoi(e)));
+    if (const char* e = getenv("ORB_SUBBATCH_MIN")) h->minSubFrames = std::max(1, atoi(e));
     int rc = h->dPattern.ensure(1024);
     if (rc == ORB_OK) {
         if (hipMemcpy(h->dPattern.p, ORB_BRIEF_PATTERN_XY, 1024, hipMemcpyHostToDevice) != hipSuccess) rc = ORB_ERR_HIP;
@@ -392,6 +403,11 @@ extern "C" void orb_extractor_destroy(orb_extractor* h)
         for (int i = 0; i < 5; i++)
             if (h->ev[k][i]) (void)hipEventDestroy(h->ev[k][i]);
     if (h->waitEv) (void)hipEventDestroy(h->waitEv);
+    if (h->forkEv) (void)hipEventDestroy(h->forkEv);
+    for (int i = 0; i < orb_extractor::kMaxSub; i++) {
+        if (h->sub[i]) { (void)hipStreamSynchronize(h->sub[i]); (void)hipStreamDestroy(h->sub[i]); }
+        if (h->joinEv[i]) (void)hipEventDestroy(h->joinEv[i]);
+    }
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -469,6 +485,8 @@ extern "C" int orb_extractor_get_stage_ms(orb_extractor* h, float* ms5)
     return ORB_OK;
 }
 
+extern "C" int orb_extractor_profiled_frames(const orb_extractor* h) { return h ? h->profFrames : ORB_ERR_INVALID; }
+
 // make this handle's stream wait for everything already enqueued on `other_stream` (hipStream_t)
 extern "C" int orb_extractor_wait_for(orb_extractor* h, void* other_stream)
 {
@@ -503,27 +521,54 @@ extern "C" int orb_extract_batch_device(orb_extractor* h, const uint8_t* d_imgs,
     hipStream_t st = h->stream;
     uint8_t* pyr = (uint8_t*)h->dPyr.p;
 
-    ORB_HIP_TRY(hipMemsetAsync(h->dCandCount.p, 0, (size_t)ORB_MAX_LEVELS * 4 * nFrames, st));
-    ORB_HIP_TRY(hipMemsetAsync(h->dErr.p, 0, (size_t)4 * nFrames, st));
+    // Frames are independent, and the stages are bound by different units (pyramid: memory latency,
+    // FAST: VALU issue, descriptors: LDS), so a large batch is cut into sub-batches that run the whole
+    // chain on separate streams and overlap each other's stages.  Stage events are recorded around
+    // sub-batch 0 only (h->profFrames = frames in it).
+    int nSub = 1;
+    if (h->maxSub > 1 && nFrames >= 2 * h->minSubFrames) nSub = std::min(h->maxSub, nFrames / h->minSubFrames);
+    if (nSub > 1) {
+        ORB_HIP_TRY(hipEventRecord(h->forkEv, st));
+        for (int s = 0; s < nSub; s++) ORB_HIP_TRY(hipStreamWaitEvent(h->sub[s], h->forkEv, 0));
+    }
     hipEvent_t* pe = h->ev[h->profCount % orb_extractor::kProfSlots];
-    if (h->profiling) ORB_HIP_TRY(hipEventRecord(pe[0], st));
-    orb_launch_copy_level0(st, d_imgs, rowStride, frameStride, pyr, h->pyrSlab, G.L[0].w, G.L[0].h, G.L[0].pitch, nFrames);
-    for (int l = 1; l < G.nlevels; l++)
-        orb_launch_resize(st, pyr, h->pyrSlab, G.L[l - 1], G.L[l], (const int2*)h->dXtab.p + h->xtabOff[l],
-                          (const int2*)h->dYtab.p + h->ytabOff[l], nFrames);
-    if (h->profiling) ORB_HIP_TRY(hipEventRecord(pe[1], st));
-    orb_launch_fast_cells(st, G, pyr, h->pyrSlab, (const OrbCell*)h->dCells.p, (int)h->cells.size(),
-                          (const uint32_t*)h->dPath.p, (unsigned long long*)h->dCand.p, h->candSlab, (int*)h->dCandCount.p, (int*)h->dErr.p,
-                          h->prm.ini_th_fast, h->prm.min_th_fast, nFrames);
-    if (h->profiling) ORB_HIP_TRY(hipEventRecord(pe[2], st));
-    orb_launch_quadtree(st, G, (unsigned long long*)h->dCand.p, h->candSlab, (const int*)h->dCandCount.p,
-                        (uint32_t*)h->dKpl.p, (int*)h->dKpCount.p, (int*)h->dErr.p, h->sortCap, h->nodeCap, nFrames);
-    if (h->profiling) ORB_HIP_TRY(hipEventRecord(pe[3], st));
-    orb_launch_orient_desc(st, G, pyr, h->pyrSlab, (const uint32_t*)h->dKpl.p, (const int*)h->dKpCount.p,
-                           h->patternPtr, d_kps, d_desc, cap, d_counts, (int*)h->dErr.p, nFrames);
-    if (h->profiling) {
-        ORB_HIP_TRY(hipEventRecord(pe[4], st));
-        h->profCount++;
+    for (int s = 0; s < nSub; s++) {
+        const int f0 = (int)((long long)nFrames * s / nSub), f1 = (int)((long long)nFrames * (s + 1) / nSub);
+        const int n = f1 - f0;
+        hipStream_t ss = nSub > 1 ? h->sub[s] : st;
+        const bool prof = h->profiling && s == 0;
+        uint8_t* spyr = pyr + h->pyrSlab * f0;
+        unsigned long long* scand = (unsigned long long*)h->dCand.p + h->candSlab * f0;
+        int* scc = (int*)h->dCandCount.p + (size_t)ORB_MAX_LEVELS * f0;
+        int* skc = (int*)h->dKpCount.p + (size_t)ORB_MAX_LEVELS * f0;
+        int* serr = (int*)h->dErr.p + f0;
+        uint32_t* skpl = (uint32_t*)h->dKpl.p + (size_t)G.kpSlab * f0;
+        ORB_HIP_TRY(hipMemsetAsync(scc, 0, (size_t)ORB_MAX_LEVELS * 4 * n, ss));
+        ORB_HIP_TRY(hipMemsetAsync(serr, 0, (size_t)4 * n, ss));
+        if (prof) ORB_HIP_TRY(hipEventRecord(pe[0], ss));
+        orb_launch_copy_level0(ss, d_imgs + frameStride * f0, rowStride, frameStride, spyr, h->pyrSlab, G.L[0].w, G.L[0].h,
+                               G.L[0].pitch, n);
+        for (int l = 1; l < G.nlevels; l++)
+            orb_launch_resize(ss, spyr, h->pyrSlab, G.L[l - 1], G.L[l], (const int2*)h->dXtab.p + h->xtabOff[l],
+                              (const int2*)h->dYtab.p + h->ytabOff[l], n);
+        if (prof) ORB_HIP_TRY(hipEventRecord(pe[1], ss));
+        orb_launch_fast_cells(ss, G, spyr, h->pyrSlab, (const OrbCell*)h->dCells.p, (int)h->cells.size(),
+                              (const uint32_t*)h->dPath.p, scand, h->candSlab, scc, serr, h->prm.ini_th_fast,
+                              h->prm.min_th_fast, n);
+        if (prof) ORB_HIP_TRY(hipEventRecord(pe[2], ss));
+        orb_launch_quadtree(ss, G, scand, h->candSlab, scc, skpl, skc, serr, h->sortCap, h->nodeCap, n);
+        if (prof) ORB_HIP_TRY(hipEventRecord(pe[3], ss));
+        orb_launch_orient_desc(ss, G, spyr, h->pyrSlab, skpl, skc, h->patternPtr, d_kps + (size_t)cap * f0,
+                               d_desc + (size_t)ORB_DESC_BYTES * cap * f0, cap, d_counts + f0, serr, n);
+        if (prof) {
+            ORB_HIP_TRY(hipEventRecord(pe[4], ss));
+            h->profCount++;
+            h->profFrames = n;
+        }
+        if (nSub > 1) {
+            ORB_HIP_TRY(hipEventRecord(h->joinEv[s], ss));
+            ORB_HIP_TRY(hipStreamWaitEvent(st, h->joinEv[s], 0));
+        }
     }
     ORB_HIP_TRY(hipGetLastError());
     h->lastFrames = nFrames;

@@ -57,7 +57,7 @@ SYMBOLS = [
     "orb_extractor_create", "orb_extractor_destroy", "orb_extractor_get_tables", "orb_extractor_max_keypoints",
     "orb_extractor_set_pattern", "orb_extractor_set_pattern_device", "orb_builtin_pattern", "orb_extract",
     "orb_extract_batch", "orb_extract_batch_device", "orb_extractor_sync", "orb_get_pyramid_level",
-    "orb_get_level_counts", "orb_extractor_set_profiling", "orb_extractor_get_stage_ms", "orb_extractor_stream",
+    "orb_get_level_counts", "orb_extractor_set_profiling", "orb_extractor_get_stage_ms", "orb_extractor_profiled_frames", "orb_extractor_stream",
     "orb_hamming", "orb_three_maxima", "orb_matcher_create", "orb_matcher_destroy", "orb_matcher_sync",
     "orb_match_bow", "orb_match_bow_kk", "orb_match_init", "orb_bow_assign_device", "orb_match_bow_batch_device",
     "orb_matcher_stream", "orb_extractor_wait_for", "orb_matcher_wait_for", "orb_last_error", "orb_version",
@@ -92,6 +92,7 @@ def lib():
     L.orb_get_level_counts.argtypes = [vp, ci, vp, vp]
     L.orb_extractor_set_profiling.argtypes = [vp, ci]
     L.orb_extractor_get_stage_ms.argtypes = [vp, vp]
+    L.orb_extractor_profiled_frames.argtypes = [vp]
     L.orb_extractor_stream.argtypes = [vp]
     L.orb_extractor_stream.restype = vp
     L.orb_hamming.argtypes = [vp, vp]
@@ -237,6 +238,9 @@ class Extractor:
         ms = np.zeros(5, np.float32)
         _check(self.L.orb_extractor_get_stage_ms(self.h, _p(ms)))
         return ms
+
+    def profiled_frames(self):
+        return self.L.orb_extractor_profiled_frames(self.h)
 
     @property
     def stream(self):
