@@ -146,51 +146,96 @@ struct BowSide {
     int n;
 };
 
-// Build offsets/indices of one side in LDS: thread t owns node t and scans the features in
-// ascending index order (the order DBoW2 pushes them), so lists come out exactly as the map holds them.
-__device__ void build_csr(const uint16_t* nodeLds, int n, int nNodes, uint16_t* offs, uint16_t* idx, int* cnt)
+// ---- wave64 unsigned-min reduction with DPP (row_shr 1,2,4,8, row_bcast 15/31): result in lane 63
+#define ORB_DPP_UMIN(v, ctrl, rmask, bmask) \
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)0xFFFFFFFF, (int)(v), ctrl, rmask, bmask, false))
+__device__ __forceinline__ unsigned wave_umin_dpp(unsigned v)
 {
-    for (int t = threadIdx.x; t < nNodes; t += blockDim.x) {
-        int c = 0;
-        for (int i = 0; i < n; i++) c += (nodeLds[i] == t);
-        cnt[t] = c;
+    ORB_DPP_UMIN(v, 0x111, 0xf, 0xf);
+    ORB_DPP_UMIN(v, 0x112, 0xf, 0xf);
+    ORB_DPP_UMIN(v, 0x114, 0xf, 0xf);
+    ORB_DPP_UMIN(v, 0x118, 0xf, 0xf);
+    ORB_DPP_UMIN(v, 0x142, 0xa, 0xf);
+    ORB_DPP_UMIN(v, 0x143, 0xc, 0xf);
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// ascending bitonic sort of a[0..n) (u32) by the whole block, virtual +inf padding
+__device__ void block_sort_u32(uint32_t* a, int n)
+{
+    int np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    for (int k = 2; k <= np2; k <<= 1) {
+        for (int i = threadIdx.x; i < np2; i += blockDim.x) {
+            const int p = i ^ (k - 1);
+            if (p > i && p < n) {
+                const uint32_t x = a[i], y = a[p];
+                if (x > y) { a[i] = y; a[p] = x; }
+            }
+        }
+        __syncthreads();
+        for (int j = k >> 2; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < np2; i += blockDim.x) {
+                const int p = i ^ j;
+                if (p > i && p < n) {
+                    const uint32_t x = a[i], y = a[p];
+                    if (x > y) { a[i] = y; a[p] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// One side's feature vector as CSR in LDS: keys = (node << 16 | index), sorted -> node-major, ascending
+// index inside a node (DBoW2's push order); start[node] / cnt[node] from the run boundaries.
+__device__ void build_csr(const uint16_t* __restrict__ nodeOf, int n, int nNodes, uint32_t* keys, uint16_t* start,
+                          uint16_t* cnt)
+{
+    for (int t = threadIdx.x; t < nNodes; t += blockDim.x) { start[t] = 0xFFFF; cnt[t] = 0; }
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const unsigned nd = nodeOf[i];
+        keys[i] = ((nd < (unsigned)nNodes ? nd : 0xFFFFu) << 16) | (unsigned)i;   // node-less features sort last
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        int run = 0;
-        for (int t = 0; t < nNodes; t++) { offs[t] = (uint16_t)run; run += cnt[t]; }
-        offs[nNodes] = (uint16_t)run;
+    block_sort_u32(keys, n);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const unsigned nd = keys[i] >> 16;
+        if (nd < (unsigned)nNodes && (i == 0 || (keys[i - 1] >> 16) != nd)) start[nd] = (uint16_t)i;
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < nNodes; t += blockDim.x) {
-        int w = offs[t];
-        for (int i = 0; i < n; i++)
-            if (nodeLds[i] == t) idx[w++] = (uint16_t)i;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const unsigned nd = keys[i] >> 16;
+        if (nd < (unsigned)nNodes && (i + 1 == n || (keys[i + 1] >> 16) != nd)) cnt[nd] = (uint16_t)(i + 1 - start[nd]);
     }
     __syncthreads();
 }
 
 // KK == false: SearchByBoW(KeyFrame*, Frame&)   -> out[iB] = iA   (B = Frame, A = KeyFrame)
 // KK == true : SearchByBoW(KeyFrame*, KeyFrame*) -> out[iA] = iB  (A = KF1, B = KF2), B needs valid, strict <
+//
+// 16 waves per pair; a wave owns whole vocabulary nodes.  Inside a node the A-side loop is serial (the
+// greedy rule), but nothing in it touches memory: each lane keeps ONE B descriptor and its "taken" flag
+// in registers, the A descriptors of the node are preloaded one per lane and broadcast with v_readlane,
+// best / second-best are two DPP min-reductions on packed (distance << 16 | position).
 template <bool KK>
-__global__ __launch_bounds__(256) void k_match_bow(const BowSide* __restrict__ sidesA, const BowSide* __restrict__ sidesB,
-                                                   int nNodes, int capLds, float ratio, int checkOri,
-                                                   int32_t* __restrict__ match, int matchStride,
-                                                   int32_t* __restrict__ nmatchesOut)
+__global__ __launch_bounds__(1024) void k_match_bow(const BowSide* __restrict__ sidesA, const BowSide* __restrict__ sidesB,
+                                                    int nNodes, int capLds, float ratio, int checkOri,
+                                                    int32_t* __restrict__ match, int matchStride,
+                                                    int32_t* __restrict__ nmatchesOut)
 {
-    extern __shared__ uint16_t msm[];
-    // carve-up (u16 units): nodeA[cap] nodeB[cap] idxA[cap] idxB[cap] offsA[nNodes+1] offsB[nNodes+1]
-    //                       res[cap] (i16 match) bin[cap] (u8 pairs packed in u16 slots) taken[cap]
-    uint16_t* nodeA = msm;
-    uint16_t* nodeB = nodeA + capLds;
-    uint16_t* idxA = nodeB + capLds;
-    uint16_t* idxB = idxA + capLds;
-    uint16_t* offsA = idxB + capLds;
-    uint16_t* offsB = offsA + (nNodes + 2);
-    int16_t* res = reinterpret_cast<int16_t*>(offsB + (nNodes + 2));
-    uint16_t* bin = reinterpret_cast<uint16_t*>(res + capLds);
-    uint16_t* taken = bin + capLds;
-    int* cnt = reinterpret_cast<int*>(taken + capLds + (capLds & 1));   // [nNodes] scratch, 4-byte aligned
+    extern __shared__ uint32_t msm[];
+    // carve-up: keysA[cap] keysB[cap] (u32) | startA cntA startB cntB [nNodes] (u16) | res[cap] (i16) |
+    //           bin[cap] takenB[cap] (u8)
+    uint32_t* keysA = msm;
+    uint32_t* keysB = keysA + capLds;
+    uint16_t* startA = reinterpret_cast<uint16_t*>(keysB + capLds);
+    uint16_t* cntA = startA + nNodes;
+    uint16_t* startB = cntA + nNodes;
+    uint16_t* cntB = startB + nNodes;
+    int16_t* res = reinterpret_cast<int16_t*>(cntB + nNodes);
+    uint8_t* bin = reinterpret_cast<uint8_t*>(res + capLds);
+    uint8_t* takenB = bin + capLds;
     __shared__ int hist[HISTO_LENGTH];
     __shared__ int keepBins[3];
     __shared__ int nm;
@@ -198,76 +243,105 @@ __global__ __launch_bounds__(256) void k_match_bow(const BowSide* __restrict__ s
     const BowSide A = sidesA[blockIdx.x], B = sidesB[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nWaves = blockDim.x >> 6;
     const int nRes = KK ? A.n : B.n;
-    for (int i = tid; i < A.n; i += blockDim.x) nodeA[i] = A.nodeOf[i];
-    for (int i = tid; i < B.n; i += blockDim.x) {
-        nodeB[i] = B.nodeOf[i];
-        taken[i] = (KK && B.valid && !B.valid[i]) ? 1 : 0;     // :750 "!pMP2 || isBad" folded into the taken flag
-    }
     for (int i = tid; i < nRes; i += blockDim.x) { res[i] = -1; bin[i] = 0xFF; }
+    for (int i = tid; i < B.n; i += blockDim.x) takenB[i] = (KK && B.valid && !B.valid[i]) ? 1 : 0;   // :750
     if (tid < HISTO_LENGTH) hist[tid] = 0;
     if (tid == 0) nm = 0;
-    __syncthreads();
-    build_csr(nodeA, A.n, nNodes, offsA, idxA, cnt);
-    build_csr(nodeB, B.n, nNodes, offsB, idxB, cnt);
+    build_csr(A.nodeOf, A.n, nNodes, keysA, startA, cntA);
+    build_csr(B.nodeOf, B.n, nNodes, keysB, startB, cntB);
 
     for (int node = wave; node < nNodes; node += nWaves) {
-        const int a0 = offsA[node], a1 = offsA[node + 1];
-        const int b0 = offsB[node], b1 = offsB[node + 1];
-        if (a0 == a1 || b0 == b1) continue;
-        const int nb = b1 - b0;
-        // fast path: the node's B features fit one wave -> keep their descriptors in registers
-        uint32_t dB[8];
-        int iB = -1;
-        if (lane < nb) {
-            iB = idxB[b0 + lane];
-            load_desc(B.desc + (size_t)iB * 32, dB);
-        }
-        for (int p = a0; p < a1; p++) {
-            const int iA = idxA[p];
-            if (A.valid && !A.valid[iA]) continue;                       // :590-595
-            uint32_t dA[8];
-            load_desc(A.desc + (size_t)iA * 32, dA);
-            unsigned best = (256u << 16) | 0xFFFFu;                      // (dist, position) packed
-            unsigned second = 256u;
-            for (int base = 0; base < nb; base += WAVE) {
-                const int q = base + lane;
-                unsigned d = 256u;
-                if (q < nb) {
-                    int j;
-                    if (base == 0) j = iB;
-                    else { j = idxB[b0 + q]; load_desc(B.desc + (size_t)j * 32, dB); }
-                    if (!taken[j]) d = (unsigned)hamming8(dA, dB);       // :607 / :750
-                }
-                const unsigned mine = (d << 16) | (unsigned)q;
-                const unsigned m1 = wave_min_u32(mine);
-                const unsigned m2 = wave_min_u32(mine == m1 ? 0xFFFFFFFFu : mine);
-                // merge chunk (m1, m2) into running (best, second) with sequential-scan semantics
-                const unsigned d1 = m1 >> 16, d2 = (m2 == 0xFFFFFFFFu) ? 256u : (m2 >> 16);
-                if (d1 < (best >> 16)) {
-                    second = min(best >> 16, d2);
-                    best = m1;
-                } else {
-                    second = min(second, d1);
-                }
+        const int na = cntA[node], nb = cntB[node];
+        if (na == 0 || nb == 0) continue;
+        const int a0 = startA[node], b0 = startB[node];
+        if (nb <= WAVE) {
+            // ---- fast path: the node's B features fit the wave; everything stays in registers
+            uint32_t dB[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            int jB = -1;
+            bool taken = true;
+            if (lane < nb) {
+                jB = (int)(keysB[b0 + lane] & 0xFFFFu);
+                load_desc(B.desc + (size_t)jB * 32, dB);
+                taken = takenB[jB] != 0;
             }
-            if (nb > WAVE && lane < nb) {                                // restore chunk 0 for the next KF feature
-                iB = idxB[b0 + lane];
-                load_desc(B.desc + (size_t)iB * 32, dB);
-            }
-            const int best1 = (int)(best >> 16), best2 = (int)second;
-            const bool pass = KK ? (best1 < TH_LOW) : (best1 <= TH_LOW);  // :772 vs :625
-            if (pass && (float)best1 < __fmul_rn(ratio, (float)best2)) {
-                const int jB = idxB[b0 + (int)(best & 0xFFFFu)];
-                if (lane == 0) {
-                    taken[jB] = 1;
-                    const int rIdx = KK ? iA : jB;
-                    res[rIdx] = (int16_t)(KK ? jB : iA);
-                    if (checkOri)
-                        bin[rIdx] = (uint16_t)rot_bin(A.angle[(size_t)iA * A.angleStride], B.angle[(size_t)jB * B.angleStride]);
+            for (int abase = 0; abase < na; abase += WAVE) {
+                const int nChunk = min(WAVE, na - abase);
+                uint32_t dA[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                int iAl = -1;
+                bool okA = false;
+                if (lane < nChunk) {
+                    iAl = (int)(keysA[a0 + abase + lane] & 0xFFFFu);
+                    okA = !(A.valid && !A.valid[iAl]);                     // :590-595
+                    if (okA) load_desc(A.desc + (size_t)iAl * 32, dA);
+                }
+                const unsigned long long okMask = __ballot(okA);
+                for (int p = 0; p < nChunk; p++) {
+                    if (!((okMask >> p) & 1)) continue;
+                    unsigned d = 256u;
+                    if (!taken) {
+                        d = 0;
+#pragma unroll
+                        for (int w = 0; w < 8; w++) d += __popc(dB[w] ^ (uint32_t)__builtin_amdgcn_readlane((int)dA[w], p));
+                    }
+                    const unsigned mine = (d << 16) | (unsigned)lane;
+                    const unsigned m1 = wave_umin_dpp(mine);
+                    const unsigned m2 = wave_umin_dpp(mine == m1 ? 0xFFFFFFFFu : mine);
+                    const int best1 = (int)(m1 >> 16), best2 = (int)(m2 >> 16);      // 256 when nothing is left
+                    const bool pass = KK ? (best1 < TH_LOW) : (best1 <= TH_LOW);      // :772 vs :625
+                    if (pass && (float)best1 < __fmul_rn(ratio, (float)best2)) {
+                        const int win = (int)(m1 & 0xFFFFu);
+                        const int iA = __builtin_amdgcn_readlane(iAl, p);
+                        if (lane == win) {
+                            taken = true;
+                            takenB[jB] = 1;
+                            const int rIdx = KK ? iA : jB;
+                            res[rIdx] = (int16_t)(KK ? jB : iA);
+                            if (checkOri)
+                                bin[rIdx] = (uint8_t)rot_bin(A.angle[(size_t)iA * A.angleStride], B.angle[(size_t)jB * B.angleStride]);
+                        }
+                    }
                 }
             }
-            __builtin_amdgcn_wave_barrier();
-            __threadfence_block();
+        } else {
+            // ---- general path (> 64 B features in one node): chunked, taken flags in LDS
+            for (int p = a0; p < a0 + na; p++) {
+                const int iA = (int)(keysA[p] & 0xFFFFu);
+                if (A.valid && !A.valid[iA]) continue;
+                uint32_t dA[8], dB[8];
+                load_desc(A.desc + (size_t)iA * 32, dA);
+                unsigned best = (256u << 16) | 0xFFFFu, second = 256u;
+                for (int base = 0; base < nb; base += WAVE) {
+                    const int q = base + lane;
+                    unsigned d = 256u;
+                    if (q < nb) {
+                        const int j = (int)(keysB[b0 + q] & 0xFFFFu);
+                        if (!takenB[j]) {
+                            load_desc(B.desc + (size_t)j * 32, dB);
+                            d = (unsigned)hamming8(dA, dB);
+                        }
+                    }
+                    const unsigned mine = (d << 16) | (unsigned)q;
+                    const unsigned m1 = wave_umin_dpp(mine);
+                    const unsigned m2 = wave_umin_dpp(mine == m1 ? 0xFFFFFFFFu : mine);
+                    const unsigned d1 = m1 >> 16, d2 = min(256u, m2 >> 16);
+                    if (d1 < (best >> 16)) { second = min(best >> 16, d2); best = m1; }
+                    else second = min(second, d1);
+                }
+                const int best1 = (int)(best >> 16), best2 = (int)second;
+                const bool pass = KK ? (best1 < TH_LOW) : (best1 <= TH_LOW);
+                if (pass && (float)best1 < __fmul_rn(ratio, (float)best2)) {
+                    const int jB = (int)(keysB[b0 + (int)(best & 0xFFFFu)] & 0xFFFFu);
+                    if (lane == 0) {
+                        takenB[jB] = 1;
+                        const int rIdx = KK ? iA : jB;
+                        res[rIdx] = (int16_t)(KK ? jB : iA);
+                        if (checkOri)
+                            bin[rIdx] = (uint8_t)rot_bin(A.angle[(size_t)iA * A.angleStride], B.angle[(size_t)jB * B.angleStride]);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                __threadfence_block();
+            }
         }
     }
     __syncthreads();
@@ -279,7 +353,7 @@ __global__ __launch_bounds__(256) void k_match_bow(const BowSide* __restrict__ s
             local++;
             if (checkOri) atomicAdd(&hist[bin[i]], 1);
         }
-    atomicAdd(&nm, local);
+    if (local) atomicAdd(&nm, local);
     __syncthreads();
     if (checkOri) {
         if (tid == 0) {
@@ -294,7 +368,7 @@ __global__ __launch_bounds__(256) void k_match_bow(const BowSide* __restrict__ s
                 const int bb = bin[i];
                 if (bb != keepBins[0] && bb != keepBins[1] && bb != keepBins[2]) { res[i] = -1; dropped++; }
             }
-        atomicSub(&nm, dropped);
+        if (dropped) atomicSub(&nm, dropped);
         __syncthreads();
     }
     int32_t* out = match + (size_t)blockIdx.x * matchStride;
@@ -326,8 +400,7 @@ __global__ void k_fill_sides(orb_featstore S, const int32_t* __restrict__ kfInde
 // ------------------------------------------------------------------ host side
 static size_t match_lds_bytes(int capLds, int nNodes)
 {
-    size_t u16s = (size_t)capLds * 7 + (capLds & 1) + 2 * (size_t)(nNodes + 2);
-    return u16s * 2 + (size_t)nNodes * 4 + 8;
+    return (size_t)capLds * (4 + 4 + 2 + 1 + 1) + (size_t)nNodes * 8 + 16;
 }
 
 extern "C" int orb_matcher_create(int device_id, orb_matcher** out)
@@ -404,10 +477,10 @@ static int launch_match(orb_matcher* m, bool kk, const BowSide* dA, const BowSid
         return ORB_ERR_UNSUPPORTED;
     }
     if (kk)
-        hipLaunchKernelGGL(k_match_bow<true>, dim3(nPairs), dim3(256), lds, m->stream, dA, dB, nNodes, capLds, ratio,
+        hipLaunchKernelGGL(k_match_bow<true>, dim3(nPairs), dim3(1024), lds, m->stream, dA, dB, nNodes, capLds, ratio,
                            checkOri, dMatch, matchStride, dNm);
     else
-        hipLaunchKernelGGL(k_match_bow<false>, dim3(nPairs), dim3(256), lds, m->stream, dA, dB, nNodes, capLds, ratio,
+        hipLaunchKernelGGL(k_match_bow<false>, dim3(nPairs), dim3(1024), lds, m->stream, dA, dB, nNodes, capLds, ratio,
                            checkOri, dMatch, matchStride, dNm);
     ORB_HIP_TRY(hipGetLastError());
     return ORB_OK;
