@@ -215,6 +215,25 @@ int orb_match_bow_batch_device(orb_matcher* m, const orb_featstore* store,
 void* orb_matcher_stream(orb_matcher* m);
 int orb_matcher_wait_for(orb_matcher* m, void* hip_stream);
 
+/* ---------------------------------------------------------------- stereo search -------------
+ * Additional entry point (Frame.cc links unchanged and keeps its own CPU body): the whole of
+ * void Frame::ComputeStereoMatches(), reference src/Frame.cc:513-699, on the pyramids that the LEFT and
+ * RIGHT extractor handles hold on the device after their last orb_extract*() call (the reference reads
+ * mpORBextractorLeft/Right->mvImagePyramid, :520,611,626,633).  kps/desc are mvKeys/mDescriptors and
+ * mvKeysRight/mDescriptorsRight; mb, mbf are Frame::mb, Frame::mbf.  u_right/depth receive mvuRight /
+ * mvDepth (n_l floats each, -1 = no match).  Both handles must be on the same device and have seen
+ * images of the same size.  Host buffers, synchronous. */
+int orb_stereo_match(orb_extractor* left, orb_extractor* right,
+                     const orb_keypoint* kps_l, const uint8_t* desc_l, int n_l,
+                     const orb_keypoint* kps_r, const uint8_t* desc_r, int n_r,
+                     float mb, float mbf, float* u_right, float* depth);
+/* Same with device pointers, for frame_l / frame_r of the handles' last batches; asynchronous on the
+ * LEFT handle's stream (which is made to wait for the right handle's stream). */
+int orb_stereo_match_device(orb_extractor* left, orb_extractor* right, int frame_l, int frame_r,
+                            const orb_keypoint* d_kps_l, const uint8_t* d_desc_l, int n_l,
+                            const orb_keypoint* d_kps_r, const uint8_t* d_desc_r, int n_r,
+                            float mb, float mbf, float* d_u_right, float* d_depth);
+
 /* ---------------------------------------------------------------- misc ---------------------*/
 const char* orb_last_error(void);   /* thread-local description of the last failure */
 const char* orb_version(void);

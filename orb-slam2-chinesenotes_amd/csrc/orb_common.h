@@ -34,6 +34,7 @@ struct OrbLevelGeom {
     float hX;                   // root width (reference :568)
     int boxW, boxH;             // maxX-minX, maxY-minY
     float scale;                // mvScaleFactor[level]
+    float invScale;             // mvInvScaleFactor[level]
     float sizeField;            // (float)(int)(31*scale)
 };
 

@@ -10,7 +10,7 @@
 #include <vector>
 
 #include "../../include/orb_brief_pattern.h"
-#include "orb_kernels.h"
+#include "orb_extractor_internal.h"
 
 #pragma clang fp contract(off)
 
@@ -29,61 +29,6 @@ extern "C" const char* orb_version(void) { return "orbhip 0.1 (gfx950)"; }
 static inline int cv_round_f(float v) { return (int)lrintf(v); }      // round-half-even
 static inline int cv_round_d(double v) { return (int)lrint(v); }
 static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
-
-struct DevBuf {
-    void* p = nullptr;
-    size_t bytes = 0;
-    int ensure(size_t need)
-    {
-        if (need <= bytes) return ORB_OK;
-        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
-        ORB_HIP_TRY(hipMalloc(&p, need));
-        bytes = need;
-        return ORB_OK;
-    }
-    void release()
-    {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        bytes = 0;
-    }
-};
-
-struct orb_extractor {
-    orb_extractor_params prm;
-    int device = 0;
-    hipStream_t stream = nullptr;
-    static const int kProfSlots = 64;
-    hipEvent_t ev[kProfSlots][5];           // ring of per-batch stage boundaries
-    hipEvent_t waitEv = nullptr, forkEv = nullptr;
-    static const int kMaxSub = 8;
-    hipStream_t sub[kMaxSub] = {};
-    hipEvent_t joinEv[kMaxSub] = {};
-    int maxSub = 1, minSubFrames = 32, profFrames = 0;   // sub-batching measured: no gain on MI355X (kernels already fill the chip)
-    bool profiling = false;
-    int profCount = 0;                      // batches recorded since profiling was (re)enabled
-
-    // constructor tables (reference :503-558)
-    std::vector<float> scale, invScale, sigma2, invSigma2;
-    std::vector<int> quota;
-    int umax[16];
-
-    // geometry for the current image size
-    int rows = 0, cols = 0;
-    OrbGeom G;
-    std::vector<OrbCell> cells;
-    size_t pyrSlab = 0, candSlab = 0;
-    int sortCap = 4096, nodeCap = 0, maxKp = 0;
-
-    // device memory
-    DevBuf dPattern, dCells, dXtab, dYtab, dPath;   // constants
-    std::vector<size_t> xtabOff, ytabOff;       // per level offsets (in int2 units)
-    DevBuf dPyr, dCand, dKpl, dCandCount, dKpCount, dErr;   // per-batch scratch
-    DevBuf dImgs, dKps, dDesc, dCounts;         // staging for the host-buffer API
-    const int8_t* patternPtr = nullptr;         // device pointer in use (own copy or caller's)
-    int framesCap = 0, lastFrames = 0;
-    std::vector<int> hErr;
-};
 
 // ------------------------------------------------------------------ ctor tables (A.1)
 static void build_tables(orb_extractor* h)
@@ -180,6 +125,7 @@ static int build_geometry(orb_extractor* h, int rows, int cols)
         if (pyrOff > 0x7fffffffu) return ORB_ERR_UNSUPPORTED;
         L.quota = h->quota[l];
         L.scale = h->scale[l];
+        L.invScale = h->invScale[l];
         L.sizeField = (float)(int)(31 * h->scale[l]);                  // :886, :895
 
         // FAST cell grid (:805-849)
@@ -397,7 +343,8 @@ extern "C" void orb_extractor_destroy(orb_extractor* h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     DevBuf* bufs[] = {&h->dPattern, &h->dCells, &h->dXtab, &h->dYtab, &h->dPath, &h->dPyr, &h->dCand, &h->dKpl,
-                      &h->dCandCount, &h->dKpCount, &h->dErr, &h->dImgs, &h->dKps, &h->dDesc, &h->dCounts};
+                      &h->dCandCount, &h->dKpCount, &h->dErr, &h->dImgs, &h->dKps, &h->dDesc, &h->dCounts,
+                      &h->dStereo, &h->dStereoIn};
     for (DevBuf* b : bufs) b->release();
     for (int k = 0; k < orb_extractor::kProfSlots; k++)
         for (int i = 0; i < 5; i++)

@@ -1,0 +1,62 @@
+// orb_extractor_internal.h -- the extractor handle (shared by orb_extractor.hip and orb_stereo.hip).
+#pragma once
+#include <vector>
+
+#include "orb_kernels.h"
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need)
+    {
+        if (need <= bytes) return ORB_OK;
+        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+        ORB_HIP_TRY(hipMalloc(&p, need));
+        bytes = need;
+        return ORB_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
+struct orb_extractor {
+    orb_extractor_params prm;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    static const int kProfSlots = 64;
+    hipEvent_t ev[kProfSlots][5];           // ring of per-batch stage boundaries
+    hipEvent_t waitEv = nullptr, forkEv = nullptr;
+    static const int kMaxSub = 8;
+    hipStream_t sub[kMaxSub] = {};
+    hipEvent_t joinEv[kMaxSub] = {};
+    int maxSub = 1, minSubFrames = 32, profFrames = 0;   // sub-batching measured: no gain on MI355X (kernels already fill the chip)
+    bool profiling = false;
+    int profCount = 0;                      // batches recorded since profiling was (re)enabled
+
+    // constructor tables (reference :503-558)
+    std::vector<float> scale, invScale, sigma2, invSigma2;
+    std::vector<int> quota;
+    int umax[16];
+
+    // geometry for the current image size
+    int rows = 0, cols = 0;
+    OrbGeom G;
+    std::vector<OrbCell> cells;
+    size_t pyrSlab = 0, candSlab = 0;
+    int sortCap = 4096, nodeCap = 0, maxKp = 0;
+
+    // device memory
+    DevBuf dPattern, dCells, dXtab, dYtab, dPath;   // constants
+    std::vector<size_t> xtabOff, ytabOff;       // per level offsets (in int2 units)
+    DevBuf dPyr, dCand, dKpl, dCandCount, dKpCount, dErr;   // per-batch scratch
+    DevBuf dImgs, dKps, dDesc, dCounts;         // staging for the host-buffer API
+    DevBuf dStereo, dStereoIn;                  // stereo search: (SAD, index) pairs; host-API staging
+    const int8_t* patternPtr = nullptr;         // device pointer in use (own copy or caller's)
+    int framesCap = 0, lastFrames = 0;
+    std::vector<int> hErr;
+};
+

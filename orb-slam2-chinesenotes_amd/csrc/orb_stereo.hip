@@ -1,0 +1,250 @@
+// orb_stereo.hip -- "ORBmatcher stereo search" of BASELINE config 3: Frame::ComputeStereoMatches,
+// reference src/Frame.cc:513-699, on gfx950, reading the two extractors' DEVICE-RESIDENT pyramids
+// (the reference reads mpORBextractorLeft/Right->mvImagePyramid, :520,611,626,633).
+//
+// Frame.cc must link unchanged, so this is an ADDITIONAL entry point, parity-
+// checked against the oracle's restatement; a maintainer may call it from ComputeStereoMatches.
+//
+//   k_stereo_match     one wave64 per left keypoint: row-band test against every right keypoint
+//                      (no row table: 64 candidates per step, ascending index = the table's order),
+//                      Hamming coarse match (first minimum wins), 11x11 SAD at 11 offsets from LDS
+//                      patches (exact integers: the float patches of the reference hold integers),
+//                      parabola fit and depth in float with the reference's operation order.
+//   k_stereo_outliers  one workgroup: sort (SAD, index), median, cut >= 1.5*1.4*median (:685-698).
+#include <algorithm>
+#include <vector>
+
+#include "orb_extractor_internal.h"
+
+#pragma clang fp contract(off)
+
+#define WAVE 64
+
+__device__ __forceinline__ unsigned st_umin_dpp(unsigned v)
+{
+#define ST_DPP(ctrl, rmask) v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)0xFFFFFFFF, (int)(v), ctrl, rmask, 0xf, false))
+    ST_DPP(0x111, 0xf); ST_DPP(0x112, 0xf); ST_DPP(0x114, 0xf); ST_DPP(0x118, 0xf); ST_DPP(0x142, 0xa); ST_DPP(0x143, 0xc);
+#undef ST_DPP
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+__global__ __launch_bounds__(WAVE) void k_stereo_match(const OrbGeom G, const uint8_t* __restrict__ pyrL,
+                                                       const uint8_t* __restrict__ pyrR,
+                                                       const orb_keypoint* __restrict__ kL,
+                                                       const uint8_t* __restrict__ dL, int N,
+                                                       const orb_keypoint* __restrict__ kR,
+                                                       const uint8_t* __restrict__ dR, int Nr, float maxD,
+                                                       float mbf, float* __restrict__ uRight,
+                                                       float* __restrict__ depth,
+                                                       unsigned long long* __restrict__ pairs,
+                                                       int* __restrict__ pairCount)
+{
+    __shared__ int IL[11][11];
+    __shared__ int IR[11][21];
+    __shared__ int part[11][11];
+    const int iL = blockIdx.x, lane = threadIdx.x;
+    if (iL >= N) return;
+    if (lane == 0) { uRight[iL] = -1.0f; depth[iL] = -1.0f; }
+    const orb_keypoint kpL = kL[iL];
+    const int levelL = kpL.octave;
+    const float vL = kpL.y, uL = kpL.x;
+    const int nRows = G.L[0].h;
+    const int row = (int)vL;                                       // vRowIndices[vL] (:560)
+    if (vL < 0.0f || row >= nRows) return;
+    const float minU = __fsub_rn(uL, maxD), maxU = uL;             // minD == 0 (:543-544, :565-566)
+    if (maxU < 0) return;
+
+    // ---- coarse match (:573-595): candidates in ascending iR, first minimum below TH_HIGH wins
+    uint32_t dl[8];
+    {
+        const uint4 lo = reinterpret_cast<const uint4*>(dL + (size_t)iL * 32)[0], hi = reinterpret_cast<const uint4*>(dL + (size_t)iL * 32)[1];
+        dl[0] = lo.x; dl[1] = lo.y; dl[2] = lo.z; dl[3] = lo.w; dl[4] = hi.x; dl[5] = hi.y; dl[6] = hi.z; dl[7] = hi.w;
+    }
+    unsigned best = 0xFFFFFFFFu;
+    for (int base = 0; base < Nr; base += WAVE) {
+        const int iR = base + lane;
+        unsigned mine = 0xFFFFFFFFu;
+        if (iR < Nr) {
+            const orb_keypoint kp = kR[iR];
+            const float r = __fmul_rn(2.0f, G.L[kp.octave].scale);            // :531
+            const int maxr = (int)ceilf(__fadd_rn(kp.y, r)), minr = (int)floorf(__fsub_rn(kp.y, r));
+            if (row >= minr && row <= maxr && kp.octave >= levelL - 1 && kp.octave <= levelL + 1 && kp.x >= minU &&
+                kp.x <= maxU) {
+                const uint4 lo = reinterpret_cast<const uint4*>(dR + (size_t)iR * 32)[0], hi = reinterpret_cast<const uint4*>(dR + (size_t)iR * 32)[1];
+                const int dist = __popc(dl[0] ^ lo.x) + __popc(dl[1] ^ lo.y) + __popc(dl[2] ^ lo.z) + __popc(dl[3] ^ lo.w) +
+                                 __popc(dl[4] ^ hi.x) + __popc(dl[5] ^ hi.y) + __popc(dl[6] ^ hi.z) + __popc(dl[7] ^ hi.w);
+                mine = ((unsigned)dist << 16) | (unsigned)iR;
+            }
+        }
+        best = min(best, st_umin_dpp(mine));
+    }
+    const int bestDist = (best == 0xFFFFFFFFu) ? 100 : min(100, (int)(best >> 16));   // init TH_HIGH, strict <
+    if (!(bestDist < 75) || best == 0xFFFFFFFFu) return;                              // thOrbDist (:518, :599)
+    const int bestIdxR = (int)(best & 0xFFFFu);
+
+    // ---- SAD refinement on the pyramid level of the LEFT keypoint (:601-648)
+    const OrbLevelGeom& Lv = G.L[levelL];
+    const float uR0 = kR[bestIdxR].x;
+    const float sf = Lv.invScale;
+    const float scaleduL = roundf(__fmul_rn(kpL.x, sf)), scaledvL = roundf(__fmul_rn(kpL.y, sf));
+    const float scaleduR0 = roundf(__fmul_rn(uR0, sf));
+    const int w = 5, Lr = 5;
+    const float iniu = __fsub_rn(__fadd_rn(scaleduR0, (float)Lr), (float)w);          // sic (:624)
+    const float endu = __fadd_rn(__fadd_rn(__fadd_rn(scaleduR0, (float)Lr), (float)w), 1.0f);
+    if (iniu < 0 || endu >= (float)Lv.w) return;
+    const int y0 = (int)__fsub_rn(scaledvL, (float)w), xL0 = (int)__fsub_rn(scaleduL, (float)w);
+    const int xR0 = (int)__fsub_rn(__fsub_rn(scaleduR0, (float)Lr), (float)w);        // leftmost column of the strip
+    const uint8_t* imL = pyrL + Lv.pyrOff;
+    const uint8_t* imR = pyrR + Lv.pyrOff;
+    // the reference would read out of the Mat here; inside the supported envelope keypoints sit >= 19 px inside
+    if (y0 < 0 || y0 + 11 > Lv.h || xL0 < 0 || xL0 + 11 > Lv.w || xR0 < 0 || xR0 + 21 > Lv.w) return;
+    for (int i = lane; i < 121; i += WAVE) IL[i / 11][i % 11] = imL[(size_t)(y0 + i / 11) * Lv.pitch + xL0 + i % 11];
+    for (int i = lane; i < 231; i += WAVE) IR[i / 21][i % 21] = imR[(size_t)(y0 + i / 21) * Lv.pitch + xR0 + i % 21];
+    __syncthreads();
+    const int cL = IL[5][5];
+    for (int i = lane; i < 121; i += WAVE) {
+        const int inc = i / 11, dy = i % 11;                     // inc = incR + 5
+        const int cR = IR[5][inc + 5];
+        int s = 0;
+#pragma unroll
+        for (int dx = 0; dx < 11; dx++) s += abs((IL[dy][dx] - cL) - (IR[dy][dx + inc] - cR));
+        part[inc][dy] = s;
+    }
+    __syncthreads();
+    if (lane != 0) return;
+    int sad[11];
+    for (int inc = 0; inc < 11; inc++) {
+        int s = 0;
+        for (int dy = 0; dy < 11; dy++) s += part[inc][dy];
+        sad[inc] = s;
+    }
+    int bestSad = 0x7FFFFFFF, bestinc = 5;                        // bestincR = 0
+    for (int inc = 0; inc < 11; inc++)
+        if (sad[inc] < bestSad) { bestSad = sad[inc]; bestinc = inc; }   // strict <, first minimum (:641-645)
+    const int bestincR = bestinc - 5;
+    if (bestincR == -Lr || bestincR == Lr) return;                 // :651
+    const float dist1 = (float)sad[bestinc - 1], dist2 = (float)sad[bestinc], dist3 = (float)sad[bestinc + 1];
+    const float deltaR = __fdiv_rn(__fsub_rn(dist1, dist3),
+                                   __fmul_rn(2.0f, __fsub_rn(__fadd_rn(dist1, dist3), __fmul_rn(2.0f, dist2))));
+    if (deltaR < -1 || deltaR > 1) return;
+    float bestuR = __fmul_rn(Lv.scale, __fadd_rn(__fadd_rn(scaleduR0, (float)bestincR), deltaR));
+    float disparity = __fsub_rn(uL, bestuR);
+    if (disparity >= 0.0f && disparity < maxD) {
+        if (disparity <= 0) {
+            disparity = (float)0.01;
+            bestuR = (float)((double)uL - 0.01);
+        }
+        depth[iL] = __fdiv_rn(mbf, disparity);
+        uRight[iL] = bestuR;
+        const int slot = atomicAdd(pairCount, 1);
+        pairs[slot] = ((unsigned long long)(unsigned)bestSad << 32) | (unsigned)iL;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_stereo_outliers(unsigned long long* __restrict__ pairs,
+                                                          const int* __restrict__ pairCount,
+                                                          float* __restrict__ uRight, float* __restrict__ depth)
+{
+    const int n = *pairCount;
+    if (n == 0) return;                                            // reference: UB on the empty vector (:686)
+    int np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    for (int k = 2; k <= np2; k <<= 1) {
+        for (int i = threadIdx.x; i < np2; i += blockDim.x) {
+            const int p = i ^ (k - 1);
+            if (p > i && p < n) {
+                const unsigned long long x = pairs[i], y = pairs[p];
+                if (x > y) { pairs[i] = y; pairs[p] = x; }
+            }
+        }
+        __syncthreads();
+        for (int j = k >> 2; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < np2; i += blockDim.x) {
+                const int p = i ^ j;
+                if (p > i && p < n) {
+                    const unsigned long long x = pairs[i], y = pairs[p];
+                    if (x > y) { pairs[i] = y; pairs[p] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const float median = (float)(int)(pairs[n / 2] >> 32);
+    const float thDist = __fmul_rn(1.5f * 1.4f, median);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const unsigned long long e = pairs[i];
+        if (!((float)(int)(e >> 32) < thDist)) {                   // sorted ascending: same set as the backwards scan
+            const int iL = (int)(e & 0xFFFFFFFFu);
+            uRight[iL] = -1.0f;
+            depth[iL] = -1.0f;
+        }
+    }
+}
+
+extern "C" int orb_stereo_match_device(orb_extractor* left, orb_extractor* right, int frame_l, int frame_r,
+                                       const orb_keypoint* d_kps_l, const uint8_t* d_desc_l, int n_l,
+                                       const orb_keypoint* d_kps_r, const uint8_t* d_desc_r, int n_r, float mb,
+                                       float mbf, float* d_u_right, float* d_depth)
+{
+    if (!left || !right || n_l < 0 || n_r < 0) return ORB_ERR_INVALID;
+    if (n_l == 0) return ORB_OK;
+    if (!d_kps_l || !d_desc_l || !d_u_right || !d_depth || (n_r > 0 && (!d_kps_r || !d_desc_r))) return ORB_ERR_INVALID;
+    if (left->rows == 0 || left->rows != right->rows || left->cols != right->cols ||
+        left->prm.nlevels != right->prm.nlevels || left->prm.scale_factor != right->prm.scale_factor) {
+        orb_set_error("stereo: both extractors must have processed images of the same size with the same pyramid");
+        return ORB_ERR_INVALID;
+    }
+    if (frame_l < 0 || frame_l >= left->lastFrames || frame_r < 0 || frame_r >= right->lastFrames) return ORB_ERR_INVALID;
+    if (n_l > 65535 || n_r > 65535 || left->device != right->device) return ORB_ERR_UNSUPPORTED;
+    ORB_HIP_TRY(hipSetDevice(left->device));
+    int rc;
+    if ((rc = left->dStereo.ensure((size_t)8 * n_l + 16)) != ORB_OK) return rc;
+    hipStream_t st = left->stream;
+    ORB_HIP_TRY(hipEventRecord(left->waitEv, right->stream));      // the right pyramid must be complete
+    ORB_HIP_TRY(hipStreamWaitEvent(st, left->waitEv, 0));
+    unsigned long long* pairs = (unsigned long long*)left->dStereo.p;
+    int* pairCount = (int*)(pairs + n_l);
+    ORB_HIP_TRY(hipMemsetAsync(pairCount, 0, 4, st));
+    const float maxD = mbf / mb;                                   // :546
+    hipLaunchKernelGGL(k_stereo_match, dim3(n_l), dim3(WAVE), 0, st, left->G,
+                       (const uint8_t*)left->dPyr.p + left->pyrSlab * frame_l,
+                       (const uint8_t*)right->dPyr.p + right->pyrSlab * frame_r, d_kps_l, d_desc_l, n_l, d_kps_r,
+                       d_desc_r, n_r, maxD, mbf, d_u_right, d_depth, pairs, pairCount);
+    hipLaunchKernelGGL(k_stereo_outliers, dim3(1), dim3(1024), 0, st, pairs, pairCount, d_u_right, d_depth);
+    ORB_HIP_TRY(hipGetLastError());
+    return ORB_OK;
+}
+
+extern "C" int orb_stereo_match(orb_extractor* left, orb_extractor* right, const orb_keypoint* kps_l,
+                                const uint8_t* desc_l, int n_l, const orb_keypoint* kps_r, const uint8_t* desc_r,
+                                int n_r, float mb, float mbf, float* u_right, float* depth)
+{
+    if (!left || !right || n_l < 0 || n_r < 0) return ORB_ERR_INVALID;
+    if (n_l == 0) return ORB_OK;
+    if (!kps_l || !desc_l || !u_right || !depth) return ORB_ERR_INVALID;
+    ORB_HIP_TRY(hipSetDevice(left->device));
+    const size_t szl = sizeof(orb_keypoint) * (size_t)n_l, szr = sizeof(orb_keypoint) * (size_t)std::max(n_r, 1);
+    int rc;
+    if ((rc = left->dStereoIn.ensure(szl + szr + (size_t)32 * n_l + (size_t)32 * std::max(n_r, 1) + (size_t)8 * n_l + 64)) != ORB_OK)
+        return rc;
+    uint8_t* base = (uint8_t*)left->dStereoIn.p;
+    orb_keypoint* dKl = (orb_keypoint*)base;
+    orb_keypoint* dKr = (orb_keypoint*)(base + szl);
+    uint8_t* dDl = base + szl + szr;
+    uint8_t* dDr = dDl + (size_t)32 * n_l;
+    float* dU = (float*)(((uintptr_t)(dDr + (size_t)32 * std::max(n_r, 1)) + 15) & ~(uintptr_t)15);
+    float* dZ = dU + n_l;
+    hipStream_t st = left->stream;
+    ORB_HIP_TRY(hipMemcpyAsync(dKl, kps_l, szl, hipMemcpyHostToDevice, st));
+    ORB_HIP_TRY(hipMemcpyAsync(dDl, desc_l, (size_t)32 * n_l, hipMemcpyHostToDevice, st));
+    if (n_r > 0) {
+        ORB_HIP_TRY(hipMemcpyAsync(dKr, kps_r, sizeof(orb_keypoint) * (size_t)n_r, hipMemcpyHostToDevice, st));
+        ORB_HIP_TRY(hipMemcpyAsync(dDr, desc_r, (size_t)32 * n_r, hipMemcpyHostToDevice, st));
+    }
+    rc = orb_stereo_match_device(left, right, 0, 0, dKl, dDl, n_l, dKr, dDr, n_r, mb, mbf, dU, dZ);
+    if (rc != ORB_OK) return rc;
+    ORB_HIP_TRY(hipMemcpyAsync(u_right, dU, (size_t)4 * n_l, hipMemcpyDeviceToHost, st));
+    ORB_HIP_TRY(hipMemcpyAsync(depth, dZ, (size_t)4 * n_l, hipMemcpyDeviceToHost, st));
+    ORB_HIP_TRY(hipStreamSynchronize(st));
+    return ORB_OK;
+}

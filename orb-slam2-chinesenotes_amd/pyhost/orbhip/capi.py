@@ -60,7 +60,7 @@ SYMBOLS = [
     "orb_get_level_counts", "orb_extractor_set_profiling", "orb_extractor_get_stage_ms", "orb_extractor_profiled_frames", "orb_extractor_stream",
     "orb_hamming", "orb_three_maxima", "orb_matcher_create", "orb_matcher_destroy", "orb_matcher_sync",
     "orb_match_bow", "orb_match_bow_kk", "orb_match_init", "orb_bow_assign_device", "orb_match_bow_batch_device",
-    "orb_matcher_stream", "orb_extractor_wait_for", "orb_matcher_wait_for", "orb_last_error", "orb_version",
+    "orb_matcher_stream", "orb_stereo_match", "orb_stereo_match_device", "orb_extractor_wait_for", "orb_matcher_wait_for", "orb_last_error", "orb_version",
 ]
 
 
@@ -112,6 +112,8 @@ def lib():
     L.orb_matcher_stream.argtypes = [vp]
     L.orb_matcher_stream.restype = vp
     L.orb_extractor_wait_for.argtypes = [vp, vp]
+    L.orb_stereo_match.argtypes = [vp, vp, vp, vp, ci, vp, vp, ci, cf, cf, vp, vp]
+    L.orb_stereo_match_device.argtypes = [vp, vp, ci, ci, vp, vp, ci, vp, vp, ci, cf, cf, vp, vp]
     L.orb_matcher_wait_for.argtypes = [vp, vp]
     L.orb_last_error.restype = C.c_char_p
     L.orb_version.restype = C.c_char_p
@@ -336,3 +338,15 @@ class Matcher:
         _check(self.L.orb_match_bow_batch_device(self.h, C.byref(s), C.c_void_p(d_kf_index), C.c_void_p(d_f_index), n_pairs,
                                                  self.nnratio, int(self.check_ori), C.c_void_p(d_match),
                                                  C.c_void_p(d_nmatches)))
+
+
+def stereo_match(ex_left, ex_right, k_l, d_l, k_r, d_r, mb, mbf):
+    """== Frame::ComputeStereoMatches() on the pyramids the two extractor handles hold on the device."""
+    k_l = np.ascontiguousarray(k_l); k_r = np.ascontiguousarray(k_r)
+    d_l = np.ascontiguousarray(d_l, np.uint8); d_r = np.ascontiguousarray(d_r, np.uint8)
+    n = k_l.shape[0]
+    u = np.zeros(max(n, 1), np.float32)
+    z = np.zeros(max(n, 1), np.float32)
+    _check(lib().orb_stereo_match(ex_left.h, ex_right.h, _p(k_l), _p(d_l), n, _p(k_r), _p(d_r), k_r.shape[0],
+                                  float(mb), float(mbf), _p(u), _p(z)))
+    return u[:n], z[:n]

@@ -71,6 +71,8 @@ def lib():
         L.orbref_search_for_init.restype = C.c_int
         L.orbref_search_for_init.argtypes = ([C.c_void_p, C.c_void_p, C.c_int] * 2 + [C.c_float] * 4 +
                                              [C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p])
+        L.orbref_stereo.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                    C.c_float, C.c_float, C.c_void_p, C.c_void_p]
         L.orbref_features_in_area.restype = C.c_int
         L.orbref_features_in_area.argtypes = ([C.c_void_p, C.c_int] + [C.c_float] * 7 + [C.c_int] * 2 +
                                               [C.c_void_p, C.c_int])
@@ -275,3 +277,14 @@ def features_in_area(kps, grid, x, y, r, min_level=-1, max_level=-1):
     n = lib().orbref_features_in_area(_p(kps), kps.shape[0], *[float(g) for g in grid], float(x), float(y), float(r),
                                       min_level, max_level, _p(out), cap)
     return out[:n].copy()
+
+
+def stereo_matches(ex_left, ex_right, k_l, d_l, k_r, d_r, mb, mbf):
+    """Frame::ComputeStereoMatches on the pyramids currently held by the two oracle extractors."""
+    k_l = np.ascontiguousarray(k_l); k_r = np.ascontiguousarray(k_r)
+    d_l = np.ascontiguousarray(d_l, np.uint8); d_r = np.ascontiguousarray(d_r, np.uint8)
+    n = k_l.shape[0]
+    u = np.zeros(max(n, 1), np.float32)
+    z = np.zeros(max(n, 1), np.float32)
+    lib().orbref_stereo(ex_left.h, ex_right.h, _p(k_l), _p(d_l), n, _p(k_r), _p(d_r), k_r.shape[0], mb, mbf, _p(u), _p(z))
+    return u[:n], z[:n]

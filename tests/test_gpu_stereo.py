@@ -1,0 +1,50 @@
+"""GPU parity of the stereo search (Frame::ComputeStereoMatches, config 3: KITTI-sized pair, 2000 features)."""
+import numpy as np
+import pytest
+
+import oracle
+from orbhip import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+MBF = 386.1448                      # KITTI-00-like constants
+MB = MBF / 718.856
+
+
+def _pair(idx, w, h, nf):
+    left = synth.synth_frame(idx, w, h)
+    right = synth.synth_stereo_right(idx, w, h)
+    exl, exr = capi.Extractor(nf), capi.Extractor(nf)
+    kl, dl = exl.extract(left)
+    kr, dr = exr.extract(right)
+    rl, rr = oracle.Extractor(nf), oracle.Extractor(nf)
+    okl, odl = rl.extract(left)
+    okr, odr = rr.extract(right)
+    assert kl.tobytes() == okl.tobytes() and kr.tobytes() == okr.tobytes()
+    assert np.array_equal(dl, odl) and np.array_equal(dr, odr)
+    return (exl, exr, kl, dl, kr, dr), (rl, rr)
+
+
+@pytest.mark.parametrize("idx,w,h,nf", [(100, 1241, 376, 2000), (101, 1241, 376, 2000), (7, 640, 480, 1000)])
+def test_stereo_matches_bit_exact(idx, w, h, nf):
+    (exl, exr, kl, dl, kr, dr), (rl, rr) = _pair(idx, w, h, nf)
+    want_u, want_z = oracle.stereo_matches(rl, rr, kl, dl, kr, dr, MB, MBF)
+    got_u, got_z = capi.stereo_match(exl, exr, kl, dl, kr, dr, MB, MBF)
+    assert (want_u >= 0).sum() > 0.3 * len(kl)
+    assert got_u.tobytes() == want_u.tobytes()
+    assert got_z.tobytes() == want_z.tobytes()
+    # the synthetic pair has disparity 12 + 8*floor(y/94): the recovered disparities cluster there
+    ok = got_u >= 0
+    disp = kl["x"][ok] - got_u[ok]
+    band = 12 + 8 * np.floor(kl["y"][ok] / 94.0)
+    assert np.mean(np.abs(disp - band) < 1.5) > 0.8
+
+
+def test_stereo_no_right_features_and_swapped_baseline():
+    (exl, exr, kl, dl, kr, dr), (rl, rr) = _pair(9, 640, 480, 500)
+    u, z = capi.stereo_match(exl, exr, kl, dl, kr[:0], dr[:0], MB, MBF)
+    assert np.all(u == -1) and np.all(z == -1)
+    # tiny maxD (= mbf/mb) leaves (almost) no candidate in range: still identical to the oracle
+    wu, wz = oracle.stereo_matches(rl, rr, kl, dl, kr, dr, 10.0, 40.0)
+    gu, gz = capi.stereo_match(exl, exr, kl, dl, kr, dr, 10.0, 40.0)
+    assert gu.tobytes() == wu.tobytes() and gz.tobytes() == wz.tobytes()
