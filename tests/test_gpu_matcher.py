@@ -154,3 +154,61 @@ def test_search_for_initialization_edges(feats2000):
     wn, w = oracle.search_for_init(k1, d1, k2, d2, g, pr, 60, 0.9, True)
     n, out = m.search_for_initialization(k1, d1, k2, d2, g, pg, 60)
     assert n == wn and np.array_equal(out, w) and pg.tobytes() == pr.tobytes()
+
+
+def test_c5_style_stream_vs_keyframe_db_device_batch():
+    """Config 5 in miniature: frames of a 752x480 stream, each matched by SearchByBoW against every keyframe of
+    a descriptor DB that lives in HBM (the Relocalization candidate loop, Tracking.cc:1471-1492), through the
+    device-resident batch entry points; every (keyframe, frame) pair bit-exact vs the oracle."""
+    import torch
+    nkf, nq, W, H = 12, 3, 752, 480
+    frames = synth.synth_batch(300, nkf + nq, W, H)
+    frames[nkf:] = frames[:nq]                                   # queries revisit keyframe scenes ...
+    for q in range(nq):                                          # ... under fresh noise
+        nz = (synth.splitmix64(4242 + q, 0, W * H) % np.uint64(9)).astype(np.int16).reshape(H, W) - 4
+        frames[nkf + q] = np.clip(frames[q].astype(np.int16) + nz, 0, 255).astype(np.uint8)
+    ex = capi.Extractor()
+    mt = capi.Matcher(0.75, True)                                # Tracking.cc:1458
+    cap, F = ex.max_keypoints, nkf + nq
+    dev = torch.device("cuda", 0)
+    d_imgs = torch.from_numpy(frames).to(dev)
+    d_kps = torch.zeros(F * cap * 28, dtype=torch.uint8, device=dev)
+    d_desc = torch.zeros(F * cap * 32, dtype=torch.uint8, device=dev)
+    d_counts = torch.zeros(F, dtype=torch.int32, device=dev)
+    d_node = torch.zeros(F * cap, dtype=torch.int16, device=dev)
+    valid_np = np.stack([synth.synth_valid_flags(cap, 900 + i) for i in range(F)])
+    d_valid = torch.from_numpy(valid_np).to(dev)
+    d_cent = torch.from_numpy(synth.synth_vocabulary()).to(dev)
+    pairs = [(k, nkf + q) for q in range(nq) for k in range(nkf)]
+    kf_idx = torch.tensor([p[0] for p in pairs], dtype=torch.int32, device=dev)
+    f_idx = torch.tensor([p[1] for p in pairs], dtype=torch.int32, device=dev)
+    d_match = torch.zeros(len(pairs) * cap, dtype=torch.int32, device=dev)
+    d_nm = torch.zeros(len(pairs), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    ex.extract_batch_device(d_imgs.data_ptr(), F, H, W, W, W * H, d_kps.data_ptr(), d_desc.data_ptr(), cap, d_counts.data_ptr())
+    mt.wait_for(ex.stream)
+    mt.bow_assign_device(d_desc.data_ptr(), d_counts.data_ptr(), F, cap, d_cent.data_ptr(), d_node.data_ptr())
+    store = dict(desc=d_desc.data_ptr(), kps=d_kps.data_ptr(), valid=d_valid.data_ptr(), counts=d_counts.data_ptr(),
+                 node_of=d_node.data_ptr(), cap=cap, n_frames=F)
+    mt.match_bow_batch_device(store, kf_idx.data_ptr(), f_idx.data_ptr(), len(pairs), d_match.data_ptr(), d_nm.data_ptr())
+    ex.sync(); mt.sync(); torch.cuda.synchronize()
+    counts = d_counts.cpu().numpy()
+    kps = d_kps.cpu().numpy().view(capi.KP_DTYPE).reshape(F, cap)
+    desc = d_desc.cpu().numpy().reshape(F, cap, 32)
+    match = d_match.cpu().numpy().reshape(len(pairs), cap)
+    nm = d_nm.cpu().numpy()
+    ref = oracle.Extractor()
+    cent = synth.synth_vocabulary()
+    feats = []
+    for i in range(F):
+        k, d = ref.extract(frames[i])
+        assert counts[i] == len(k) and kps[i, :len(k)].tobytes() == k.tobytes() and np.array_equal(desc[i, :len(k)], d)
+        feats.append((k, d, oracle.bow_transform(d, cent)))
+    best = []
+    for p, (a, b) in enumerate(pairs):
+        (ka, da, fa), (kb, db, fb) = feats[a], feats[b]
+        wn, wm = oracle.search_by_bow(da, ka["angle"], valid_np[a][:len(ka)], fa, db, kb["angle"], fb, 0.75, True)
+        assert nm[p] == wn and np.array_equal(match[p, :len(kb)], wm), (a, b)
+        best.append(wn)
+    best = np.array(best).reshape(nq, nkf)
+    assert np.all(best.argmax(axis=1) == np.arange(nq))          # each query recognises its own keyframe
