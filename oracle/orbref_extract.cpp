@@ -145,17 +145,21 @@ static const int kRingDy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1,
 
 int fastScoreV(const uint8_t* p, int pitch)
 {
-    int d[16];
+    // V = max over the 16 contiguous 9-arcs of min(+d) and of min(-d), d_k = I(p) - I(ring_k).
+    // 9-arc minima via minima of 3 (k,k+1,k+2) combined at k, k+3, k+6 -- same value as the plain
+    // 16 x 9 scan, an order of magnitude fewer operations (keeps the cpu_baseline honest).
+    int d[16], lo3[16], hi3[16];
     const int c = p[0];
     for (int k = 0; k < 16; k++) d[k] = c - p[kRingDy[k] * pitch + kRingDx[k]];
+    for (int k = 0; k < 16; k++) {
+        const int a = d[k], b = d[(k + 1) & 15], e = d[(k + 2) & 15];
+        lo3[k] = std::min(a, std::min(b, e));
+        hi3[k] = std::max(a, std::max(b, e));
+    }
     int best = -256;
-    for (int s = 0; s < 16; s++) {
-        int mn = 255, mx = -255;
-        for (int t = 0; t < 9; t++) {
-            int v = d[(s + t) & 15];
-            mn = std::min(mn, v);
-            mx = std::max(mx, v);
-        }
+    for (int k = 0; k < 16; k++) {
+        const int mn = std::min(lo3[k], std::min(lo3[(k + 3) & 15], lo3[(k + 6) & 15]));
+        const int mx = std::max(hi3[k], std::max(hi3[(k + 3) & 15], hi3[(k + 6) & 15]));
         best = std::max(best, std::max(mn, -mx));
     }
     return best;   // corner at threshold th  <=>  best > th;  cornerScore == best-1
@@ -167,27 +171,39 @@ static void fastCell(const Image& im, int x0, int y0, int w, int h, int th,
                      std::vector<Candidate>& out)
 {
     if (w < 7 || h < 7) return;
-    std::vector<uint8_t> score((size_t)w * h, 0), corner((size_t)w * h, 0);
+    static thread_local std::vector<uint8_t> score, corner;       // per-call scratch, reused
+    score.assign((size_t)w * h, 0);
+    corner.assign((size_t)w * h, 0);
     const int pitch = im.w;
-    for (int y = 3; y < h - 3; y++)
-        for (int x = 3; x < w - 3; x++) {
-            const uint8_t* p = &im.px[(size_t)(y0 + y) * pitch + x0 + x];
-            // Cheap exact rejection (what cv::FAST's threshold-table tests amount to): every
-            // 9-arc of the 16-ring contains ring pixel k or k+8, for each k.
-            const int c = p[0];
-            bool maybe = true;
-            for (int k = 0; k < 8 && maybe; k += 2) {
-                int da = c - p[kRingDy[k] * pitch + kRingDx[k]];
-                int db = c - p[kRingDy[k + 8] * pitch + kRingDx[k + 8]];
-                maybe = (da > th || db > th) || (da < -th || db < -th);
-            }
-            if (!maybe) continue;
-            int V = fastScoreV(p, pitch);
+    const int o0 = kRingDy[0] * pitch + kRingDx[0], o8 = kRingDy[8] * pitch + kRingDx[8];
+    const int o4 = kRingDy[4] * pitch + kRingDx[4], o12 = kRingDy[12] * pitch + kRingDx[12];
+    const int o2 = kRingDy[2] * pitch + kRingDx[2], o10 = kRingDy[10] * pitch + kRingDx[10];
+    const int o6 = kRingDy[6] * pitch + kRingDx[6], o14 = kRingDy[14] * pitch + kRingDx[14];
+    for (int y = 3; y < h - 3; y++) {
+        const uint8_t* p = &im.px[(size_t)(y0 + y) * pitch + x0 + 3];
+        for (int x = 3; x < w - 3; x++, p++) {
+            // Cheap exact rejection (what cv::FAST's threshold-table tests amount to): every 9-arc of the
+            // 16-ring contains ring pixel k or k+8, for each k; and it is all-darker or all-brighter.
+            const int lo = p[0] - th, hi = p[0] + th;
+            int a = p[o0], b = p[o8];
+            bool dark = a < lo || b < lo, bright = a > hi || b > hi;
+            if (!(dark || bright)) continue;
+            a = p[o4]; b = p[o12];
+            dark = dark && (a < lo || b < lo); bright = bright && (a > hi || b > hi);
+            if (!(dark || bright)) continue;
+            a = p[o2]; b = p[o10];
+            dark = dark && (a < lo || b < lo); bright = bright && (a > hi || b > hi);
+            if (!(dark || bright)) continue;
+            a = p[o6]; b = p[o14];
+            dark = dark && (a < lo || b < lo); bright = bright && (a > hi || b > hi);
+            if (!(dark || bright)) continue;
+            const int V = fastScoreV(p, pitch);
             if (V > th) {
                 score[(size_t)y * w + x] = (uint8_t)(V - 1);
                 corner[(size_t)y * w + x] = 1;
             }
         }
+    }
     for (int y = 3; y < h - 3; y++)
         for (int x = 3; x < w - 3; x++) {
             // only pixels that passed the arc test are considered (their score may be 0 at th==0)
@@ -436,24 +452,36 @@ static inline int reflect101(int i, int n)
 void gaussianBlur7(const Image& src, Image& dst)
 {
     // OpenCV 2.4 / 3.0-3.3 8-bit separable path: 8.8 fixed-point taps {18,34,49,55,49,34,18}.
-    static const int k[7] = {18, 34, 49, 55, 49, 34, 18};
+    // Row pass on a REFLECT_101-padded copy of each row, column pass over seven row pointers; the
+    // arithmetic (int32 sums, +32768 >> 16, saturate) is unchanged, only the loop structure is CPU-friendly
+    // so that the cpu_baseline timing is not inflated by a naive restatement.
     const int w = src.w, h = src.h;
     std::vector<int> rowbuf((size_t)w * h);
-    for (int y = 0; y < h; y++)
-        for (int x = 0; x < w; x++) {
-            int acc = 0;
-            for (int t = 0; t < 7; t++) acc += k[t] * src.px[(size_t)y * w + reflect101(x + t - 3, w)];
-            rowbuf[(size_t)y * w + x] = acc;
+    std::vector<uint8_t> pad((size_t)w + 6);
+    for (int y = 0; y < h; y++) {
+        const uint8_t* s = &src.px[(size_t)y * w];
+        for (int i = 0; i < 3; i++) {
+            pad[i] = s[reflect101(i - 3, w)];
+            pad[w + 3 + i] = s[reflect101(w + i, w)];
         }
+        std::memcpy(&pad[3], s, w);
+        int* r = &rowbuf[(size_t)y * w];
+        const uint8_t* p = pad.data();
+        for (int x = 0; x < w; x++)
+            r[x] = 18 * (p[x] + p[x + 6]) + 34 * (p[x + 1] + p[x + 5]) + 49 * (p[x + 2] + p[x + 4]) + 55 * p[x + 3];
+    }
     dst.w = w; dst.h = h;
     dst.px.resize((size_t)w * h);
-    for (int y = 0; y < h; y++)
+    for (int y = 0; y < h; y++) {
+        const int* r[7];
+        for (int t = 0; t < 7; t++) r[t] = &rowbuf[(size_t)reflect101(y + t - 3, h) * w];
+        uint8_t* d = &dst.px[(size_t)y * w];
         for (int x = 0; x < w; x++) {
-            int acc = 0;
-            for (int t = 0; t < 7; t++) acc += k[t] * rowbuf[(size_t)reflect101(y + t - 3, h) * w + x];
-            int v = (acc + 32768) >> 16;
-            dst.px[(size_t)y * w + x] = (uint8_t)std::min(255, std::max(0, v));
+            const int acc = 18 * (r[0][x] + r[6][x]) + 34 * (r[1][x] + r[5][x]) + 49 * (r[2][x] + r[4][x]) + 55 * r[3][x];
+            const int v = (acc + 32768) >> 16;
+            d[x] = (uint8_t)(v > 255 ? 255 : v);
         }
+    }
 }
 
 // ------------------------------------------------------------------ descriptor (A.8, :120-161)
