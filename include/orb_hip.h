@@ -186,6 +186,37 @@ int orb_match_init(orb_matcher* m,
                    const float* grid4, float* prev_xy, int window_size,
                    float ratio, int check_ori, int32_t* match_12, int* nmatches);
 
+/* The two tracking matchers.  The MapPoint projection itself (cv::Mat arithmetic,
+ * reference src/ORBmatcher.cc:195-212 resp. Frame::isInFrustum) stays with the caller, written with the
+ * reference's own expressions; one orb_proj_query per projected MapPoint carries its result:
+ *   x, y        the projection handed to GetFeaturesInArea            (:96 mTrackProjX/Y, :204-205 u, v)
+ *   r           the window radius                                      (:97 r*mvScaleFactors[level], :215 radius)
+ *   min_level, max_level   the level range handed to GetFeaturesInArea (:98; :219-225 by bForward/bBackward)
+ *   ur, er_max  stereo check: a candidate with mvuRight > 0 is skipped when |ur - mvuRight| > er_max
+ *               (:113-118 mTrackProjXR, r*scale;  :238-244 u - mbf*invzc, radius)
+ *   flags       bit0: query is live (:85-88 mbTrackInView && !isBad; :189-212 has MapPoint, not outlier,
+ *               projects inside);  bit1: its MapPoint has Observations() > 0 (decides whether the feature it
+ *               is assigned to blocks later queries, :109-111 / :233-235) */
+typedef struct orb_proj_query {
+    float x, y, r;
+    int32_t min_level, max_level;
+    float ur, er_max;
+    int32_t flags;
+} orb_proj_query;
+
+/* mode 0 replaces: int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, float th,
+ *                  bool bMono), reference src/ORBmatcher.cc:160-300 (q_angle[i] = LastFrame.mvKeysUn[i].angle).
+ * mode 1 replaces: int ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>&, float th),
+ *                  reference src/ORBmatcher.cc:73-157 (ratio = mfNNratio; q_angle unused).
+ * q_desc[i] is pMP->GetDescriptor().  kps_un/desc/u_right describe the current Frame (mvKeysUn, mDescriptors,
+ * mvuRight); occupied[i] != 0 iff F.mvpMapPoints[i] && Observations() > 0 on entry; grid4 as for orb_match_init.
+ * match_cur[i] receives the index of the query now assigned to feature i, -1 if the entry was not touched, and
+ * (mode 0) -2 if the rotation filter reset it to NULL.  *nmatches is the reference's return value. */
+int orb_match_projection(orb_matcher* m, int mode, const orb_proj_query* queries, const uint8_t* q_desc,
+                         const float* q_angle, int nq, const orb_keypoint* kps_un, const uint8_t* desc,
+                         const float* u_right, const uint8_t* occupied, int n, const float* grid4, float ratio,
+                         int check_ori, int32_t* match_cur, int* nmatches);
+
 /* Batched device-resident SearchByBoW: pair p matches keyframe kf_index[p] against frame
  * f_index[p] of a feature store that lives in HBM (the Relocalization candidate loop of
  * reference src/Tracking.cc:1471-1492 is the batch axis).  See orb_featstore below. */

@@ -116,6 +116,20 @@ int searchForInitialization(const KeyPoint* kps1, const uint8_t* desc1, int n1,
                             const FrameGrid& grid2, float* prevMatchedXY, int windowSize,
                             float nnRatio, bool checkOri, std::vector<int32_t>& matches12);
 
+// One projected MapPoint of the tracking matchers (what the reference computes with cv::Mat before the search).
+struct ProjQuery {
+    float x, y, r;              // projection and window radius handed to GetFeaturesInArea
+    int32_t minLevel, maxLevel; // level range handed to GetFeaturesInArea (-1 = open)
+    float ur, erMax;            // stereo check: skip if uRight>0 && |ur - uRight| > erMax
+    int32_t flags;              // bit0: query is live; bit1: its MapPoint has Observations() > 0
+};
+int searchByProjectionMap(const ProjQuery* q, const uint8_t* qDesc, int nq, const KeyPoint* kps, const uint8_t* desc,
+                          const float* uRight, const uint8_t* occupiedIn, int n, const FrameGrid& grid, float ratio,
+                          std::vector<int32_t>& matchCur);
+int searchByProjectionLast(const ProjQuery* q, const uint8_t* qDesc, const float* qAngle, int nq, const KeyPoint* kps,
+                           const uint8_t* desc, const float* uRight, const uint8_t* occupiedIn, int n,
+                           const FrameGrid& grid, bool checkOri, std::vector<int32_t>& matchCur);
+
 // Synthetic stand-in for the (absent) ORB vocabulary: 2-level k=10 tree of 256-bit centroids
 // (SURVEY §8d).  nodeId = 11 + 10*c1 + c2.  centroids: 10 level-1 then 100 level-2, 32 B each.
 FeatVec bowTransform(const uint8_t* desc, int n, const uint8_t* centroids /*110 x 32*/);

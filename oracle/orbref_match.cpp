@@ -291,3 +291,96 @@ FeatVec bowTransform(const uint8_t* desc, int n, const uint8_t* cent)
 }
 
 }  // namespace orbref
+
+// ------------------------------------------------------------------ SearchByProjection (tracking matchers)
+// The reference projects MapPoints with cv::Mat arithmetic (src/ORBmatcher.cc:195-212; Frame::isInFrustum for the
+// local-map variant).  That O(N) host arithmetic stays in the caller/shim; the oracle (and the GPU entry point)
+// start from the projected query: position, window radius, level range, stereo check, descriptor.
+namespace orbref {
+
+static void bestTwo(const std::vector<int32_t>& cand, const KeyPoint* kps, const uint8_t* desc, const float* uRight,
+                    const std::vector<uint8_t>& occupied, const ProjQuery& q, const uint8_t* qd,
+                    int& best, int& best2, int& level, int& level2, int& bestIdx)
+{
+    best = 256; best2 = 256; level = -1; level2 = -1; bestIdx = -1;
+    for (int32_t idx : cand) {
+        if (occupied[idx]) continue;                                   // mvpMapPoints[idx] && Observations()>0
+        if (uRight[idx] > 0) {
+            const float er = std::fabs(q.ur - uRight[idx]);
+            if (er > q.erMax) continue;
+        }
+        const int d = hamming256(qd, desc + 32 * (size_t)idx);
+        if (d < best) { best2 = best; best = d; level2 = level; level = kps[idx].octave; bestIdx = idx; }
+        else if (d < best2) { level2 = kps[idx].octave; best2 = d; }
+    }
+}
+
+// SearchByProjection(Frame&, const vector<MapPoint*>&, th)  src/ORBmatcher.cc:73-157.  matchCur[idx] = query index.
+int searchByProjectionMap(const ProjQuery* q, const uint8_t* qDesc, int nq, const KeyPoint* kps, const uint8_t* desc,
+                          const float* uRight, const uint8_t* occupiedIn, int n, const FrameGrid& grid, float ratio,
+                          std::vector<int32_t>& matchCur)
+{
+    matchCur.assign(n, -1);
+    std::vector<uint8_t> occupied(occupiedIn, occupiedIn + n);
+    int nmatches = 0;
+    for (int i = 0; i < nq; i++) {
+        if (!(q[i].flags & 1)) continue;                               // mbTrackInView && !isBad()
+        std::vector<int32_t> cand = grid.inArea(kps, q[i].x, q[i].y, q[i].r, q[i].minLevel, q[i].maxLevel);
+        if (cand.empty()) continue;
+        int best, best2, level, level2, bestIdx;
+        bestTwo(cand, kps, desc, uRight, occupied, q[i], qDesc + 32 * (size_t)i, best, best2, level, level2, bestIdx);
+        if (best <= 100) {                                             // TH_HIGH
+            if (level == level2 && (float)best > ratio * (float)best2) continue;
+            matchCur[bestIdx] = i;
+            occupied[bestIdx] = (q[i].flags & 2) ? 1 : 0;              // the new MapPoint's Observations()>0
+            nmatches++;
+        }
+    }
+    return nmatches;
+}
+
+// SearchByProjection(Frame& Current, const Frame& Last, th, bMono)  src/ORBmatcher.cc:160-300.
+// matchCur[i2] = last-frame index, -2 = reset to NULL by the rotation filter, -1 = untouched.
+int searchByProjectionLast(const ProjQuery* q, const uint8_t* qDesc, const float* qAngle, int nq, const KeyPoint* kps,
+                           const uint8_t* desc, const float* uRight, const uint8_t* occupiedIn, int n,
+                           const FrameGrid& grid, bool checkOri, std::vector<int32_t>& matchCur)
+{
+    matchCur.assign(n, -1);
+    std::vector<uint8_t> occupied(occupiedIn, occupiedIn + n);
+    std::vector<int> rotHist[HISTO_LENGTH];
+    int nmatches = 0;
+    for (int i = 0; i < nq; i++) {
+        if (!(q[i].flags & 1)) continue;                               // has MapPoint, not outlier, projects inside
+        std::vector<int32_t> cand = grid.inArea(kps, q[i].x, q[i].y, q[i].r, q[i].minLevel, q[i].maxLevel);
+        if (cand.empty()) continue;
+        int best = 256, bestIdx = -1;
+        for (int32_t i2 : cand) {
+            if (occupied[i2]) continue;
+            if (uRight[i2] > 0) {
+                const float er = std::fabs(q[i].ur - uRight[i2]);
+                if (er > q[i].erMax) continue;
+            }
+            const int d = hamming256(qDesc + 32 * (size_t)i, desc + 32 * (size_t)i2);
+            if (d < best) { best = d; bestIdx = i2; }
+        }
+        if (best <= 100) {
+            matchCur[bestIdx] = i;
+            occupied[bestIdx] = (q[i].flags & 2) ? 1 : 0;
+            nmatches++;
+            if (checkOri) rotHist[rotBin(qAngle[i], kps[bestIdx].angle)].push_back(bestIdx);
+        }
+    }
+    if (checkOri) {
+        int counts[HISTO_LENGTH];
+        for (int i = 0; i < HISTO_LENGTH; i++) counts[i] = (int)rotHist[i].size();
+        int i1 = -1, i2 = -1, i3 = -1;
+        threeMaxima(counts, i1, i2, i3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == i1 || i == i2 || i == i3) continue;
+            for (int idx : rotHist[i]) { matchCur[idx] = -2; nmatches--; }   // duplicates decrement twice (:287-291)
+        }
+    }
+    return nmatches;
+}
+
+}  // namespace orbref

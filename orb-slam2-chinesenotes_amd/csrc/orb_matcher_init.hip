@@ -21,80 +21,11 @@
 #pragma clang fp contract(off)
 
 #define WAVE 64
-#define GRID_COLS 64
-#define GRID_ROWS 48
 #define TH_LOW 50
 #define HISTO_LENGTH 30
 #define DIST_NONE 0x7FFFFFFF
 
-struct InitGrid { float minX, minY, invW, invH; };
-
-__device__ __forceinline__ void load_desc8(const uint8_t* p, uint32_t v[8])
-{
-    const uint4 lo = reinterpret_cast<const uint4*>(p)[0], hi = reinterpret_cast<const uint4*>(p)[1];
-    v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w;
-    v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
-}
-
-// ascending bitonic sort (all merges ascending, virtual +inf padding), one workgroup
-__device__ void block_sort_u32(uint32_t* a, int n)
-{
-    int np2 = 1;
-    while (np2 < n) np2 <<= 1;
-    for (int k = 2; k <= np2; k <<= 1) {
-        for (int i = threadIdx.x; i < np2; i += blockDim.x) {
-            const int p = i ^ (k - 1);
-            if (p > i && p < n) {
-                const uint32_t x = a[i], y = a[p];
-                if (x > y) { a[i] = y; a[p] = x; }
-            }
-        }
-        __syncthreads();
-        for (int j = k >> 2; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < np2; i += blockDim.x) {
-                const int p = i ^ j;
-                if (p > i && p < n) {
-                    const uint32_t x = a[i], y = a[p];
-                    if (x > y) { a[i] = y; a[p] = x; }
-                }
-            }
-            __syncthreads();
-        }
-    }
-}
-
-// keys[k] = cell<<16 | index for the level-0 keypoints of frame 2 that fall inside the grid
-// (PosInGrid, :412-422), sorted ascending; *nKeys = how many.
-__global__ __launch_bounds__(256) void k_init_grid(const orb_keypoint* __restrict__ kps2, int n2, InitGrid g,
-                                                   uint32_t* __restrict__ keys, int* __restrict__ nKeys)
-{
-    __shared__ int cnt;
-    if (threadIdx.x == 0) cnt = 0;
-    __syncthreads();
-    for (int i = threadIdx.x; i < n2; i += blockDim.x) {
-        const orb_keypoint kp = kps2[i];
-        if (kp.octave != 0) continue;                              // query is (minLevel=0, maxLevel=0), :1079
-        const int px = (int)roundf(__fmul_rn(__fsub_rn(kp.x, g.minX), g.invW));
-        const int py = (int)roundf(__fmul_rn(__fsub_rn(kp.y, g.minY), g.invH));
-        if (px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS) continue;
-        const int slot = atomicAdd(&cnt, 1);
-        keys[slot] = ((uint32_t)(px * GRID_ROWS + py) << 16) | (uint32_t)i;
-    }
-    __syncthreads();
-    const int n = cnt;
-    block_sort_u32(keys, n);                                       // global memory, one workgroup
-    if (threadIdx.x == 0) *nKeys = n;
-}
-
-__device__ __forceinline__ int lower_key(const uint32_t* keys, int n, uint32_t want)
-{
-    int lo = 0, hi = n;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (keys[mid] < want) lo = mid + 1; else hi = mid;
-    }
-    return lo;
-}
+#include "orb_grid_device.h"
 
 // candList[i1*stride + k] = (i2 << 16) | dist, k < candCount[i1], in GetFeaturesInArea order
 __global__ __launch_bounds__(WAVE) void k_init_candidates(const orb_keypoint* __restrict__ kps1,
@@ -150,13 +81,6 @@ __global__ __launch_bounds__(WAVE) void k_init_candidates(const orb_keypoint* __
         }
     }
     if (lane == 0) candCount[i1] = count;
-}
-
-__device__ __forceinline__ unsigned wave_min_u(unsigned v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = min(v, (unsigned)__shfl_xor((int)v, o));
-    return v;
 }
 
 __global__ __launch_bounds__(WAVE) void k_init_resolve(const orb_keypoint* __restrict__ kps1, int n1,
@@ -313,7 +237,7 @@ extern "C" int orb_match_init(orb_matcher* m, const orb_keypoint* kps1, const ui
     ORB_HIP_TRY(hipMemcpyAsync(dD2, desc2, sz[3], hipMemcpyHostToDevice, st));
     ORB_HIP_TRY(hipMemcpyAsync(dPrev, prev_xy, sz[4], hipMemcpyHostToDevice, st));
     InitGrid g = {grid4[0], grid4[1], grid4[2], grid4[3]};
-    hipLaunchKernelGGL(k_init_grid, dim3(1), dim3(256), 0, st, dK2, n2, g, dKeys, dNKeys);
+    hipLaunchKernelGGL(k_init_grid, dim3(1), dim3(256), 0, st, dK2, n2, g, 1, dKeys, dNKeys);
     hipLaunchKernelGGL(k_init_candidates, dim3(n1), dim3(WAVE), 0, st, dK1, dD1, n1, dK2, dD2, dKeys, dNKeys, g, dPrev,
                        (float)window_size, dCand, n2, dCandCount);
     hipLaunchKernelGGL(k_init_resolve, dim3(1), dim3(WAVE), 0, st, dK1, n1, dK2, n2, dCand, n2, dCandCount, ratio,

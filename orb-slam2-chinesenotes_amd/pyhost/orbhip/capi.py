@@ -16,6 +16,9 @@ LIB_PATH = os.path.join(PKG_DIR, "liborbhip.so")
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
                      ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
 
+PROJ_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("r", "<f4"), ("min_level", "<i4"), ("max_level", "<i4"),
+                       ("ur", "<f4"), ("er_max", "<f4"), ("flags", "<i4")])
+
 ORB_OK = 0
 STATUS = {0: "ORB_OK", -1: "ORB_ERR_INVALID", -2: "ORB_ERR_HIP", -3: "ORB_ERR_NO_DEVICE",
           -4: "ORB_ERR_CAPACITY", -5: "ORB_ERR_UNSUPPORTED", -6: "ORB_ERR_INTERNAL"}
@@ -59,7 +62,7 @@ SYMBOLS = [
     "orb_extract_batch", "orb_extract_batch_device", "orb_extractor_sync", "orb_get_pyramid_level",
     "orb_get_level_counts", "orb_extractor_set_profiling", "orb_extractor_get_stage_ms", "orb_extractor_profiled_frames", "orb_extractor_stream",
     "orb_hamming", "orb_three_maxima", "orb_matcher_create", "orb_matcher_destroy", "orb_matcher_sync",
-    "orb_match_bow", "orb_match_bow_kk", "orb_match_init", "orb_bow_assign_device", "orb_match_bow_batch_device",
+    "orb_match_bow", "orb_match_bow_kk", "orb_match_init", "orb_match_projection", "orb_bow_assign_device", "orb_match_bow_batch_device",
     "orb_matcher_stream", "orb_stereo_match", "orb_stereo_match_device", "orb_extractor_wait_for", "orb_matcher_wait_for", "orb_last_error", "orb_version",
 ]
 
@@ -107,6 +110,7 @@ def lib():
     L.orb_match_bow_kk.argtypes = [vp, vp, vp, vp, ci, C.POINTER(FeatVecC), vp, vp, vp, ci, C.POINTER(FeatVecC), cf, ci,
                                    vp, C.POINTER(ci)]
     L.orb_match_init.argtypes = [vp, vp, vp, ci, vp, vp, ci, vp, vp, ci, cf, ci, vp, C.POINTER(ci)]
+    L.orb_match_projection.argtypes = [vp, ci, vp, vp, vp, ci, vp, vp, vp, vp, ci, vp, cf, ci, vp, C.POINTER(ci)]
     L.orb_bow_assign_device.argtypes = [vp, vp, vp, ci, ci, vp, vp]
     L.orb_match_bow_batch_device.argtypes = [vp, C.POINTER(FeatStoreC), vp, vp, ci, cf, ci, vp, vp]
     L.orb_matcher_stream.argtypes = [vp]
@@ -326,6 +330,21 @@ class Matcher:
         _check(self.L.orb_match_init(self.h, _p(k1), _p(d1), n1, _p(k2), _p(d2), n2, _p(grid), _p(prev_xy), window,
                                      self.nnratio, int(self.check_ori), _p(out), C.byref(nm)))
         return nm.value, out[:n1]
+
+    def search_by_projection(self, mode, q, q_desc, q_angle, kps_un, desc, u_right, occupied, grid):
+        """mode 0: SearchByProjection(CurrentFrame, LastFrame, ...); mode 1: SearchByProjection(Frame, MapPoints, ...)."""
+        q = np.ascontiguousarray(q, PROJ_DTYPE); q_desc = np.ascontiguousarray(q_desc, np.uint8)
+        q_angle = np.ascontiguousarray(q_angle, np.float32)
+        kps_un = np.ascontiguousarray(kps_un); desc = np.ascontiguousarray(desc, np.uint8)
+        u_right = np.ascontiguousarray(u_right, np.float32); occupied = np.ascontiguousarray(occupied, np.uint8)
+        grid = np.ascontiguousarray(grid, np.float32)
+        n = kps_un.shape[0]
+        out = np.full(max(n, 1), -1, np.int32)
+        nm = C.c_int(0)
+        _check(self.L.orb_match_projection(self.h, mode, _p(q), _p(q_desc), _p(q_angle), q.shape[0], _p(kps_un), _p(desc),
+                                           _p(u_right), _p(occupied), n, _p(grid), self.nnratio, int(self.check_ori),
+                                           _p(out), C.byref(nm)))
+        return nm.value, out[:n]
 
     def bow_assign_device(self, d_desc, d_counts, n_frames, cap, d_centroids, d_node_of):
         _check(self.L.orb_bow_assign_device(self.h, C.c_void_p(d_desc), C.c_void_p(d_counts), n_frames, cap,

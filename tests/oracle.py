@@ -73,6 +73,9 @@ def lib():
                                              [C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p])
         L.orbref_stereo.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                     C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+        L.orbref_search_by_projection.restype = C.c_int
+        L.orbref_search_by_projection.argtypes = ([C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                                    C.c_void_p, C.c_void_p, C.c_int] + [C.c_float] * 5 + [C.c_int, C.c_void_p])
         L.orbref_features_in_area.restype = C.c_int
         L.orbref_features_in_area.argtypes = ([C.c_void_p, C.c_int] + [C.c_float] * 7 + [C.c_int] * 2 +
                                               [C.c_void_p, C.c_int])
@@ -288,3 +291,20 @@ def stereo_matches(ex_left, ex_right, k_l, d_l, k_r, d_r, mb, mbf):
     z = np.zeros(max(n, 1), np.float32)
     lib().orbref_stereo(ex_left.h, ex_right.h, _p(k_l), _p(d_l), n, _p(k_r), _p(d_r), k_r.shape[0], mb, mbf, _p(u), _p(z))
     return u[:n], z[:n]
+
+
+PROJ_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("r", "<f4"), ("min_level", "<i4"), ("max_level", "<i4"),
+                       ("ur", "<f4"), ("er_max", "<f4"), ("flags", "<i4")])
+
+
+def search_by_projection(mode, q, q_desc, q_angle, kps, desc, u_right, occupied, grid, ratio=0.8, check_ori=True):
+    """mode 0: SearchByProjection(CurrentFrame, LastFrame, ...); mode 1: SearchByProjection(Frame, MapPoints, ...)."""
+    q = np.ascontiguousarray(q, PROJ_DTYPE); q_desc = np.ascontiguousarray(q_desc, np.uint8)
+    q_angle = np.ascontiguousarray(q_angle, np.float32)
+    kps = np.ascontiguousarray(kps); desc = np.ascontiguousarray(desc, np.uint8)
+    u_right = np.ascontiguousarray(u_right, np.float32); occupied = np.ascontiguousarray(occupied, np.uint8)
+    n = kps.shape[0]
+    out = np.full(max(n, 1), -1, np.int32)
+    nm = lib().orbref_search_by_projection(mode, _p(q), _p(q_desc), _p(q_angle), q.shape[0], _p(kps), _p(desc), _p(u_right),
+                                           _p(occupied), n, *[float(g) for g in grid], ratio, int(check_ori), _p(out))
+    return nm, out[:n]

@@ -212,3 +212,67 @@ def test_c5_style_stream_vs_keyframe_db_device_batch():
         best.append(wn)
     best = np.array(best).reshape(nq, nkf)
     assert np.all(best.argmax(axis=1) == np.arange(nq))          # each query recognises its own keyframe
+
+
+def _proj_scene(feats, a, b, mode, level_mode, seed):
+    """Queries = features of frame a 'projected' near their true position in frame b (same scene, fresh noise)."""
+    rng = np.random.default_rng(seed)
+    (ka, da), (kb, db) = feats[a], feats[b]
+    nq, n = len(ka), len(kb)
+    scale = np.float32(1.2) ** ka["octave"].astype(np.float32)
+    q = np.zeros(nq, oracle.PROJ_DTYPE)
+    q["x"] = ka["x"] + rng.uniform(-3, 3, nq).astype(np.float32)
+    q["y"] = ka["y"] + rng.uniform(-3, 3, nq).astype(np.float32)
+    lvl = ka["octave"]
+    if mode == 0:
+        q["r"] = np.float32(15.0) * scale                          # th * mvScaleFactors[nLastOctave]   (:215)
+        if level_mode == "forward":
+            q["min_level"], q["max_level"] = lvl, -1
+        elif level_mode == "backward":
+            q["min_level"], q["max_level"] = 0, lvl
+        else:
+            q["min_level"], q["max_level"] = lvl - 1, lvl + 1
+        q["er_max"] = q["r"]
+    else:
+        r = np.where(rng.random(nq) < 0.5, np.float32(2.5), np.float32(4.0)) * np.float32(3.0)
+        q["r"] = r.astype(np.float32) * scale                      # r * mvScaleFactors[nPredictedLevel]   (:97)
+        q["min_level"], q["max_level"] = lvl - 1, lvl
+        q["er_max"] = q["r"]
+    q["ur"] = q["x"] - rng.uniform(5, 40, nq).astype(np.float32)
+    q["flags"] = (rng.random(nq) < 0.85).astype(np.int32) | ((rng.random(nq) < 0.8).astype(np.int32) << 1)
+    u_right = np.where(rng.random(n) < 0.5, kb["x"] - rng.uniform(5, 40, n), -1).astype(np.float32)
+    occupied = (rng.random(n) < 0.1).astype(np.uint8)
+    return q, da, ka["angle"].copy(), kb, db, u_right, occupied
+
+
+@pytest.mark.parametrize("mode,level_mode", [(0, "neither"), (0, "forward"), (0, "backward"), (1, "map")])
+def test_search_by_projection(feats, mode, level_mode):
+    grid = (0.0, 0.0, 64.0 / 640.0, 48.0 / 480.0)
+    for ori in (True, False):
+        m = capi.Matcher(0.8, ori)
+        for a, b, seed in [(0, 1, 1), (1, 2, 2), (2, 0, 3)]:
+            q, qd, qa, kb, db, ur, occ = _proj_scene(feats, a, b, mode, level_mode, seed)
+            want_n, want = oracle.search_by_projection(mode, q, qd, qa, kb, db, ur, occ, grid, 0.8, ori)
+            got_n, got = m.search_by_projection(mode, q, qd, qa, kb, db, ur, occ, grid)
+            assert want_n > 100
+            assert got_n == want_n
+            assert np.array_equal(got, want)
+
+
+def test_search_by_projection_edges(feats):
+    grid = (0.0, 0.0, 0.1, 0.1)
+    m = capi.Matcher(0.8, True)
+    q, qd, qa, kb, db, ur, occ = _proj_scene(feats, 0, 1, 0, "neither", 9)
+    q["flags"] = 0                                                  # nothing live
+    n, out = m.search_by_projection(0, q, qd, qa, kb, db, ur, occ, grid)
+    assert n == 0 and np.all(out == -1)
+    q, qd, qa, kb, db, ur, occ = _proj_scene(feats, 0, 1, 1, "map", 10)
+    occ[:] = 1                                                      # every feature already has a MapPoint
+    wn, w = oracle.search_by_projection(1, q, qd, qa, kb, db, ur, occ, grid, 0.8, True)
+    n, out = m.search_by_projection(1, q, qd, qa, kb, db, ur, occ, grid)
+    assert n == wn == 0 and np.array_equal(out, w)
+    q["flags"] = 1                                                  # MapPoints without observations never block: features get reassigned
+    occ[:] = 0
+    wn, w = oracle.search_by_projection(0, q, qd, qa, kb, db, ur, occ, grid, 0.8, True)
+    n, out = m.search_by_projection(0, q, qd, qa, kb, db, ur, occ, grid)
+    assert n == wn and np.array_equal(out, w)
