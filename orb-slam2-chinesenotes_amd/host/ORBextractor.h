@@ -42,6 +42,7 @@ public:
     // (monocular/RGB-D tracking never reads it; stereo does: Frame.cc:520,611,626,633).
     std::vector<cv::Mat> mvImagePyramid;
     void SetPyramidDownload(bool on) { mbDownloadPyramid = on; }
+    orb_extractor* Handle() { return mpHandle; }      // for orb_stereo_match on the device-resident pyramids
 
 protected:
     int nfeatures;
