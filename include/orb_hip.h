@@ -229,6 +229,7 @@ typedef struct orb_featstore {
     const uint16_t* node_of;    /* [n_frames*cap] vocabulary node per feature */
     int32_t cap;
     int32_t n_frames;
+    int32_t n_nodes;            /* size of the node-index space of node_of (0 = 128, the synthetic stand-in) */
 } orb_featstore;
 
 /* Vocabulary stand-in (DBoW2 transform(...,4) of reference src/Frame.cc:431 is
@@ -245,6 +246,28 @@ int orb_match_bow_batch_device(orb_matcher* m, const orb_featstore* store,
 
 void* orb_matcher_stream(orb_matcher* m);
 int orb_matcher_wait_for(orb_matcher* m, void* hip_stream);
+
+/* ---------------------------------------------------------------- vocabulary tree -----------
+ * The descriptor-touching part of DBoW2's TemplatedVocabulary::transform(features, BowVector&, FeatureVector&,
+ * levelsup) as called by Frame::ComputeBoW (reference src/Frame.cc:425-433, levelsup = 4) and
+ * KeyFrame::ComputeBoW (src/KeyFrame.cc:70): for every feature the word (leaf) it falls into and the node it
+ * passes at level L - levelsup (first-minimum Hamming descent, children in stored order).  DBoW2 is a
+ * third-party dependency absent from the reference tree; the host still builds the std::map containers.
+ * The tree is passed flattened: node 0 = root, children of v = children[child_begin[v] .. child_begin[v+1]),
+ * word_id[v] >= 0 for leaves, node_desc = 32 bytes per node (host pointers; copied to the device). */
+typedef struct orb_vocab orb_vocab;
+int orb_vocab_create(int device_id, const uint8_t* node_desc, const int32_t* child_begin, const int32_t* children,
+                     const int32_t* word_id, int n_nodes, int L, orb_vocab** out);
+void orb_vocab_destroy(orb_vocab* v);
+/* number of nodes at level L - levelsup = size of the compact node-index space the batch matcher works in */
+int orb_vocab_level_nodes(orb_vocab* v, int levelsup);
+/* host buffers: word_of[i], node_id[i] (-1 when the descent hit a leaf above that level) */
+int orb_bow_transform(orb_matcher* m, orb_vocab* v, const uint8_t* desc, int n, int levelsup, int32_t* word_of,
+                      int32_t* node_id);
+/* device-resident, batched like orb_bow_assign_device; any output pointer may be NULL.  d_node_of receives the
+ * COMPACT index of the level node (ascending node id), the form orb_match_bow_batch_device consumes. */
+int orb_bow_transform_device(orb_matcher* m, orb_vocab* v, const uint8_t* d_desc, const int32_t* d_counts, int n_frames,
+                             int cap, int levelsup, int32_t* d_word_of, int32_t* d_node_id, uint16_t* d_node_of);
 
 /* ---------------------------------------------------------------- stereo search -------------
  * Additional entry point (Frame.cc links unchanged and keeps its own CPU body): the whole of

@@ -130,6 +130,17 @@ int searchByProjectionLast(const ProjQuery* q, const uint8_t* qDesc, const float
                            const uint8_t* desc, const float* uRight, const uint8_t* occupiedIn, int n,
                            const FrameGrid& grid, bool checkOri, std::vector<int32_t>& matchCur);
 
+// A DBoW2 vocabulary tree flattened to arrays (node 0 = root; children of node v = children[childBegin[v] ..
+// childBegin[v+1]) in stored order; wordId[v] >= 0 for leaves).
+struct VocabTree {
+    const uint8_t* nodeDesc;      // [nNodes][32]
+    const int32_t* childBegin;    // [nNodes + 1]
+    const int32_t* children;
+    const int32_t* wordId;        // [nNodes]
+    int nNodes, L;
+};
+void vocabTransform(const VocabTree& t, const uint8_t* desc, int n, int levelsup, int32_t* wordOf, int32_t* nodeOf);
+
 // Synthetic stand-in for the (absent) ORB vocabulary: 2-level k=10 tree of 256-bit centroids
 // (SURVEY §8d).  nodeId = 11 + 10*c1 + c2.  centroids: 10 level-1 then 100 level-2, 32 B each.
 FeatVec bowTransform(const uint8_t* desc, int n, const uint8_t* centroids /*110 x 32*/);

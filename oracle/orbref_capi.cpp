@@ -217,6 +217,14 @@ int orbref_search_by_projection(int mode, const ProjQuery* q, const uint8_t* qDe
     return nm;
 }
 
+void orbref_vocab_transform(const uint8_t* nodeDesc, const int32_t* childBegin, const int32_t* children,
+                            const int32_t* wordId, int nNodes, int L, const uint8_t* desc, int n, int levelsup,
+                            int32_t* wordOf, int32_t* nodeOf)
+{
+    VocabTree t{nodeDesc, childBegin, children, wordId, nNodes, L};
+    vocabTransform(t, desc, n, levelsup, wordOf, nodeOf);
+}
+
 // grid query exposed for the grid unit tests: returns count, indices in reference order
 int orbref_features_in_area(const KeyPoint* k, int n, float minX, float minY, float invW, float invH,
                             float x, float y, float r, int minLevel, int maxLevel, int32_t* out, int cap)

@@ -384,3 +384,35 @@ int searchByProjectionLast(const ProjQuery* q, const uint8_t* qDesc, const float
 }
 
 }  // namespace orbref
+
+// ------------------------------------------------------------------ DBoW2 vocabulary-tree descent (B.5)
+// TemplatedVocabulary::transform(feature, word_id, weight, nid, levelsup) of ORB-SLAM2's vendored DBoW2 (absent from
+// the reference tree; restated from its published algorithm): from the root, repeatedly move to the child with
+// the smallest Hamming distance (first minimum wins, children in stored order) until a leaf; report the node
+// reached at level L - levelsup.  Called by Frame::ComputeBoW (reference src/Frame.cc:425-433) with levelsup = 4.
+namespace orbref {
+
+void vocabTransform(const VocabTree& t, const uint8_t* desc, int n, int levelsup, int32_t* wordOf, int32_t* nodeOf)
+{
+    const int nidLevel = t.L - levelsup;
+    for (int i = 0; i < n; i++) {
+        const uint8_t* d = desc + 32 * (size_t)i;
+        int finalId = 0, level = 0, nid = (nidLevel <= 0) ? 0 : -1;
+        do {
+            ++level;
+            const int b = t.childBegin[finalId], e = t.childBegin[finalId + 1];
+            finalId = t.children[b];
+            int best = hamming256(d, t.nodeDesc + 32 * (size_t)finalId);
+            for (int c = b + 1; c < e; c++) {
+                const int id = t.children[c];
+                const int h = hamming256(d, t.nodeDesc + 32 * (size_t)id);
+                if (h < best) { best = h; finalId = id; }
+            }
+            if (level == nidLevel) nid = finalId;
+        } while (t.childBegin[finalId + 1] > t.childBegin[finalId]);          // !isLeaf()
+        wordOf[i] = t.wordId[finalId];
+        nodeOf[i] = nid;                                                     // -1: leaf reached above that level
+    }
+}
+
+}  // namespace orbref

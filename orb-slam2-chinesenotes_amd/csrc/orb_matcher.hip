@@ -499,7 +499,8 @@ extern "C" int orb_match_bow_batch_device(orb_matcher* m, const orb_featstore* s
     if ((rc = m->sidesB.ensure(sizeof(BowSide) * (size_t)nPairs)) != ORB_OK) return rc;
     hipLaunchKernelGGL(k_fill_sides, dim3((nPairs + 255) / 256), dim3(256), 0, m->stream, *store, d_kf, d_f, nPairs,
                        (BowSide*)m->sidesA.p, (BowSide*)m->sidesB.p);
-    return launch_match(m, false, (const BowSide*)m->sidesA.p, (const BowSide*)m->sidesB.p, nPairs, 128, store->cap,
+    const int nNodes = store->n_nodes > 0 ? store->n_nodes : 128;
+    return launch_match(m, false, (const BowSide*)m->sidesA.p, (const BowSide*)m->sidesB.p, nPairs, nNodes, store->cap,
                         ratio, checkOri, d_match, store->cap, d_nm);
 }
 

@@ -41,7 +41,7 @@ class FeatVecC(C.Structure):
 
 class FeatStoreC(C.Structure):
     _fields_ = [("desc", C.c_void_p), ("kps", C.c_void_p), ("valid", C.c_void_p), ("counts", C.c_void_p),
-                ("node_of", C.c_void_p), ("cap", C.c_int32), ("n_frames", C.c_int32)]
+                ("node_of", C.c_void_p), ("cap", C.c_int32), ("n_frames", C.c_int32), ("n_nodes", C.c_int32)]
 
 
 def build_library(force=False):
@@ -62,7 +62,8 @@ SYMBOLS = [
     "orb_extract_batch", "orb_extract_batch_device", "orb_extractor_sync", "orb_get_pyramid_level",
     "orb_get_level_counts", "orb_extractor_set_profiling", "orb_extractor_get_stage_ms", "orb_extractor_profiled_frames", "orb_extractor_stream",
     "orb_hamming", "orb_three_maxima", "orb_matcher_create", "orb_matcher_destroy", "orb_matcher_sync",
-    "orb_match_bow", "orb_match_bow_kk", "orb_match_init", "orb_match_projection", "orb_bow_assign_device", "orb_match_bow_batch_device",
+    "orb_match_bow", "orb_match_bow_kk", "orb_match_init", "orb_match_projection", "orb_vocab_create", "orb_vocab_destroy", "orb_vocab_level_nodes", "orb_bow_transform",
+    "orb_bow_transform_device", "orb_bow_assign_device", "orb_match_bow_batch_device",
     "orb_matcher_stream", "orb_stereo_match", "orb_stereo_match_device", "orb_extractor_wait_for", "orb_matcher_wait_for", "orb_last_error", "orb_version",
 ]
 
@@ -111,6 +112,12 @@ def lib():
                                    vp, C.POINTER(ci)]
     L.orb_match_init.argtypes = [vp, vp, vp, ci, vp, vp, ci, vp, vp, ci, cf, ci, vp, C.POINTER(ci)]
     L.orb_match_projection.argtypes = [vp, ci, vp, vp, vp, ci, vp, vp, vp, vp, ci, vp, cf, ci, vp, C.POINTER(ci)]
+    L.orb_vocab_create.argtypes = [ci, vp, vp, vp, vp, ci, ci, C.POINTER(vp)]
+    L.orb_vocab_destroy.argtypes = [vp]
+    L.orb_vocab_destroy.restype = None
+    L.orb_vocab_level_nodes.argtypes = [vp, ci]
+    L.orb_bow_transform.argtypes = [vp, vp, vp, ci, ci, vp, vp]
+    L.orb_bow_transform_device.argtypes = [vp, vp, vp, vp, ci, ci, ci, vp, vp, vp]
     L.orb_bow_assign_device.argtypes = [vp, vp, vp, ci, ci, vp, vp]
     L.orb_match_bow_batch_device.argtypes = [vp, C.POINTER(FeatStoreC), vp, vp, ci, cf, ci, vp, vp]
     L.orb_matcher_stream.argtypes = [vp]
@@ -353,7 +360,7 @@ class Matcher:
     def match_bow_batch_device(self, store, d_kf_index, d_f_index, n_pairs, d_match, d_nmatches):
         """store = dict(desc=, kps=, valid=, counts=, node_of=, cap=, n_frames=) of raw device pointers."""
         s = FeatStoreC(store["desc"], store["kps"], store.get("valid") or None, store["counts"], store["node_of"],
-                       store["cap"], store["n_frames"])
+                       store["cap"], store["n_frames"], store.get("n_nodes", 0))
         _check(self.L.orb_match_bow_batch_device(self.h, C.byref(s), C.c_void_p(d_kf_index), C.c_void_p(d_f_index), n_pairs,
                                                  self.nnratio, int(self.check_ori), C.c_void_p(d_match),
                                                  C.c_void_p(d_nmatches)))
@@ -369,3 +376,40 @@ def stereo_match(ex_left, ex_right, k_l, d_l, k_r, d_r, mb, mbf):
     _check(lib().orb_stereo_match(ex_left.h, ex_right.h, _p(k_l), _p(d_l), n, _p(k_r), _p(d_r), k_r.shape[0],
                                   float(mb), float(mbf), _p(u), _p(z)))
     return u[:n], z[:n]
+
+
+class Vocabulary:
+    """A flattened DBoW2 vocabulary tree on the device (see orbhip.synth.synth_vocab_tree for the array layout)."""
+
+    def __init__(self, tree, device=0):
+        self.L = lib()
+        self.h = C.c_void_p()
+        nd = np.ascontiguousarray(tree["node_desc"], np.uint8)
+        cb = np.ascontiguousarray(tree["child_begin"], np.int32)
+        ch = np.ascontiguousarray(tree["children"], np.int32)
+        wi = np.ascontiguousarray(tree["word_id"], np.int32)
+        _check(self.L.orb_vocab_create(device, _p(nd), _p(cb), _p(ch), _p(wi), nd.shape[0], int(tree["L"]), C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.L.orb_vocab_destroy(self.h)
+            self.h = C.c_void_p()
+
+    __del__ = close
+
+    def level_nodes(self, levelsup=4):
+        return self.L.orb_vocab_level_nodes(self.h, levelsup)
+
+    def transform(self, matcher, desc, levelsup=4):
+        desc = np.ascontiguousarray(desc, np.uint8)
+        n = desc.shape[0]
+        word = np.zeros(max(n, 1), np.int32)
+        node = np.zeros(max(n, 1), np.int32)
+        _check(self.L.orb_bow_transform(matcher.h, self.h, _p(desc), n, levelsup, _p(word), _p(node)))
+        return word[:n], node[:n]
+
+    def transform_device(self, matcher, d_desc, d_counts, n_frames, cap, levelsup, d_word_of=0, d_node_id=0, d_node_of=0):
+        _check(self.L.orb_bow_transform_device(matcher.h, self.h, C.c_void_p(d_desc), C.c_void_p(d_counts), n_frames, cap,
+                                               levelsup, C.c_void_p(d_word_of) if d_word_of else None,
+                                               C.c_void_p(d_node_id) if d_node_id else None,
+                                               C.c_void_p(d_node_of) if d_node_of else None))

@@ -79,3 +79,41 @@ def synth_valid_flags(n: int, seed: int, p_num: int = 7, p_den: int = 10) -> np.
     """Bernoulli(p) 'has a good MapPoint' flags for a keyframe's features."""
     r = splitmix64(0x7A11D000 + seed, 0, n) % np.uint64(p_den)
     return (r < np.uint64(p_num)).astype(np.uint8)
+
+
+def synth_vocab_tree(k: int = 10, L: int = 3, seed: int = 0xB0CAB, prune: float = 0.1, shuffle_ids: bool = True) -> dict:
+    """A seeded stand-in for a DBoW2 vocabulary (the ORBvoc file is absent): branching factor k, depth L, random
+    256-bit node descriptors; a fraction `prune` of inner nodes is cut into early leaves (trained vocabularies are
+    unbalanced) and node ids are permuted so children are NOT consecutive (ids come from file order in DBoW2).
+    Returns flat arrays: node_desc (n,32) u8, child_begin (n+1) i32, children i32, word_id (n) i32 (-1 inner), L."""
+    rng = np.random.default_rng(seed)
+    children_of = [[]]
+    depth = [0]
+    frontier = [0]
+    for lvl in range(L):
+        nxt = []
+        for v in frontier:
+            if v != 0 and rng.random() < prune:
+                continue                                            # early leaf
+            for _ in range(k):
+                children_of.append([])
+                depth.append(lvl + 1)
+                children_of[v].append(len(children_of) - 1)
+                nxt.append(len(children_of) - 1)
+        frontier = nxt
+    n = len(children_of)
+    perm = np.arange(n)
+    if shuffle_ids:
+        perm[1:] = 1 + rng.permutation(n - 1)                       # root stays node 0
+    new_children = [None] * n
+    for v in range(n):
+        new_children[perm[v]] = [int(perm[c]) for c in children_of[v]]
+    child_begin = np.zeros(n + 1, np.int32)
+    for v in range(n):
+        child_begin[v + 1] = child_begin[v] + len(new_children[v])
+    children = np.array([c for v in range(n) for c in new_children[v]], np.int32)
+    word_id = np.full(n, -1, np.int32)
+    leaves = [v for v in range(n) if not new_children[v]]
+    word_id[leaves] = np.arange(len(leaves), dtype=np.int32)
+    node_desc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    return dict(node_desc=node_desc, child_begin=child_begin, children=children, word_id=word_id, L=L, k=k)

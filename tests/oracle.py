@@ -76,6 +76,7 @@ def lib():
         L.orbref_search_by_projection.restype = C.c_int
         L.orbref_search_by_projection.argtypes = ([C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                                     C.c_void_p, C.c_void_p, C.c_int] + [C.c_float] * 5 + [C.c_int, C.c_void_p])
+        L.orbref_vocab_transform.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.orbref_features_in_area.restype = C.c_int
         L.orbref_features_in_area.argtypes = ([C.c_void_p, C.c_int] + [C.c_float] * 7 + [C.c_int] * 2 +
                                               [C.c_void_p, C.c_int])
@@ -308,3 +309,14 @@ def search_by_projection(mode, q, q_desc, q_angle, kps, desc, u_right, occupied,
     nm = lib().orbref_search_by_projection(mode, _p(q), _p(q_desc), _p(q_angle), q.shape[0], _p(kps), _p(desc), _p(u_right),
                                            _p(occupied), n, *[float(g) for g in grid], ratio, int(check_ori), _p(out))
     return nm, out[:n]
+
+
+def vocab_transform(tree, desc, levelsup=4):
+    """tree = dict(node_desc, child_begin, children, word_id, L) (see orbhip.synth.synth_vocab_tree)."""
+    desc = np.ascontiguousarray(desc, np.uint8)
+    n = desc.shape[0]
+    word = np.zeros(max(n, 1), np.int32)
+    node = np.zeros(max(n, 1), np.int32)
+    lib().orbref_vocab_transform(_p(tree["node_desc"]), _p(tree["child_begin"]), _p(tree["children"]), _p(tree["word_id"]),
+                                 tree["node_desc"].shape[0], tree["L"], _p(desc), n, levelsup, _p(word), _p(node))
+    return word[:n], node[:n]

@@ -1,0 +1,84 @@
+"""GPU parity of the vocabulary-tree descent (DBoW2 transform, FeatureVector/word part) and of the whole
+device-resident chain extract -> transform -> SearchByBoW with a deeper, unbalanced, id-shuffled tree."""
+import numpy as np
+import pytest
+
+import oracle
+from orbhip import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("k,L,levelsup", [(10, 3, 1), (10, 3, 2), (5, 4, 2), (10, 2, 4), (3, 6, 4)])
+def test_vocab_transform_matches_oracle(k, L, levelsup):
+    tree = synth.synth_vocab_tree(k, L, seed=k * 100 + L)
+    rng = np.random.default_rng(L)
+    desc = rng.integers(0, 256, (1500, 32), dtype=np.uint8)
+    ww, wn = oracle.vocab_transform(tree, desc, levelsup)
+    m = capi.Matcher()
+    v = capi.Vocabulary(tree)
+    gw, gn = v.transform(m, desc, levelsup)
+    assert np.array_equal(gw, ww) and np.array_equal(gn, wn)
+    assert gw.min() >= 0 and len(set(gw.tolist())) > 20
+
+
+def test_extract_transform_match_chain_on_device():
+    import torch
+    tree = synth.synth_vocab_tree(10, 3, seed=77, prune=0.15)
+    levelsup = 1                                                      # FeatureVector nodes at depth 2 (~90 nodes)
+    F, W, H = 4, 640, 480
+    base = synth.synth_frame(60, noise=0).astype(np.int16)
+    frames = np.stack([np.clip(base + (synth.splitmix64(5 + i, 0, base.size) % np.uint64(13)).astype(np.int16).reshape(base.shape) - 6,
+                               0, 255).astype(np.uint8) for i in range(F)])
+    ex, mt, voc = capi.Extractor(), capi.Matcher(0.7, True), capi.Vocabulary(tree)
+    K = voc.level_nodes(levelsup)
+    cap = ex.max_keypoints
+    dev = torch.device("cuda", 0)
+    d_imgs = torch.from_numpy(frames).to(dev)
+    d_kps = torch.zeros(F * cap * 28, dtype=torch.uint8, device=dev)
+    d_desc = torch.zeros(F * cap * 32, dtype=torch.uint8, device=dev)
+    d_counts = torch.zeros(F, dtype=torch.int32, device=dev)
+    d_node = torch.zeros(F * cap, dtype=torch.int16, device=dev)
+    d_nodeid = torch.zeros(F * cap, dtype=torch.int32, device=dev)
+    d_word = torch.zeros(F * cap, dtype=torch.int32, device=dev)
+    valid_np = np.stack([synth.synth_valid_flags(cap, 40 + i) for i in range(F)])
+    d_valid = torch.from_numpy(valid_np).to(dev)
+    pairs = [(a, b) for a in range(F) for b in range(F) if a != b]
+    kf_idx = torch.tensor([p[0] for p in pairs], dtype=torch.int32, device=dev)
+    f_idx = torch.tensor([p[1] for p in pairs], dtype=torch.int32, device=dev)
+    d_match = torch.zeros(len(pairs) * cap, dtype=torch.int32, device=dev)
+    d_nm = torch.zeros(len(pairs), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    ex.extract_batch_device(d_imgs.data_ptr(), F, H, W, W, W * H, d_kps.data_ptr(), d_desc.data_ptr(), cap, d_counts.data_ptr())
+    mt.wait_for(ex.stream)
+    voc.transform_device(mt, d_desc.data_ptr(), d_counts.data_ptr(), F, cap, levelsup, d_word.data_ptr(), d_nodeid.data_ptr(),
+                         d_node.data_ptr())
+    store = dict(desc=d_desc.data_ptr(), kps=d_kps.data_ptr(), valid=d_valid.data_ptr(), counts=d_counts.data_ptr(),
+                 node_of=d_node.data_ptr(), cap=cap, n_frames=F, n_nodes=K)
+    mt.match_bow_batch_device(store, kf_idx.data_ptr(), f_idx.data_ptr(), len(pairs), d_match.data_ptr(), d_nm.data_ptr())
+    ex.sync(); mt.sync(); torch.cuda.synchronize()
+    counts = d_counts.cpu().numpy()
+    kps = d_kps.cpu().numpy().view(capi.KP_DTYPE).reshape(F, cap)
+    desc = d_desc.cpu().numpy().reshape(F, cap, 32)
+    nodeid = d_nodeid.cpu().numpy().reshape(F, cap)
+    word = d_word.cpu().numpy().reshape(F, cap)
+    match = d_match.cpu().numpy().reshape(len(pairs), cap)
+    nm = d_nm.cpu().numpy()
+    feats = []
+    for i in range(F):
+        n = counts[i]
+        ww, wn = oracle.vocab_transform(tree, desc[i, :n], levelsup)
+        assert np.array_equal(word[i, :n], ww) and np.array_equal(nodeid[i, :n], wn)
+        ids = sorted(set(int(v) for v in wn if v >= 0))                # FeatureVector: ascending node ids, ascending indices
+        offs, idx = [0], []
+        for nid in ids:
+            idx += np.nonzero(wn == nid)[0].tolist()
+            offs.append(len(idx))
+        feats.append((kps[i, :n], desc[i, :n], oracle.FeatVec(ids, offs, idx)))
+    total = 0
+    for p, (a, b) in enumerate(pairs):
+        (ka, da, fa), (kb, db, fb) = feats[a], feats[b]
+        wn_, wm = oracle.search_by_bow(da, ka["angle"], valid_np[a][:len(ka)], fa, db, kb["angle"], fb, 0.7, True)
+        assert nm[p] == wn_ and np.array_equal(match[p, :len(kb)], wm), (a, b)
+        total += wn_
+    assert total > 50 * len(pairs)
