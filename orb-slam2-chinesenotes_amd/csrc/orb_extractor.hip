@@ -111,6 +111,7 @@ static int build_geometry(orb_extractor* h, int rows, int cols)
     size_t candOff = 0;
     int kpOff = 0, nodeCap = 0;
     std::vector<uint32_t> pathTab;
+    int maxItems = 1, maxPdw = 4, maxRows = 7, maxZone = 1;
     for (int l = 0; l < nl; l++) {
         OrbLevelGeom& L = G.L[l];
         L.w = cv_round_f((float)cols * h->invScale[l]);                 // :1158
@@ -155,9 +156,17 @@ static int build_geometry(orb_extractor* h, int rows, int cols)
                     c.w = (short)((int)maxX - (int)iniX); c.h = (short)((int)maxY - (int)iniY);
                     c.level = (unsigned char)l; c.ci = (unsigned char)i; c.cj = (unsigned char)j; c.pad = 0;
                     if (c.w < 7 || c.h < 7) continue;                    // cv::FAST finds nothing in such a ROI
-                    if (((c.w - 6 + 10) / 4 + 1) * (c.h - 6) > 1024) {     // k_fast_cells: <= 16 quad steps per lane
-                        orb_set_error("FAST cell %dx%d too large for the kernel", c.w, c.h);
-                        return ORB_ERR_UNSUPPORTED;
+                    {   // k_fast_cells works on quads of 4 aligned columns: items = quads per row x zone rows
+                        const int xoff = c.x0 & 3, zLo = xoff + 3, zHi = zLo + c.w - 6;
+                        const int items = ((zHi >> 2) + 1 - ((zLo - 1) >> 2)) * (c.h - 6);
+                        if (items > 1024) {                              // <= 16 quad steps per lane
+                            orb_set_error("FAST cell %dx%d too large for the kernel", c.w, c.h);
+                            return ORB_ERR_UNSUPPORTED;
+                        }
+                        maxItems = std::max(maxItems, items);
+                        maxPdw = std::max(maxPdw, (xoff + c.w + 3) / 4 + 1);       // staged dwords + one of right slack
+                        maxRows = std::max(maxRows, (int)c.h);
+                        maxZone = std::max(maxZone, (c.w - 6) * (c.h - 6));
                     }
                     h->cells.push_back(c);
                     candCap += ((c.w - 6 + 1) / 2) * ((c.h - 6 + 1) / 2);   // 3x3 strict NMS bound
@@ -227,6 +236,10 @@ static int build_geometry(orb_extractor* h, int rows, int cols)
     h->candSlab = candOff;
     h->nodeCap = nodeCap;
     h->maxKp = kpOff;
+    h->fastMaxItems = (maxItems + 63) / 64 * 64;
+    h->fastPdw = maxPdw;
+    h->fastRows = maxRows;
+    h->fastMaxZone = maxZone;
     // LDS sort capacity per (frame, level) instance; larger candidate sets are sorted in global memory.
     h->sortCap = (h->prm.nfeatures <= 1500) ? 2048 : 4096;
     if (const char* e = getenv("ORB_SORT_CAP")) h->sortCap = std::max(256, atoi(e));
@@ -501,7 +514,7 @@ extern "C" int orb_extract_batch_device(orb_extractor* h, const uint8_t* d_imgs,
         if (prof) ORB_HIP_TRY(hipEventRecord(pe[1], ss));
         orb_launch_fast_cells(ss, G, spyr, h->pyrSlab, (const OrbCell*)h->dCells.p, (int)h->cells.size(),
                               (const uint32_t*)h->dPath.p, scand, h->candSlab, scc, serr, h->prm.ini_th_fast,
-                              h->prm.min_th_fast, n);
+                              h->prm.min_th_fast, h->fastMaxItems, h->fastPdw, h->fastRows, h->fastMaxZone, n);
         if (prof) ORB_HIP_TRY(hipEventRecord(pe[2], ss));
         orb_launch_quadtree(ss, G, scand, h->candSlab, scc, skpl, skc, serr, h->sortCap, h->nodeCap, n);
         if (prof) ORB_HIP_TRY(hipEventRecord(pe[3], ss));

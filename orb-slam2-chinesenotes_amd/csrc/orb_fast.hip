@@ -16,14 +16,15 @@
 //   * only pixels with V > min(iniTh, minTh) can ever be keypoints: they are queued (the queue
 //     re-uses the image tile's LDS) and NMS + emission run over the queue, not over the zone;
 //   * the quadtree path of a candidate is two table look-ups (x and y bisect independently).
+#include <algorithm>
+
 #include "orb_kernels.h"
 
 #define WAVE 64
-#define FT_PITCH 72                    // tile / score-map pitch in bytes (18 dwords): 66 + 3 + slack
-#define FT_PDW (FT_PITCH / 4)
-#define FT_ROWS 66                     // max ROI rows
 #define FT_PAD 4                       // dwords of slack around the tile (edge quads read one dword outside)
-#define FT_QCAP (FT_ROWS * FT_PITCH / 2)   // candidate-queue capacity in u16 entries (aliases the tile)
+// LDS is sized per image geometry (dynamic): tile and score map use a row pitch of `pdw` dwords that covers the
+// widest ROI of the frame (13 dwords at 640x480 instead of the 18 a 66-px ROI would need), which roughly doubles
+// the number of resident waves -- the kernel is latency/occupancy-bound once the arithmetic is this lean.
 
 __device__ __forceinline__ unsigned pk_max3(unsigned a, unsigned b, unsigned c)
 {
@@ -114,11 +115,14 @@ __global__ __launch_bounds__(WAVE) void k_fast_cells(const OrbGeom G, const uint
                                                      const uint32_t* __restrict__ pathTab,
                                                      unsigned long long* __restrict__ cand, size_t candSlab,
                                                      int* __restrict__ candCount, int* __restrict__ errFlags,
-                                                     int iniTh, int minTh)
+                                                     int iniTh, int minTh, int maxItems, int pdw, int rowsMax, int tileDwords)
 {
-    __shared__ uint32_t tileRaw[FT_PAD + FT_ROWS * FT_PDW + FT_PAD];
-    __shared__ uint32_t smapDw[FT_ROWS * FT_PDW];
-    uint32_t* tileDw = tileRaw + FT_PAD;
+    // dynamic LDS: [pad | tile (>= 2 bytes per zone pixel: it later holds the candidate queue) | pad | score map | pair queues]
+    extern __shared__ uint32_t fsm[];
+    uint32_t* tileDw = fsm + FT_PAD;
+    uint32_t* smapDw = tileDw + tileDwords + FT_PAD;
+    uint16_t* pairQ = reinterpret_cast<uint16_t*>(smapDw + rowsMax * pdw);   // [2][maxItems]
+    const int FT_PDW = pdw, FT_PITCH = 4 * pdw;
     const int lane = threadIdx.x;
     const int f = blockIdx.y;
     const OrbCell cell = cells[blockIdx.x];
@@ -150,44 +154,95 @@ __global__ __launch_bounds__(WAVE) void k_fast_cells(const OrbGeom G, const uint
     }
     __syncthreads();
 
-    // ---- V for the zone, 4 pixels per lane per step; remember which pixels exceed the lower threshold
+    // ---- phase A: cheap exact rejection on every pixel pair (what cv::FAST's threshold tests amount to).
+    // A 9-arc of the 16-ring contains ring pixel k or k+8 for every k, so with lo_k = min(r_k, r_k+8),
+    // hi_k = max(r_k, r_k+8):   V <= U := max(I - max_k lo_k, min_k hi_k - I).
+    // Only the 4 even k are used here (rows y, y+-2, y+-3: 11 dword reads instead of 21); pairs with
+    // U <= lowTh in both pixels score 0 (never a corner at either threshold) and skip the exact V (about 5 in 6 pairs).
     const int lowTh = min(iniTh, minTh);
     const int nItems = nq * zh;
     const unsigned invq = ((1u << 20) + nq - 1) / nq;
-    unsigned long long cmask = 0;                                  // bit 4*step+j: pixel j of this lane's step-th quad
-    int step = 0;
-    for (int base = 0; base < nItems; base += WAVE, step++) {
+    int nA = 0, nB = 0;                                            // wave-uniform queue lengths
+    for (int base = 0; base < nItems; base += WAVE) {
         const int item = base + lane;
+        bool pa = false, pb = false;
         if (item < nItems) {
             const int ry = (int)(((unsigned)item * invq) >> 20);
             const int q = qLo + item - ry * nq;
             const int row = 3 + ry;
-            unsigned W[7][3];
+            const uint32_t* p = tileDw + row * FT_PDW + q - 1;
+            const unsigned c0 = p[0], c1 = p[1], c2 = p[2];                                   // row y
+            const unsigned u1 = p[-3 * FT_PDW + 1], d1 = p[3 * FT_PDW + 1];                   // rows y-3, y+3: x .. x+3
+            const unsigned a0 = p[-2 * FT_PDW], a1 = p[-2 * FT_PDW + 1], a2 = p[-2 * FT_PDW + 2];   // row y-2
+            const unsigned b0 = p[2 * FT_PDW], b1 = p[2 * FT_PDW + 1], b2 = p[2 * FT_PDW + 2];      // row y+2
+            smapDw[row * FT_PDW + q] = 0;
+            unsigned u[2];
 #pragma unroll
-            for (int r = 0; r < 7; r++) {
-                const uint32_t* p = tileDw + (row - 3 + r) * FT_PDW + q - 1;
-                W[r][0] = p[0]; W[r][1] = p[1]; W[r][2] = p[2];
+            for (int h = 0; h < 2; h++) {
+                // window byte index of the pair's first pixel: 4 (pixels 4q,4q+1) or 6 (4q+2,4q+3)
+                const unsigned cc = h ? pick2<6>(c0, c1, c2) : pick2<4>(c0, c1, c2);
+                const unsigned r0 = h ? pick2<6>(0, d1, 0) : pick2<4>(0, d1, 0);              // k=0  (0,+3)
+                const unsigned r8 = h ? pick2<6>(0, u1, 0) : pick2<4>(0, u1, 0);              // k=8  (0,-3)
+                const unsigned r4 = h ? pick2<9>(c0, c1, c2) : pick2<7>(c0, c1, c2);          // k=4  (+3,0)
+                const unsigned r12 = h ? pick2<3>(c0, c1, c2) : pick2<1>(c0, c1, c2);         // k=12 (-3,0)
+                const unsigned r2 = h ? pick2<8>(b0, b1, b2) : pick2<6>(b0, b1, b2);          // k=2  (+2,+2)
+                const unsigned r10 = h ? pick2<4>(a0, a1, a2) : pick2<2>(a0, a1, a2);         // k=10 (-2,-2)
+                const unsigned r6 = h ? pick2<8>(a0, a1, a2) : pick2<6>(a0, a1, a2);          // k=6  (+2,-2)
+                const unsigned r14 = h ? pick2<4>(b0, b1, b2) : pick2<2>(b0, b1, b2);         // k=14 (-2,+2)
+                const unsigned mlo = pk_max3(pk_min2(r0, r8), pk_min2(r4, r12), pk_max2(pk_min2(r2, r10), pk_min2(r6, r14)));
+                const unsigned mhi = pk_min3(pk_max2(r0, r8), pk_max2(r4, r12), pk_min2(pk_max2(r2, r10), pk_max2(r6, r14)));
+                u[h] = pk_max_i16(pk_sub_i16(cc, mlo), pk_sub_i16(mhi, cc));                  // U per 16-bit half (signed)
             }
-            const unsigned sA = fast_pair<4>(W);                   // pixels 4q, 4q+1
-            const unsigned sB = fast_pair<6>(W);                   // pixels 4q+2, 4q+3
-            unsigned s4 = __builtin_amdgcn_perm(sB, sA, 0x06040200u);
-            // pixels outside [zLo, zHi) belong to the neighbouring cell: score 0 here
-            const int c0 = 4 * q;
-            unsigned keep = 0;
-            if (c0 >= zLo && c0 < zHi) keep |= 0x000000ffu;
-            if (c0 + 1 >= zLo && c0 + 1 < zHi) keep |= 0x0000ff00u;
-            if (c0 + 2 >= zLo && c0 + 2 < zHi) keep |= 0x00ff0000u;
-            if (c0 + 3 >= zLo && c0 + 3 < zHi) keep |= 0xff000000u;
-            s4 &= keep;
-            smapDw[row * FT_PDW + q] = s4;
-            unsigned fl = 0;
-            if ((int)(s4 & 0xff) > lowTh) fl |= 1;
-            if ((int)((s4 >> 8) & 0xff) > lowTh) fl |= 2;
-            if ((int)((s4 >> 16) & 0xff) > lowTh) fl |= 4;
-            if ((int)(s4 >> 24) > lowTh) fl |= 8;
-            cmask |= (unsigned long long)fl << (4 * step);
+            // zone membership of the four pixels; a pair is queued if one of its in-zone pixels has U > lowTh
+            const int c0x = 4 * q;
+            const bool in0 = c0x >= zLo && c0x < zHi, in1 = c0x + 1 >= zLo && c0x + 1 < zHi;
+            const bool in2 = c0x + 2 >= zLo && c0x + 2 < zHi, in3 = c0x + 3 >= zLo && c0x + 3 < zHi;
+            pa = (in0 && (int)(short)(u[0] & 0xffff) > lowTh) || (in1 && (int)(short)(u[0] >> 16) > lowTh);
+            pb = (in2 && (int)(short)(u[1] & 0xffff) > lowTh) || (in3 && (int)(short)(u[1] >> 16) > lowTh);
+        }
+        const unsigned long long ba = __ballot(pa), bb = __ballot(pb);
+        const unsigned long long lt = (1ull << lane) - 1;
+        if (pa) pairQ[nA + __popcll(ba & lt)] = (uint16_t)item;
+        if (pb) pairQ[maxItems + nB + __popcll(bb & lt)] = (uint16_t)item;
+        nA += __popcll(ba);
+        nB += __popcll(bb);
+    }
+    __syncthreads();
+
+    // ---- phase B: exact V for the queued pairs (dense lanes again); remember pixels above the lower threshold
+    unsigned long long cmask = 0;                                  // bit 2*step+j, steps over queue A then queue B
+    int step = 0;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int nQ = h ? nB : nA;
+        const uint16_t* Q = pairQ + (h ? maxItems : 0);
+        for (int base = 0; base < nQ; base += WAVE, step++) {
+            const int e = base + lane;
+            if (e < nQ) {
+                const int item = Q[e];
+                const int ry = (int)(((unsigned)item * invq) >> 20);
+                const int q = qLo + item - ry * nq;
+                const int row = 3 + ry;
+                unsigned W[7][3];
+#pragma unroll
+                for (int r = 0; r < 7; r++) {
+                    const uint32_t* p = tileDw + (row - 3 + r) * FT_PDW + q - 1;
+                    W[r][0] = p[0]; W[r][1] = p[1]; W[r][2] = p[2];
+                }
+                const unsigned s2 = h ? fast_pair<6>(W) : fast_pair<4>(W);      // two scores, one per 16-bit half
+                const int cx = 4 * q + 2 * h;
+                int sLo = (int)(s2 & 0xff), sHi = (int)((s2 >> 16) & 0xff);
+                if (!(cx >= zLo && cx < zHi)) sLo = 0;             // pixel of the neighbouring cell
+                if (!(cx + 1 >= zLo && cx + 1 < zHi)) sHi = 0;
+                reinterpret_cast<uint16_t*>(smapDw)[(row * FT_PITCH + cx) >> 1] = (uint16_t)(sLo | (sHi << 8));
+                unsigned fl = 0;
+                if (sLo > lowTh) fl |= 1;
+                if (sHi > lowTh) fl |= 2;
+                cmask |= (unsigned long long)fl << (2 * step);
+            }
         }
     }
+    const int stepsA = (nA + WAVE - 1) / WAVE;                     // steps [0, stepsA) belong to queue A
     __syncthreads();                                               // tile is dead from here on: it becomes the queue
 
     // ---- queue of candidate pixels, entry = row << 8 | col (tile coordinates); order is irrelevant
@@ -202,7 +257,7 @@ __global__ __launch_bounds__(WAVE) void k_fast_cells(const OrbGeom G, const uint
     }
     const int nCand = __shfl(incl, WAVE - 1);
     if (nCand == 0) return;
-    if (nCand > FT_QCAP) {                                         // cannot happen: FT_QCAP >= 60*60/... guard anyway
+    if (nCand > 2 * tileDwords) {                                  // cannot happen: the tile region holds 2 B per zone pixel
         if (lane == 0) atomicOr(&errFlags[f], 16);
         return;
     }
@@ -212,10 +267,13 @@ __global__ __launch_bounds__(WAVE) void k_fast_cells(const OrbGeom G, const uint
         while (mm) {
             const int bit = __ffsll((long long)mm) - 1;
             mm &= mm - 1;
-            const int item = (bit >> 2) * WAVE + lane;
+            const int st = bit >> 1;
+            const int h = st >= stepsA;
+            const int e = (h ? st - stepsA : st) * WAVE + lane;
+            const int item = pairQ[(h ? maxItems : 0) + e];
             const int ry = (int)(((unsigned)item * invq) >> 20);
             const int q = qLo + item - ry * nq;
-            queue[w++] = (uint16_t)(((3 + ry) << 8) | (4 * q + (bit & 3)));
+            queue[w++] = (uint16_t)(((3 + ry) << 8) | (4 * q + 2 * h + (bit & 1)));
         }
     }
     __syncthreads();
@@ -282,9 +340,12 @@ __global__ __launch_bounds__(WAVE) void k_fast_cells(const OrbGeom G, const uint
 
 void orb_launch_fast_cells(hipStream_t st, const OrbGeom& G, const uint8_t* pyr, size_t pyrSlab,
                            const OrbCell* cells, int nCells, const uint32_t* pathTab, unsigned long long* cand,
-                           size_t candSlab, int* candCount, int* errFlags, int iniTh, int minTh, int nFrames)
+                           size_t candSlab, int* candCount, int* errFlags, int iniTh, int minTh, int maxItems,
+                           int pdw, int rowsMax, int maxZonePx, int nFrames)
 {
     if (nCells == 0) return;
-    hipLaunchKernelGGL(k_fast_cells, dim3(nCells, nFrames), dim3(WAVE), 0, st, G, pyr, pyrSlab, cells, pathTab, cand,
-                       candSlab, candCount, errFlags, iniTh, minTh);
+    const int tileDwords = std::max(rowsMax * pdw, (maxZonePx + 1) / 2);
+    const size_t lds = (size_t)4 * (FT_PAD + tileDwords + FT_PAD + rowsMax * pdw) + (size_t)4 * maxItems;
+    hipLaunchKernelGGL(k_fast_cells, dim3(nCells, nFrames), dim3(WAVE), lds, st, G, pyr, pyrSlab, cells, pathTab, cand,
+                       candSlab, candCount, errFlags, iniTh, minTh, maxItems, pdw, rowsMax, tileDwords);
 }

@@ -8,7 +8,8 @@ void orb_launch_resize(hipStream_t st, uint8_t* pyr, size_t pyrSlab, const OrbLe
                        const OrbLevelGeom& dst, const int2* xtab, const int2* ytab, int nFrames);
 void orb_launch_fast_cells(hipStream_t st, const OrbGeom& G, const uint8_t* pyr, size_t pyrSlab,
                            const OrbCell* cells, int nCells, const uint32_t* pathTab, unsigned long long* cand,
-                           size_t candSlab, int* candCount, int* errFlags, int iniTh, int minTh, int nFrames);
+                           size_t candSlab, int* candCount, int* errFlags, int iniTh, int minTh, int maxItems,
+                           int pdw, int rowsMax, int maxZonePx, int nFrames);
 size_t orb_quadtree_lds_bytes(int sortCap, int nodeCap);
 void orb_launch_quadtree(hipStream_t st, const OrbGeom& G, unsigned long long* cand, size_t candSlab,
                          const int* candCount, uint32_t* kpl, int* kpCount, int* errFlags, int sortCap,
