@@ -241,8 +241,11 @@ static int build_geometry(orb_extractor* h, int rows, int cols)
     h->fastRows = maxRows;
     h->fastMaxZone = maxZone;
     // LDS sort capacity per (frame, level) instance; larger candidate sets are sorted in global memory.
-    h->sortCap = (h->prm.nfeatures <= 1500) ? 2048 : 4096;
-    if (const char* e = getenv("ORB_SORT_CAP")) h->sortCap = std::max(256, atoi(e));
+    // It starts small (more resident workgroups: the kernel is latency-bound) and orb_extractor_sync() grows it to
+    // the largest candidate count actually seen, so steady-state batches sort in LDS.
+    h->sortCap = 1024;
+    h->sortCapFixed = false;
+    if (const char* e = getenv("ORB_SORT_CAP")) { h->sortCap = std::max(256, atoi(e)); h->sortCapFixed = true; }
     while (h->sortCap > 256 && orb_quadtree_lds_bytes(h->sortCap, nodeCap) > 60 * 1024) h->sortCap >>= 1;
     if (orb_quadtree_lds_bytes(h->sortCap, nodeCap) > 64 * 1024) {
         orb_set_error("nfeatures too large for the quadtree kernel's LDS budget");
@@ -543,6 +546,18 @@ extern "C" int orb_extractor_sync(orb_extractor* h)
     if (h->lastFrames > 0) {
         h->hErr.resize(h->lastFrames);
         ORB_HIP_TRY(hipMemcpy(h->hErr.data(), h->dErr.p, (size_t)4 * h->lastFrames, hipMemcpyDeviceToHost));
+        if (!h->sortCapFixed) {                        // adapt the quadtree's LDS sort capacity to the data
+            h->hErr.resize((size_t)ORB_MAX_LEVELS * h->lastFrames);
+            ORB_HIP_TRY(hipMemcpy(h->hErr.data(), h->dCandCount.p, (size_t)4 * ORB_MAX_LEVELS * h->lastFrames, hipMemcpyDeviceToHost));
+            int mx = 0;
+            for (size_t i = 0; i < h->hErr.size(); i++) mx = std::max(mx, h->hErr[i]);
+            int want = 1024;
+            while (want < mx && want < 4096) want <<= 1;
+            while (want > 256 && orb_quadtree_lds_bytes(want, h->nodeCap) > 60 * 1024) want >>= 1;
+            if (want > h->sortCap) h->sortCap = want;
+            h->hErr.resize(h->lastFrames);
+            ORB_HIP_TRY(hipMemcpy(h->hErr.data(), h->dErr.p, (size_t)4 * h->lastFrames, hipMemcpyDeviceToHost));
+        }
         for (int f = 0; f < h->lastFrames; f++)
             if (h->hErr[f]) {
                 orb_set_error("device-side overflow flag 0x%x on frame %d (1 candidates, 2 nodes, 4 output cap)", h->hErr[f], f);

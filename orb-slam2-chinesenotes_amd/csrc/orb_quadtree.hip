@@ -108,43 +108,17 @@ __device__ int qt_scan(int* a, int n, int* part)
     return total;
 }
 
-__global__ __launch_bounds__(256) void k_quadtree(const OrbGeom G, unsigned long long* __restrict__ cand,
-                                                  size_t candSlab, const int* __restrict__ candCount,
-                                                  uint32_t* __restrict__ kpl, int* __restrict__ kpCount,
-                                                  int* __restrict__ errFlags, int sortCap, int nodeCap)
+// Everything after the keys are in place.  Force-inlined into both call sites so that the compiler knows the
+// address space of `keys` (LDS: ds_* instructions; a runtime-selected generic pointer would turn every access
+// of the sort and of the binary searches into slow flat_* operations).
+__device__ __forceinline__ void qt_body(unsigned long long* keys, int n, const OrbGeom& G, const OrbLevelGeom& L, int f,
+                                        unsigned long long* prevA, unsigned long long* prevB, QtNode* A, QtNode* B,
+                                        int3* cuts, int* va, int* vb, int* part, uint32_t* __restrict__ kpl,
+                                        int* outCount, int* __restrict__ errFlags, int* sh)
 {
-    extern __shared__ unsigned long long qsm[];
-    // LDS carve-up: keys[sortCap] | prevA,prevB[nodeCap] (u64) | A,B[nodeCap] (QtNode) | cuts[nodeCap] (int3)
-    //               | va[nodeCap] | vb[nodeCap] (int) | part[257]
-    unsigned long long* ldsKeys = qsm;
-    unsigned long long* prevA = qsm + sortCap;
-    unsigned long long* prevB = prevA + nodeCap;
-    QtNode* A = reinterpret_cast<QtNode*>(prevB + nodeCap);
-    QtNode* B = A + nodeCap;
-    int3* cuts = reinterpret_cast<int3*>(B + nodeCap);
-    int* va = reinterpret_cast<int*>(cuts + nodeCap);
-    int* vb = va + nodeCap;
-    int* part = vb + nodeCap;
-    __shared__ int sh_size, sh_prevCount, sh_state, sh_inB, sh_prevInB, sh_tstar;   // state: 0 full pass, 1 careful, 2 done
-
-    const int level = blockIdx.x, f = blockIdx.y;
-    const OrbLevelGeom& L = G.L[level];
+    int& sh_size = sh[0]; int& sh_prevCount = sh[1]; int& sh_state = sh[2]; int& sh_inB = sh[3];
+    int& sh_prevInB = sh[4]; int& sh_tstar = sh[5];
     const int tid = threadIdx.x, T = blockDim.x;
-    int n = candCount[f * ORB_MAX_LEVELS + level];
-    if (n > L.candCap) n = L.candCap;
-    int* outCount = &kpCount[f * ORB_MAX_LEVELS + level];
-    if (n == 0) {
-        if (tid == 0) *outCount = 0;
-        return;
-    }
-    unsigned long long* gk = cand + (size_t)f * candSlab + L.candBase;
-    unsigned long long* keys;
-    if (n <= sortCap) {
-        for (int i = tid; i < n; i += T) ldsKeys[i] = gk[i];
-        keys = ldsKeys;
-    } else {
-        keys = gk;                                     // rare: sort in place in global memory (L2)
-    }
     __syncthreads();
     qt_sort_u64(keys, n);
 
@@ -340,6 +314,44 @@ __global__ __launch_bounds__(256) void k_quadtree(const OrbGeom G, unsigned long
         out[i] = ((uint32_t)x << 20) | ((uint32_t)y << 8) | (uint32_t)(bestKey & 0xFF);
     }
     if (tid == 0) *outCount = size;
+}
+
+__global__ __launch_bounds__(256) void k_quadtree(const OrbGeom G, unsigned long long* __restrict__ cand,
+                                                  size_t candSlab, const int* __restrict__ candCount,
+                                                  uint32_t* __restrict__ kpl, int* __restrict__ kpCount,
+                                                  int* __restrict__ errFlags, int sortCap, int nodeCap)
+{
+    extern __shared__ unsigned long long qsm[];
+    // LDS carve-up: keys[sortCap] | prevA,prevB[nodeCap] (u64) | A,B[nodeCap] (QtNode) | cuts[nodeCap] (int3)
+    //               | va[nodeCap] | vb[nodeCap] (int) | part[257]
+    unsigned long long* ldsKeys = qsm;
+    unsigned long long* prevA = qsm + sortCap;
+    unsigned long long* prevB = prevA + nodeCap;
+    QtNode* A = reinterpret_cast<QtNode*>(prevB + nodeCap);
+    QtNode* B = A + nodeCap;
+    int3* cuts = reinterpret_cast<int3*>(B + nodeCap);
+    int* va = reinterpret_cast<int*>(cuts + nodeCap);
+    int* vb = va + nodeCap;
+    int* part = vb + nodeCap;
+    __shared__ int sh[8];                              // size, prevCount, state (0 full pass, 1 careful, 2 done), inB, prevInB, tstar
+
+    const int level = blockIdx.x, f = blockIdx.y;
+    const OrbLevelGeom& L = G.L[level];
+    const int tid = threadIdx.x, T = blockDim.x;
+    int n = candCount[f * ORB_MAX_LEVELS + level];
+    if (n > L.candCap) n = L.candCap;
+    int* outCount = &kpCount[f * ORB_MAX_LEVELS + level];
+    if (n == 0) {
+        if (tid == 0) *outCount = 0;
+        return;
+    }
+    unsigned long long* gk = cand + (size_t)f * candSlab + L.candBase;
+    if (n <= sortCap) {
+        for (int i = tid; i < n; i += T) ldsKeys[i] = gk[i];
+        qt_body(ldsKeys, n, G, L, f, prevA, prevB, A, B, cuts, va, vb, part, kpl, outCount, errFlags, sh);
+    } else {
+        qt_body(gk, n, G, L, f, prevA, prevB, A, B, cuts, va, vb, part, kpl, outCount, errFlags, sh);   // rare: sort in global memory
+    }
 }
 
 size_t orb_quadtree_lds_bytes(int sortCap, int nodeCap)
