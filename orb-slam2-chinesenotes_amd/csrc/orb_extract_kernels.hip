@@ -19,12 +19,15 @@
 // into its bordered buffer).  One thread per 16 output bytes.
 __global__ __launch_bounds__(256) void k_copy_level0(const uint8_t* __restrict__ src, size_t rowStride,
                                                      size_t frameStride, uint8_t* __restrict__ pyr,
-                                                     size_t pyrSlab, int w, int h, int pitch, int vec16)
+                                                     size_t pyrSlab, int w, int h, int pitch, int vec16, int x16n,
+                                                     unsigned invx)
 {
-    const int x16 = blockIdx.x * blockDim.x + threadIdx.x;   // 16-byte column
-    const int y = blockIdx.y;
-    const int f = blockIdx.z;
-    if (x16 * 16 >= w) return;
+    // flattened (row, 16-byte column) index: every lane of every wave has work (a 640-px row is only 40 columns)
+    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = blockIdx.y;
+    const int y = (int)(((unsigned long long)idx * invx) >> 32);
+    const int x16 = (int)idx - y * x16n;
+    if (y >= h) return;
     const uint8_t* s = src + (size_t)f * frameStride + (size_t)y * rowStride + (size_t)x16 * 16;
     uint8_t* d = pyr + (size_t)f * pyrSlab + (size_t)y * pitch + (size_t)x16 * 16;
     if (vec16 && x16 * 16 + 16 <= w) {
@@ -80,12 +83,14 @@ __global__ __launch_bounds__(256) void k_resize_level(uint8_t* __restrict__ pyr,
 __global__ __launch_bounds__(256) void k_resize_level4(uint8_t* __restrict__ pyr, size_t pyrSlab,
                                                        int srcOff, int srcPitch, int dstOff, int dstPitch,
                                                        int dw, int dh, const int2* __restrict__ xtab,
-                                                       const int2* __restrict__ ytab)
+                                                       const int2* __restrict__ ytab, int x4n, unsigned invx)
 {
-    const int x4 = blockIdx.x * 64 + threadIdx.x;
-    const int y = blockIdx.y * 4 + threadIdx.y;
-    const int f = blockIdx.z;
-    if (x4 * 4 >= dw || y >= dh) return;
+    // flattened (row, pixel quad) index so that every lane has work whatever the level width
+    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = blockIdx.y;
+    const int y = (int)(((unsigned long long)idx * invx) >> 32);
+    const int x4 = (int)idx - y * x4n;
+    if (y >= dh) return;
     const uint8_t* src = pyr + (size_t)f * pyrSlab + srcOff;
     uint8_t* dst = pyr + (size_t)f * pyrSlab + dstOff;
     const int2 ty = ytab[y];
@@ -116,13 +121,18 @@ __global__ __launch_bounds__(256) void k_resize_level4(uint8_t* __restrict__ pyr
 
 // ------------------------------------------------------------------------------------------------
 // launch wrappers (keep <<<>>> syntax inside this translation unit)
+// exact division of idx < 2^31 by d via multiply-high: q = (idx * ceil(2^32/d)) >> 32 is exact while idx*d < 2^32
+static unsigned inv32(int d) { return (unsigned)(((1ull << 32) + d - 1) / d); }
+
 void orb_launch_copy_level0(hipStream_t st, const uint8_t* src, size_t rowStride, size_t frameStride,
                             uint8_t* pyr, size_t pyrSlab, int w, int h, int pitch, int nFrames)
 {
     const int vec16 = ((reinterpret_cast<uintptr_t>(src) | rowStride | frameStride) & 15) == 0;
     const int x16 = (w + 15) / 16;
-    dim3 grid((x16 + 255) / 256, h, nFrames);
-    hipLaunchKernelGGL(k_copy_level0, grid, dim3(256), 0, st, src, rowStride, frameStride, pyr, pyrSlab, w, h, pitch, vec16);
+    const int total = x16 * h;
+    dim3 grid((total + 255) / 256, nFrames);
+    hipLaunchKernelGGL(k_copy_level0, grid, dim3(256), 0, st, src, rowStride, frameStride, pyr, pyrSlab, w, h, pitch, vec16,
+                       x16, inv32(x16));
 }
 
 void orb_launch_resize(hipStream_t st, uint8_t* pyr, size_t pyrSlab, const OrbLevelGeom& src,
@@ -130,11 +140,14 @@ void orb_launch_resize(hipStream_t st, uint8_t* pyr, size_t pyrSlab, const OrbLe
 {
     const int x4 = (dst.w + 3) / 4;
     dim3 grid((x4 + 63) / 64, (dst.h + 3) / 4, nFrames);
-    // window form needs sx(dx+3)+1 - (sx(dx) & ~3) <= 11, i.e. 3 + ceil(3*scale) + 1 <= 11
+    // window form needs sx(dx+3)+1 - (sx(dx) & ~3) <= 11, i.e. 3 + ceil(3*scale) + 1 <= 11; the flattened index
+    // decode (multiply-high) is exact while total * x4 < 2^32.  (An LDS-tiled variant was measured: no faster.)
     const double scale = (double)src.w / dst.w;
-    if (scale <= 2.2)
-        hipLaunchKernelGGL(k_resize_level4, grid, dim3(64, 4), 0, st, pyr, pyrSlab, src.pyrOff, src.pitch,
-                           dst.pyrOff, dst.pitch, dst.w, dst.h, xtab, ytab);
+    const long long total = (long long)x4 * dst.h;
+    if (scale <= 2.2 && total * x4 < (1ll << 32)) {
+        hipLaunchKernelGGL(k_resize_level4, dim3((unsigned)((total + 255) / 256), nFrames), dim3(256), 0, st, pyr, pyrSlab,
+                           src.pyrOff, src.pitch, dst.pyrOff, dst.pitch, dst.w, dst.h, xtab, ytab, x4, inv32(x4));
+    }
     else
         hipLaunchKernelGGL(k_resize_level, grid, dim3(64, 4), 0, st, pyr, pyrSlab, src.pyrOff, src.pitch,
                            dst.pyrOff, dst.pitch, dst.w, dst.h, xtab, ytab);
