@@ -247,6 +247,15 @@ int orb_match_bow_batch_device(orb_matcher* m, const orb_featstore* store,
 void* orb_matcher_stream(orb_matcher* m);
 int orb_matcher_wait_for(orb_matcher* m, void* hip_stream);
 
+/* replaces the arithmetic of void MapPoint::ComputeDistinctiveDescriptors(), reference src/MapPoint.cc:275-342, for
+ * a batch of MapPoints: the observed descriptors of point p are rows offsets[p] .. offsets[p+1] of desc
+ * (what :297-304 collects); best_idx[p] receives the index, inside that list, of the descriptor with the least
+ * median Hamming distance to the others (first minimum; -1 for an empty list).  <= 256 observations per point. */
+int orb_distinctive_descriptors(orb_matcher* m, const uint8_t* desc, const int32_t* offsets, int n_points,
+                                int32_t* best_idx);
+int orb_distinctive_descriptors_device(orb_matcher* m, const uint8_t* d_desc, const int32_t* d_offsets, int n_points,
+                                       int32_t* d_best_idx);
+
 /* ---------------------------------------------------------------- vocabulary tree -----------
  * The descriptor-touching part of DBoW2's TemplatedVocabulary::transform(features, BowVector&, FeatureVector&,
  * levelsup) as called by Frame::ComputeBoW (reference src/Frame.cc:425-433, levelsup = 4) and

@@ -141,6 +141,10 @@ struct VocabTree {
 };
 void vocabTransform(const VocabTree& t, const uint8_t* desc, int n, int levelsup, int32_t* wordOf, int32_t* nodeOf);
 
+// MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:275-342) for a batch of MapPoints: descriptors of point p
+// are rows offsets[p]..offsets[p+1] of desc; bestIdx[p] = index inside that list (-1 for an empty list).
+void distinctiveDescriptors(const uint8_t* desc, const int32_t* offsets, int nPoints, int32_t* bestIdx);
+
 // Synthetic stand-in for the (absent) ORB vocabulary: 2-level k=10 tree of 256-bit centroids
 // (SURVEY §8d).  nodeId = 11 + 10*c1 + c2.  centroids: 10 level-1 then 100 level-2, 32 B each.
 FeatVec bowTransform(const uint8_t* desc, int n, const uint8_t* centroids /*110 x 32*/);

@@ -225,6 +225,11 @@ void orbref_vocab_transform(const uint8_t* nodeDesc, const int32_t* childBegin, 
     vocabTransform(t, desc, n, levelsup, wordOf, nodeOf);
 }
 
+void orbref_distinctive(const uint8_t* desc, const int32_t* offsets, int nPoints, int32_t* bestIdx)
+{
+    distinctiveDescriptors(desc, offsets, nPoints, bestIdx);
+}
+
 // grid query exposed for the grid unit tests: returns count, indices in reference order
 int orbref_features_in_area(const KeyPoint* k, int n, float minX, float minY, float invW, float invH,
                             float x, float y, float r, int minLevel, int maxLevel, int32_t* out, int cap)

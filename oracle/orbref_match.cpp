@@ -416,3 +416,27 @@ void vocabTransform(const VocabTree& t, const uint8_t* desc, int n, int levelsup
 }
 
 }  // namespace orbref
+
+// ------------------------------------------------------------------ MapPoint::ComputeDistinctiveDescriptors
+// reference src/MapPoint.cc:275-342: among the N observed descriptors of a MapPoint pick the one whose MEDIAN Hamming
+// distance to all N (itself included, distance 0) is smallest; median = sorted[(int)(0.5*(N-1))]; first minimum wins.
+namespace orbref {
+
+void distinctiveDescriptors(const uint8_t* desc, const int32_t* offsets, int nPoints, int32_t* bestIdx)
+{
+    for (int p = 0; p < nPoints; p++) {
+        const int b = offsets[p], N = offsets[p + 1] - b;
+        if (N <= 0) { bestIdx[p] = -1; continue; }
+        int bestMedian = INT_MAX, best = 0;
+        std::vector<int> row(N);
+        for (int i = 0; i < N; i++) {
+            for (int j = 0; j < N; j++) row[j] = (i == j) ? 0 : hamming256(desc + 32 * (size_t)(b + i), desc + 32 * (size_t)(b + j));
+            std::sort(row.begin(), row.end());
+            const int median = row[(int)(0.5 * (N - 1))];
+            if (median < bestMedian) { bestMedian = median; best = i; }
+        }
+        bestIdx[p] = best;
+    }
+}
+
+}  // namespace orbref

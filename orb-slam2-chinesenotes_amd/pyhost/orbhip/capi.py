@@ -63,7 +63,7 @@ SYMBOLS = [
     "orb_get_level_counts", "orb_extractor_set_profiling", "orb_extractor_get_stage_ms", "orb_extractor_profiled_frames", "orb_extractor_stream",
     "orb_hamming", "orb_three_maxima", "orb_matcher_create", "orb_matcher_destroy", "orb_matcher_sync",
     "orb_match_bow", "orb_match_bow_kk", "orb_match_init", "orb_match_projection", "orb_vocab_create", "orb_vocab_destroy", "orb_vocab_level_nodes", "orb_bow_transform",
-    "orb_bow_transform_device", "orb_bow_assign_device", "orb_match_bow_batch_device",
+    "orb_bow_transform_device", "orb_distinctive_descriptors", "orb_distinctive_descriptors_device", "orb_bow_assign_device", "orb_match_bow_batch_device",
     "orb_matcher_stream", "orb_stereo_match", "orb_stereo_match_device", "orb_extractor_wait_for", "orb_matcher_wait_for", "orb_last_error", "orb_version",
 ]
 
@@ -118,6 +118,8 @@ def lib():
     L.orb_vocab_level_nodes.argtypes = [vp, ci]
     L.orb_bow_transform.argtypes = [vp, vp, vp, ci, ci, vp, vp]
     L.orb_bow_transform_device.argtypes = [vp, vp, vp, vp, ci, ci, ci, vp, vp, vp]
+    L.orb_distinctive_descriptors.argtypes = [vp, vp, vp, ci, vp]
+    L.orb_distinctive_descriptors_device.argtypes = [vp, vp, vp, ci, vp]
     L.orb_bow_assign_device.argtypes = [vp, vp, vp, ci, ci, vp, vp]
     L.orb_match_bow_batch_device.argtypes = [vp, C.POINTER(FeatStoreC), vp, vp, ci, cf, ci, vp, vp]
     L.orb_matcher_stream.argtypes = [vp]
@@ -352,6 +354,14 @@ class Matcher:
                                            _p(u_right), _p(occupied), n, _p(grid), self.nnratio, int(self.check_ori),
                                            _p(out), C.byref(nm)))
         return nm.value, out[:n]
+
+    def distinctive_descriptors(self, desc, offsets):
+        """MapPoint::ComputeDistinctiveDescriptors for a batch: desc rows offsets[p]:offsets[p+1] belong to point p."""
+        desc = np.ascontiguousarray(desc, np.uint8); offsets = np.ascontiguousarray(offsets, np.int32)
+        n = offsets.shape[0] - 1
+        out = np.zeros(max(n, 1), np.int32)
+        _check(self.L.orb_distinctive_descriptors(self.h, _p(desc), _p(offsets), n, _p(out)))
+        return out[:n]
 
     def bow_assign_device(self, d_desc, d_counts, n_frames, cap, d_centroids, d_node_of):
         _check(self.L.orb_bow_assign_device(self.h, C.c_void_p(d_desc), C.c_void_p(d_counts), n_frames, cap,

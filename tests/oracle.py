@@ -77,6 +77,7 @@ def lib():
         L.orbref_search_by_projection.argtypes = ([C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                                     C.c_void_p, C.c_void_p, C.c_int] + [C.c_float] * 5 + [C.c_int, C.c_void_p])
         L.orbref_vocab_transform.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.orbref_distinctive.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.orbref_features_in_area.restype = C.c_int
         L.orbref_features_in_area.argtypes = ([C.c_void_p, C.c_int] + [C.c_float] * 7 + [C.c_int] * 2 +
                                               [C.c_void_p, C.c_int])
@@ -320,3 +321,11 @@ def vocab_transform(tree, desc, levelsup=4):
     lib().orbref_vocab_transform(_p(tree["node_desc"]), _p(tree["child_begin"]), _p(tree["children"]), _p(tree["word_id"]),
                                  tree["node_desc"].shape[0], tree["L"], _p(desc), n, levelsup, _p(word), _p(node))
     return word[:n], node[:n]
+
+
+def distinctive_descriptors(desc, offsets):
+    desc = np.ascontiguousarray(desc, np.uint8); offsets = np.ascontiguousarray(offsets, np.int32)
+    n = offsets.shape[0] - 1
+    out = np.zeros(max(n, 1), np.int32)
+    lib().orbref_distinctive(_p(desc), _p(offsets), n, _p(out))
+    return out[:n]

@@ -276,3 +276,21 @@ def test_search_by_projection_edges(feats):
     wn, w = oracle.search_by_projection(0, q, qd, qa, kb, db, ur, occ, grid, 0.8, True)
     n, out = m.search_by_projection(0, q, qd, qa, kb, db, ur, occ, grid)
     assert n == wn and np.array_equal(out, w)
+
+
+def test_distinctive_descriptors_batch():
+    rng = np.random.default_rng(11)
+    sizes = [1, 2, 3, 4, 5, 8, 17, 33, 64, 65, 100, 200, 0, 7] + rng.integers(1, 40, 300).tolist()
+    offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    # observations of one MapPoint resemble each other: a base descriptor with a few flipped bits, so medians tie often
+    desc = np.zeros((offsets[-1], 32), np.uint8)
+    for p, n in enumerate(sizes):
+        base = rng.integers(0, 256, 32, dtype=np.uint8)
+        for i in range(n):
+            flips = np.zeros(256, np.uint8)
+            flips[rng.choice(256, rng.integers(0, 12), replace=False)] = 1
+            desc[offsets[p] + i] = base ^ np.packbits(flips)
+    want = oracle.distinctive_descriptors(desc, offsets)
+    got = capi.Matcher().distinctive_descriptors(desc, offsets)
+    assert np.array_equal(got, want)
+    assert want[12] == -1 and want[0] == 0
