@@ -139,8 +139,11 @@ __global__ __launch_bounds__(WAVE) void k_fast_cells(const OrbGeom G, const uint
         if (rp < rowsPerPass) {
             const uint8_t* src = img + (size_t)(cell.y0 + rp) * L.pitch + xa + 4 * c;
             const size_t step = (size_t)rowsPerPass * L.pitch;
-            for (int r = rp; r < cell.h; r += rowsPerPass, src += step)
-                tileDw[r * FT_PDW + c] = *reinterpret_cast<const uint32_t*>(src);
+            uint32_t* dstp = tileDw + rp * FT_PDW + c;
+            const int dstep = rowsPerPass * FT_PDW;
+#pragma unroll 4
+            for (int r = rp; r < cell.h; r += rowsPerPass, src += step, dstp += dstep)
+                *dstp = *reinterpret_cast<const uint32_t*>(src);
         }
     }
     const int zw = cell.w - 6, zh = cell.h - 6;                    // detection zone: tile rows [3,3+zh), cols [zLo,zHi)
@@ -163,13 +166,16 @@ __global__ __launch_bounds__(WAVE) void k_fast_cells(const OrbGeom G, const uint
     const int nItems = nq * zh;
     const unsigned invq = ((1u << 20) + nq - 1) / nq;
     int nA = 0, nB = 0;                                            // wave-uniform queue lengths
+    // item -> (zone row ry, quad qi) is advanced incrementally (64 items per step): no per-item division
+    int ry = (int)(((unsigned)lane * invq) >> 20);
+    int qi = lane - ry * nq;
+    const int stepR = WAVE / nq, stepQ = WAVE - stepR * nq;
     for (int base = 0; base < nItems; base += WAVE) {
         const int item = base + lane;
         bool pa = false, pb = false;
+        const int q = qLo + qi;
+        const int row = 3 + ry;
         if (item < nItems) {
-            const int ry = (int)(((unsigned)item * invq) >> 20);
-            const int q = qLo + item - ry * nq;
-            const int row = 3 + ry;
             const uint32_t* p = tileDw + row * FT_PDW + q - 1;
             const unsigned c0 = p[0], c1 = p[1], c2 = p[2];                                   // row y
             const unsigned u1 = p[-3 * FT_PDW + 1], d1 = p[3 * FT_PDW + 1];                   // rows y-3, y+3: x .. x+3
@@ -202,10 +208,14 @@ __global__ __launch_bounds__(WAVE) void k_fast_cells(const OrbGeom G, const uint
         }
         const unsigned long long ba = __ballot(pa), bb = __ballot(pb);
         const unsigned long long lt = (1ull << lane) - 1;
-        if (pa) pairQ[nA + __popcll(ba & lt)] = (uint16_t)item;
-        if (pb) pairQ[maxItems + nB + __popcll(bb & lt)] = (uint16_t)item;
+        const uint16_t ent = (uint16_t)((row << 8) | q);          // queue entries carry (row, quad) directly
+        if (pa) pairQ[nA + __popcll(ba & lt)] = ent;
+        if (pb) pairQ[maxItems + nB + __popcll(bb & lt)] = ent;
         nA += __popcll(ba);
         nB += __popcll(bb);
+        qi += stepQ;
+        ry += stepR;
+        if (qi >= nq) { qi -= nq; ry++; }
     }
     __syncthreads();
 
@@ -219,10 +229,8 @@ __global__ __launch_bounds__(WAVE) void k_fast_cells(const OrbGeom G, const uint
         for (int base = 0; base < nQ; base += WAVE, step++) {
             const int e = base + lane;
             if (e < nQ) {
-                const int item = Q[e];
-                const int ry = (int)(((unsigned)item * invq) >> 20);
-                const int q = qLo + item - ry * nq;
-                const int row = 3 + ry;
+                const int ent = Q[e];
+                const int row = ent >> 8, q = ent & 0xff;
                 unsigned W[7][3];
 #pragma unroll
                 for (int r = 0; r < 7; r++) {
@@ -270,10 +278,8 @@ __global__ __launch_bounds__(WAVE) void k_fast_cells(const OrbGeom G, const uint
             const int st = bit >> 1;
             const int h = st >= stepsA;
             const int e = (h ? st - stepsA : st) * WAVE + lane;
-            const int item = pairQ[(h ? maxItems : 0) + e];
-            const int ry = (int)(((unsigned)item * invq) >> 20);
-            const int q = qLo + item - ry * nq;
-            queue[w++] = (uint16_t)(((3 + ry) << 8) | (4 * q + 2 * h + (bit & 1)));
+            const int ent = pairQ[(h ? maxItems : 0) + e];
+            queue[w++] = (uint16_t)((ent & 0xff00) | (4 * (ent & 0xff) + 2 * h + (bit & 1)));
         }
     }
     __syncthreads();
