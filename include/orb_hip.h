@@ -204,18 +204,26 @@ typedef struct orb_proj_query {
     int32_t flags;
 } orb_proj_query;
 
-/* mode 0 replaces: int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, float th,
- *                  bool bMono), reference src/ORBmatcher.cc:160-300 (q_angle[i] = LastFrame.mvKeysUn[i].angle).
- * mode 1 replaces: int ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>&, float th),
- *                  reference src/ORBmatcher.cc:73-157 (ratio = mfNNratio; q_angle unused).
- * q_desc[i] is pMP->GetDescriptor().  kps_un/desc/u_right describe the current Frame (mvKeysUn, mDescriptors,
- * mvuRight); occupied[i] != 0 iff F.mvpMapPoints[i] && Observations() > 0 on entry; grid4 as for orb_match_init.
+/* mode 0 (best candidate, rotation histogram) replaces
+ *     int SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, float th, bool bMono)   src/ORBmatcher.cc:160-300
+ *         (max_dist = TH_HIGH = 100, q_angle[i] = LastFrame.mvKeysUn[i].angle)
+ *     int SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const set<MapPoint*>&, float th, int ORBdist)  :303-440
+ *         (max_dist = ORBdist, u_right = NULL, every assigned feature blocks: flags bit1 set, q_angle = pKF->mvKeysUn[i].angle)
+ *     int SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const vector<MapPoint*>&, vector<MapPoint*>& vpMatched, int th)
+ *         :443-550 (max_dist = TH_LOW = 50, check_ori = 0, occupied = vpMatched[idx] != NULL; KeyFrame::GetFeaturesInArea
+ *         src/KeyFrame.cc:637-676 + the level test of :520-521 == level range (level-1, level))
+ * mode 1 (best and second best with levels, ratio test) replaces
+ *     int SearchByProjection(Frame& F, const vector<MapPoint*>&, float th)                          src/ORBmatcher.cc:73-157
+ *         (ratio = mfNNratio, max_dist = TH_HIGH; q_angle unused).
+ * q_desc[i] is pMP->GetDescriptor().  kps_un/desc/u_right describe the searched Frame/KeyFrame (mvKeysUn,
+ * mDescriptors, mvuRight; u_right may be NULL = no stereo check); occupied[i] != 0 iff the feature already blocks
+ * (F.mvpMapPoints[i] && Observations() > 0 on entry, resp. != NULL); grid4 as for orb_match_init.
  * match_cur[i] receives the index of the query now assigned to feature i, -1 if the entry was not touched, and
  * (mode 0) -2 if the rotation filter reset it to NULL.  *nmatches is the reference's return value. */
 int orb_match_projection(orb_matcher* m, int mode, const orb_proj_query* queries, const uint8_t* q_desc,
                          const float* q_angle, int nq, const orb_keypoint* kps_un, const uint8_t* desc,
                          const float* u_right, const uint8_t* occupied, int n, const float* grid4, float ratio,
-                         int check_ori, int32_t* match_cur, int* nmatches);
+                         int max_dist, int check_ori, int32_t* match_cur, int* nmatches);
 
 /* Batched device-resident SearchByBoW: pair p matches keyframe kf_index[p] against frame
  * f_index[p] of a feature store that lives in HBM (the Relocalization candidate loop of

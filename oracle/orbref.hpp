@@ -125,10 +125,10 @@ struct ProjQuery {
 };
 int searchByProjectionMap(const ProjQuery* q, const uint8_t* qDesc, int nq, const KeyPoint* kps, const uint8_t* desc,
                           const float* uRight, const uint8_t* occupiedIn, int n, const FrameGrid& grid, float ratio,
-                          std::vector<int32_t>& matchCur);
+                          int maxDist, std::vector<int32_t>& matchCur);
 int searchByProjectionLast(const ProjQuery* q, const uint8_t* qDesc, const float* qAngle, int nq, const KeyPoint* kps,
                            const uint8_t* desc, const float* uRight, const uint8_t* occupiedIn, int n,
-                           const FrameGrid& grid, bool checkOri, std::vector<int32_t>& matchCur);
+                           const FrameGrid& grid, int maxDist, bool checkOri, std::vector<int32_t>& matchCur);
 
 // A DBoW2 vocabulary tree flattened to arrays (node 0 = root; children of node v = children[childBegin[v] ..
 // childBegin[v+1]) in stored order; wordId[v] >= 0 for leaves).

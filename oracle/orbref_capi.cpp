@@ -204,15 +204,15 @@ int orbref_search_for_init(const KeyPoint* k1, const uint8_t* d1, int n1,
 
 int orbref_search_by_projection(int mode, const ProjQuery* q, const uint8_t* qDesc, const float* qAngle, int nq,
                                 const KeyPoint* kps, const uint8_t* desc, const float* uRight, const uint8_t* occupied,
-                                int n, float minX, float minY, float invW, float invH, float ratio, int checkOri,
-                                int32_t* matchCur)
+                                int n, float minX, float minY, float invW, float invH, float ratio, int maxDist,
+                                int checkOri, int32_t* matchCur)
 {
     FrameGrid g;
     g.minX = minX; g.minY = minY; g.invW = invW; g.invH = invH;
     g.assign(kps, n);
     std::vector<int32_t> out;
-    const int nm = mode == 0 ? searchByProjectionLast(q, qDesc, qAngle, nq, kps, desc, uRight, occupied, n, g, checkOri != 0, out)
-                             : searchByProjectionMap(q, qDesc, nq, kps, desc, uRight, occupied, n, g, ratio, out);
+    const int nm = mode == 0 ? searchByProjectionLast(q, qDesc, qAngle, nq, kps, desc, uRight, occupied, n, g, maxDist, checkOri != 0, out)
+                             : searchByProjectionMap(q, qDesc, nq, kps, desc, uRight, occupied, n, g, ratio, maxDist, out);
     if (n) std::memcpy(matchCur, out.data(), (size_t)n * 4);
     return nm;
 }

@@ -305,7 +305,7 @@ static void bestTwo(const std::vector<int32_t>& cand, const KeyPoint* kps, const
     best = 256; best2 = 256; level = -1; level2 = -1; bestIdx = -1;
     for (int32_t idx : cand) {
         if (occupied[idx]) continue;                                   // mvpMapPoints[idx] && Observations()>0
-        if (uRight[idx] > 0) {
+        if (uRight && uRight[idx] > 0) {
             const float er = std::fabs(q.ur - uRight[idx]);
             if (er > q.erMax) continue;
         }
@@ -318,7 +318,7 @@ static void bestTwo(const std::vector<int32_t>& cand, const KeyPoint* kps, const
 // SearchByProjection(Frame&, const vector<MapPoint*>&, th)  src/ORBmatcher.cc:73-157.  matchCur[idx] = query index.
 int searchByProjectionMap(const ProjQuery* q, const uint8_t* qDesc, int nq, const KeyPoint* kps, const uint8_t* desc,
                           const float* uRight, const uint8_t* occupiedIn, int n, const FrameGrid& grid, float ratio,
-                          std::vector<int32_t>& matchCur)
+                          int maxDist, std::vector<int32_t>& matchCur)
 {
     matchCur.assign(n, -1);
     std::vector<uint8_t> occupied(occupiedIn, occupiedIn + n);
@@ -329,7 +329,7 @@ int searchByProjectionMap(const ProjQuery* q, const uint8_t* qDesc, int nq, cons
         if (cand.empty()) continue;
         int best, best2, level, level2, bestIdx;
         bestTwo(cand, kps, desc, uRight, occupied, q[i], qDesc + 32 * (size_t)i, best, best2, level, level2, bestIdx);
-        if (best <= 100) {                                             // TH_HIGH
+        if (best <= maxDist) {                                         // TH_HIGH
             if (level == level2 && (float)best > ratio * (float)best2) continue;
             matchCur[bestIdx] = i;
             occupied[bestIdx] = (q[i].flags & 2) ? 1 : 0;              // the new MapPoint's Observations()>0
@@ -343,7 +343,7 @@ int searchByProjectionMap(const ProjQuery* q, const uint8_t* qDesc, int nq, cons
 // matchCur[i2] = last-frame index, -2 = reset to NULL by the rotation filter, -1 = untouched.
 int searchByProjectionLast(const ProjQuery* q, const uint8_t* qDesc, const float* qAngle, int nq, const KeyPoint* kps,
                            const uint8_t* desc, const float* uRight, const uint8_t* occupiedIn, int n,
-                           const FrameGrid& grid, bool checkOri, std::vector<int32_t>& matchCur)
+                           const FrameGrid& grid, int maxDist, bool checkOri, std::vector<int32_t>& matchCur)
 {
     matchCur.assign(n, -1);
     std::vector<uint8_t> occupied(occupiedIn, occupiedIn + n);
@@ -356,14 +356,14 @@ int searchByProjectionLast(const ProjQuery* q, const uint8_t* qDesc, const float
         int best = 256, bestIdx = -1;
         for (int32_t i2 : cand) {
             if (occupied[i2]) continue;
-            if (uRight[i2] > 0) {
+            if (uRight && uRight[i2] > 0) {
                 const float er = std::fabs(q[i].ur - uRight[i2]);
                 if (er > q[i].erMax) continue;
             }
             const int d = hamming256(qDesc + 32 * (size_t)i, desc + 32 * (size_t)i2);
             if (d < best) { best = d; bestIdx = i2; }
         }
-        if (best <= 100) {
+        if (best <= maxDist) {                                         // TH_HIGH / ORBdist / TH_LOW
             matchCur[bestIdx] = i;
             occupied[bestIdx] = (q[i].flags & 2) ? 1 : 0;
             nmatches++;

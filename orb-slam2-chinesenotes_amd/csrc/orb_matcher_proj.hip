@@ -16,7 +16,6 @@
 #pragma clang fp contract(off)
 
 #define WAVE 64
-#define TH_HIGH 100
 #define HISTO_LENGTH 30
 
 struct ProjQuery {                 // == orb_proj_query
@@ -81,7 +80,7 @@ __global__ __launch_bounds__(WAVE) void k_proj_candidates(const ProjQuery* __res
                     const float dx = __fsub_rn(kp.x, x), dy = __fsub_rn(kp.y, y);
                     if (!(fabsf(dx) < r && fabsf(dy) < r)) pass = false;
                     if (pass) {
-                        const float ur2 = uRight[i2];
+                        const float ur2 = uRight ? uRight[i2] : -1.0f;
                         if (ur2 > 0 && fabsf(__fsub_rn(Q.ur, ur2)) > Q.erMax) pass = false;
                     }
                     if (pass) {
@@ -108,7 +107,8 @@ __global__ __launch_bounds__(WAVE) void k_proj_resolve(int mode, const ProjQuery
                                                        const float* __restrict__ qAngle, int nq,
                                                        const orb_keypoint* __restrict__ kps, int n,
                                                        const uint32_t* __restrict__ candList, int stride,
-                                                       const int* __restrict__ candCount, float ratio, int checkOri,
+                                                       const int* __restrict__ candCount, float ratio, int maxDist,
+                                                       int checkOri,
                                                        uint8_t* __restrict__ occupied /*in/out copy*/,
                                                        int32_t* __restrict__ matchCur,
                                                        uint32_t* __restrict__ events /*[nq] bin<<16|idx*/,
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(WAVE) void k_proj_resolve(int mode, const ProjQuery
         if (b1 == 0xFFFFFFFFu) continue;
         const int best = (int)(b1 >> 16);
         const int bestIdx = (int)(list[b1 & 0xFFFFu] >> 16);
-        if (best > TH_HIGH) continue;
+        if (best > maxDist) continue;                             // TH_HIGH (:136, :258), ORBdist (:379), TH_LOW (:493)
         if (mode == 1) {
             const int best2 = (b2 == 0xFFFFFFFFu) ? 256 : (int)(b2 >> 16);
             const int level = kps[bestIdx].octave;
@@ -197,14 +197,14 @@ __global__ __launch_bounds__(WAVE) void k_proj_resolve(int mode, const ProjQuery
 extern "C" int orb_match_projection(orb_matcher* m, int mode, const orb_proj_query* queries, const uint8_t* q_desc,
                                     const float* q_angle, int nq, const orb_keypoint* kps_un, const uint8_t* desc,
                                     const float* u_right, const uint8_t* occupied, int n, const float* grid4, float ratio,
-                                    int check_ori, int32_t* match_cur, int* nmatches)
+                                    int max_dist, int check_ori, int32_t* match_cur, int* nmatches)
 {
     if (!m || (mode != 0 && mode != 1) || nq < 0 || n < 0 || !nmatches || !grid4) return ORB_ERR_INVALID;
     *nmatches = 0;
     if (n > 0 && !match_cur) return ORB_ERR_INVALID;
     for (int i = 0; i < n; i++) match_cur[i] = -1;
     if (nq == 0 || n == 0) return ORB_OK;
-    if (!queries || !q_desc || !kps_un || !desc || !u_right || !occupied || (mode == 0 && check_ori && !q_angle))
+    if (!queries || !q_desc || !kps_un || !desc || !occupied || (mode == 0 && check_ori && !q_angle))
         return ORB_ERR_INVALID;
     if (nq > 65535 || n > 65535) return ORB_ERR_UNSUPPORTED;
     ORB_HIP_TRY(hipSetDevice(m->device));
@@ -235,14 +235,14 @@ extern "C" int orb_match_projection(orb_matcher* m, int mode, const orb_proj_que
     if (q_angle) ORB_HIP_TRY(hipMemcpyAsync(dQA, q_angle, sz[2], hipMemcpyHostToDevice, st));
     ORB_HIP_TRY(hipMemcpyAsync(dK, kps_un, sz[3], hipMemcpyHostToDevice, st));
     ORB_HIP_TRY(hipMemcpyAsync(dD, desc, sz[4], hipMemcpyHostToDevice, st));
-    ORB_HIP_TRY(hipMemcpyAsync(dUR, u_right, sz[5], hipMemcpyHostToDevice, st));
+    if (u_right) ORB_HIP_TRY(hipMemcpyAsync(dUR, u_right, sz[5], hipMemcpyHostToDevice, st));
     ORB_HIP_TRY(hipMemcpyAsync(dOcc, occupied, sz[6], hipMemcpyHostToDevice, st));
     InitGrid g = {grid4[0], grid4[1], grid4[2], grid4[3]};
     hipLaunchKernelGGL(k_init_grid, dim3(1), dim3(256), 0, st, dK, n, g, 0, dKeys, dNKeys);
-    hipLaunchKernelGGL(k_proj_candidates, dim3(nq), dim3(WAVE), 0, st, dQ, dQD, nq, dK, dD, dUR, dKeys, dNKeys, g, dCand, n,
+    hipLaunchKernelGGL(k_proj_candidates, dim3(nq), dim3(WAVE), 0, st, dQ, dQD, nq, dK, dD, u_right ? dUR : (const float*)nullptr, dKeys, dNKeys, g, dCand, n,
                        dCandCount);
     hipLaunchKernelGGL(k_proj_resolve, dim3(1), dim3(WAVE), 0, st, mode, dQ, dQA, nq, dK, n, dCand, n, dCandCount, ratio,
-                       check_ori, dOcc, dMatch, dEvents, dNm);
+                       max_dist, check_ori, dOcc, dMatch, dEvents, dNm);
     ORB_HIP_TRY(hipGetLastError());
     std::vector<int32_t> host((size_t)n + 1);
     ORB_HIP_TRY(hipMemcpyAsync(host.data(), dMatch, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost, st));

@@ -111,7 +111,7 @@ def lib():
     L.orb_match_bow_kk.argtypes = [vp, vp, vp, vp, ci, C.POINTER(FeatVecC), vp, vp, vp, ci, C.POINTER(FeatVecC), cf, ci,
                                    vp, C.POINTER(ci)]
     L.orb_match_init.argtypes = [vp, vp, vp, ci, vp, vp, ci, vp, vp, ci, cf, ci, vp, C.POINTER(ci)]
-    L.orb_match_projection.argtypes = [vp, ci, vp, vp, vp, ci, vp, vp, vp, vp, ci, vp, cf, ci, vp, C.POINTER(ci)]
+    L.orb_match_projection.argtypes = [vp, ci, vp, vp, vp, ci, vp, vp, vp, vp, ci, vp, cf, ci, ci, vp, C.POINTER(ci)]
     L.orb_vocab_create.argtypes = [ci, vp, vp, vp, vp, ci, ci, C.POINTER(vp)]
     L.orb_vocab_destroy.argtypes = [vp]
     L.orb_vocab_destroy.restype = None
@@ -340,19 +340,20 @@ class Matcher:
                                      self.nnratio, int(self.check_ori), _p(out), C.byref(nm)))
         return nm.value, out[:n1]
 
-    def search_by_projection(self, mode, q, q_desc, q_angle, kps_un, desc, u_right, occupied, grid):
+    def search_by_projection(self, mode, q, q_desc, q_angle, kps_un, desc, u_right, occupied, grid, max_dist=100):
         """mode 0: SearchByProjection(CurrentFrame, LastFrame, ...); mode 1: SearchByProjection(Frame, MapPoints, ...)."""
         q = np.ascontiguousarray(q, PROJ_DTYPE); q_desc = np.ascontiguousarray(q_desc, np.uint8)
         q_angle = np.ascontiguousarray(q_angle, np.float32)
         kps_un = np.ascontiguousarray(kps_un); desc = np.ascontiguousarray(desc, np.uint8)
-        u_right = np.ascontiguousarray(u_right, np.float32); occupied = np.ascontiguousarray(occupied, np.uint8)
+        u_right = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+        occupied = np.ascontiguousarray(occupied, np.uint8)
         grid = np.ascontiguousarray(grid, np.float32)
         n = kps_un.shape[0]
         out = np.full(max(n, 1), -1, np.int32)
         nm = C.c_int(0)
         _check(self.L.orb_match_projection(self.h, mode, _p(q), _p(q_desc), _p(q_angle), q.shape[0], _p(kps_un), _p(desc),
-                                           _p(u_right), _p(occupied), n, _p(grid), self.nnratio, int(self.check_ori),
-                                           _p(out), C.byref(nm)))
+                                           _p(u_right), _p(occupied), n, _p(grid), self.nnratio, int(max_dist),
+                                           int(self.check_ori), _p(out), C.byref(nm)))
         return nm.value, out[:n]
 
     def distinctive_descriptors(self, desc, offsets):

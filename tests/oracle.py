@@ -75,7 +75,7 @@ def lib():
                                     C.c_float, C.c_float, C.c_void_p, C.c_void_p]
         L.orbref_search_by_projection.restype = C.c_int
         L.orbref_search_by_projection.argtypes = ([C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
-                                                    C.c_void_p, C.c_void_p, C.c_int] + [C.c_float] * 5 + [C.c_int, C.c_void_p])
+                                                    C.c_void_p, C.c_void_p, C.c_int] + [C.c_float] * 5 + [C.c_int, C.c_int, C.c_void_p])
         L.orbref_vocab_transform.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.orbref_distinctive.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.orbref_features_in_area.restype = C.c_int
@@ -85,7 +85,7 @@ def lib():
 
 
 def _p(a):
-    return a.ctypes.data_as(C.c_void_p)
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
 class FeatVec:
@@ -299,16 +299,18 @@ PROJ_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("r", "<f4"), ("min_level", "
                        ("ur", "<f4"), ("er_max", "<f4"), ("flags", "<i4")])
 
 
-def search_by_projection(mode, q, q_desc, q_angle, kps, desc, u_right, occupied, grid, ratio=0.8, check_ori=True):
+def search_by_projection(mode, q, q_desc, q_angle, kps, desc, u_right, occupied, grid, ratio=0.8, check_ori=True, max_dist=100):
     """mode 0: SearchByProjection(CurrentFrame, LastFrame, ...); mode 1: SearchByProjection(Frame, MapPoints, ...)."""
     q = np.ascontiguousarray(q, PROJ_DTYPE); q_desc = np.ascontiguousarray(q_desc, np.uint8)
     q_angle = np.ascontiguousarray(q_angle, np.float32)
     kps = np.ascontiguousarray(kps); desc = np.ascontiguousarray(desc, np.uint8)
-    u_right = np.ascontiguousarray(u_right, np.float32); occupied = np.ascontiguousarray(occupied, np.uint8)
+    u_right = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+    occupied = np.ascontiguousarray(occupied, np.uint8)
     n = kps.shape[0]
     out = np.full(max(n, 1), -1, np.int32)
     nm = lib().orbref_search_by_projection(mode, _p(q), _p(q_desc), _p(q_angle), q.shape[0], _p(kps), _p(desc), _p(u_right),
-                                           _p(occupied), n, *[float(g) for g in grid], ratio, int(check_ori), _p(out))
+                                           _p(occupied), n, *[float(g) for g in grid], ratio, int(max_dist), int(check_ori),
+                                           _p(out))
     return nm, out[:n]
 
 

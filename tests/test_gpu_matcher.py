@@ -294,3 +294,19 @@ def test_distinctive_descriptors_batch():
     got = capi.Matcher().distinctive_descriptors(desc, offsets)
     assert np.array_equal(got, want)
     assert want[12] == -1 and want[0] == 0
+
+
+@pytest.mark.parametrize("max_dist,ori", [(64, True), (50, False)])
+def test_search_by_projection_reloc_and_loop_variants(feats, max_dist, ori):
+    """SearchByProjection(Frame, KeyFrame, set, th, ORBdist) (:303-440) and SearchByProjection(KeyFrame, Scw, ...) (:443-550):
+    mode 0 with another distance threshold, no stereo check, every assigned feature blocks."""
+    grid = (0.0, 0.0, 0.1, 0.1)
+    m = capi.Matcher(0.8, ori)
+    for a, b, seed in [(0, 1, 21), (2, 1, 22)]:
+        q, qd, qa, kb, db, ur, occ = _proj_scene(feats, a, b, 0, "neither", seed)
+        q["flags"] |= 2
+        q["er_max"] = np.float32(np.inf)
+        want_n, want = oracle.search_by_projection(0, q, qd, qa, kb, db, None, occ, grid, 0.8, ori, max_dist)
+        got_n, got = m.search_by_projection(0, q, qd, qa, kb, db, None, occ, grid, max_dist)
+        assert want_n > 50
+        assert got_n == want_n and np.array_equal(got, want)
