@@ -225,6 +225,21 @@ int orb_match_projection(orb_matcher* m, int mode, const orb_proj_query* queries
                          const float* u_right, const uint8_t* occupied, int n, const float* grid4, float ratio,
                          int max_dist, int check_ori, int32_t* match_cur, int* nmatches);
 
+/* Independent best candidate per projected point (no state carried between points): the search loops of
+ *     int ORBmatcher::Fuse(KeyFrame*, const vector<MapPoint*>&, float th)                src/ORBmatcher.cc:1364-1480
+ *         (chi2 = 1: reprojection gate e2*mvInvLevelSigma2[level] > 5.99 resp. 7.8 when mvuRight >= 0, :1401-1426;
+ *          max_dist = TH_LOW; level range (level-1, level); the Replace/AddObservation surgery stays on the host)
+ *     int ORBmatcher::Fuse(KeyFrame*, cv::Mat Scw, const vector<MapPoint*>&, float th, vector<MapPoint*>&)  :1483-1633
+ *         (chi2 = 0, max_dist = TH_LOW)
+ *     int ORBmatcher::SearchBySim3(KeyFrame*, KeyFrame*, vector<MapPoint*>&, s12, R12, t12, th)  :835-1025
+ *         (two calls, one per direction, max_dist = TH_HIGH; the mutual-consistency loop :1008-1022 stays on the host)
+ * best_idx[i] = feature index in the searched KeyFrame or -1; best_dist[i] (optional) = its distance (256 = no
+ * candidate).  With chi2 = 0 the stereo check of orb_match_projection applies (disable it with er_max = +inf). */
+int orb_match_projection_best(orb_matcher* m, const orb_proj_query* queries, const uint8_t* q_desc, int nq,
+                              const orb_keypoint* kps_un, const uint8_t* desc, const float* u_right, int n,
+                              const float* grid4, int max_dist, int chi2, const float* inv_level_sigma2, int n_levels,
+                              int32_t* best_idx, int32_t* best_dist);
+
 /* Batched device-resident SearchByBoW: pair p matches keyframe kf_index[p] against frame
  * f_index[p] of a feature store that lives in HBM (the Relocalization candidate loop of
  * reference src/Tracking.cc:1471-1492 is the batch axis).  See orb_featstore below. */

@@ -130,6 +130,10 @@ int searchByProjectionLast(const ProjQuery* q, const uint8_t* qDesc, const float
                            const uint8_t* desc, const float* uRight, const uint8_t* occupiedIn, int n,
                            const FrameGrid& grid, int maxDist, bool checkOri, std::vector<int32_t>& matchCur);
 
+void searchByProjectionBest(const ProjQuery* q, const uint8_t* qDesc, int nq, const KeyPoint* kps, const uint8_t* desc,
+                            const float* uRight, int n, const FrameGrid& grid, int maxDist, bool chi2,
+                            const float* invSigma2, int32_t* bestIdx, int32_t* bestDist);
+
 // A DBoW2 vocabulary tree flattened to arrays (node 0 = root; children of node v = children[childBegin[v] ..
 // childBegin[v+1]) in stored order; wordId[v] >= 0 for leaves).
 struct VocabTree {

@@ -230,6 +230,17 @@ void orbref_distinctive(const uint8_t* desc, const int32_t* offsets, int nPoints
     distinctiveDescriptors(desc, offsets, nPoints, bestIdx);
 }
 
+void orbref_search_by_projection_best(const ProjQuery* q, const uint8_t* qDesc, int nq, const KeyPoint* kps,
+                                      const uint8_t* desc, const float* uRight, int n, float minX, float minY, float invW,
+                                      float invH, int maxDist, int chi2, const float* invSigma2, int32_t* bestIdx,
+                                      int32_t* bestDist)
+{
+    FrameGrid g;
+    g.minX = minX; g.minY = minY; g.invW = invW; g.invH = invH;
+    g.assign(kps, n);
+    searchByProjectionBest(q, qDesc, nq, kps, desc, uRight, n, g, maxDist, chi2 != 0, invSigma2, bestIdx, bestDist);
+}
+
 // grid query exposed for the grid unit tests: returns count, indices in reference order
 int orbref_features_in_area(const KeyPoint* k, int n, float minX, float minY, float invW, float invH,
                             float x, float y, float r, int minLevel, int maxLevel, int32_t* out, int cap)

@@ -440,3 +440,45 @@ void distinctiveDescriptors(const uint8_t* desc, const int32_t* offsets, int nPo
 }
 
 }  // namespace orbref
+
+// ------------------------------------------------------------------ independent best candidate per projected point
+// The search loops of ORBmatcher::Fuse (src/ORBmatcher.cc:1386-1432, with the chi-square reprojection gate, and
+// :1570-1600 without) and of ORBmatcher::SearchBySim3 (:905-932, :975-1002): window query, level range, first
+// minimum; no state is carried between points.
+namespace orbref {
+
+void searchByProjectionBest(const ProjQuery* q, const uint8_t* qDesc, int nq, const KeyPoint* kps, const uint8_t* desc,
+                            const float* uRight, int /*n*/, const FrameGrid& grid, int maxDist, bool chi2,
+                            const float* invSigma2, int32_t* bestIdx, int32_t* bestDist)
+{
+    for (int i = 0; i < nq; i++) {
+        bestIdx[i] = -1;
+        if (bestDist) bestDist[i] = 256;
+        if (!(q[i].flags & 1)) continue;
+        std::vector<int32_t> cand = grid.inArea(kps, q[i].x, q[i].y, q[i].r, q[i].minLevel, q[i].maxLevel);
+        int best = INT_MAX, idxBest = -1;
+        for (int32_t idx : cand) {
+            const KeyPoint& kp = kps[idx];
+            if (chi2) {
+                const float u = q[i].x, v = q[i].y;
+                if (uRight && uRight[idx] >= 0) {
+                    const float ex = u - kp.x, ey = v - kp.y, er = q[i].ur - uRight[idx];
+                    const float e2 = ex * ex + ey * ey + er * er;
+                    if (e2 * invSigma2[kp.octave] > 7.8) continue;
+                } else {
+                    const float ex = u - kp.x, ey = v - kp.y;
+                    const float e2 = ex * ex + ey * ey;
+                    if (e2 * invSigma2[kp.octave] > 5.99) continue;
+                }
+            } else if (uRight && uRight[idx] > 0) {
+                if (std::fabs(q[i].ur - uRight[idx]) > q[i].erMax) continue;
+            }
+            const int d = hamming256(qDesc + 32 * (size_t)i, desc + 32 * (size_t)idx);
+            if (d < best) { best = d; idxBest = idx; }
+        }
+        if (idxBest >= 0 && bestDist) bestDist[i] = best;
+        if (idxBest >= 0 && best <= maxDist) bestIdx[i] = idxBest;
+    }
+}
+
+}  // namespace orbref

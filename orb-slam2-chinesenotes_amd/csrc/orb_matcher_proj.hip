@@ -18,6 +18,8 @@
 #define WAVE 64
 #define HISTO_LENGTH 30
 
+struct Sigma2Tab { float inv[16]; };   // mvInvLevelSigma2 of the searched KeyFrame
+
 struct ProjQuery {                 // == orb_proj_query
     float x, y, r;
     int32_t minLevel, maxLevel;
@@ -44,7 +46,7 @@ __global__ __launch_bounds__(WAVE) void k_proj_candidates(const ProjQuery* __res
                                                           const uint32_t* __restrict__ keys,
                                                           const int* __restrict__ nKeysPtr, InitGrid g,
                                                           uint32_t* __restrict__ candList, int stride,
-                                                          int* __restrict__ candCount)
+                                                          int* __restrict__ candCount, int chi2, Sigma2Tab sig)
 {
     const int i = blockIdx.x, lane = threadIdx.x;
     if (i >= nq) return;
@@ -81,7 +83,19 @@ __global__ __launch_bounds__(WAVE) void k_proj_candidates(const ProjQuery* __res
                     if (!(fabsf(dx) < r && fabsf(dy) < r)) pass = false;
                     if (pass) {
                         const float ur2 = uRight ? uRight[i2] : -1.0f;
-                        if (ur2 > 0 && fabsf(__fsub_rn(Q.ur, ur2)) > Q.erMax) pass = false;
+                        if (!chi2) {
+                            if (ur2 > 0 && fabsf(__fsub_rn(Q.ur, ur2)) > Q.erMax) pass = false;
+                        } else {
+                            // reprojection-error gate of ORBmatcher::Fuse (:1401-1426): chi-square 3 dof / 2 dof
+                            const float ex = __fsub_rn(x, kp.x), ey = __fsub_rn(y, kp.y);
+                            float e2 = __fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey));
+                            const float is2 = sig.inv[min(max(kp.octave, 0), 15)];
+                            if (ur2 >= 0) {
+                                const float er = __fsub_rn(Q.ur, ur2);
+                                e2 = __fadd_rn(e2, __fmul_rn(er, er));
+                                if ((double)__fmul_rn(e2, is2) > 7.8) pass = false;
+                            } else if ((double)__fmul_rn(e2, is2) > 5.99) pass = false;
+                        }
                     }
                     if (pass) {
                         uint32_t d2[8];
@@ -194,6 +208,88 @@ __global__ __launch_bounds__(WAVE) void k_proj_resolve(int mode, const ProjQuery
     if (lane == 0) *nmatchesOut = nmatches;
 }
 
+// independent best candidate per query (no assignment state): the search loops of ORBmatcher::Fuse x2 and of
+// ORBmatcher::SearchBySim3 (first minimum wins, `dist < bestDist`)
+__global__ __launch_bounds__(WAVE) void k_proj_best(const uint32_t* __restrict__ candList, int stride,
+                                                    const int* __restrict__ candCount, int nq, int maxDist,
+                                                    int32_t* __restrict__ bestIdx, int32_t* __restrict__ bestDist)
+{
+    const int i = blockIdx.x, lane = threadIdx.x;
+    if (i >= nq) return;
+    const int nc = candCount[i];
+    const uint32_t* list = candList + (size_t)i * stride;
+    unsigned b1 = 0xFFFFFFFFu;
+    for (int base = 0; base < nc; base += WAVE) {
+        const int p = base + lane;
+        unsigned mine = 0xFFFFFFFFu;
+        if (p < nc) mine = ((list[p] & 0xFFFFu) << 16) | (unsigned)p;
+        b1 = min(b1, pj_umin_dpp(mine));
+    }
+    if (lane == 0) {
+        const bool ok = b1 != 0xFFFFFFFFu && (int)(b1 >> 16) <= maxDist;
+        bestIdx[i] = ok ? (int32_t)(list[b1 & 0xFFFFu] >> 16) : -1;
+        if (bestDist) bestDist[i] = (b1 == 0xFFFFFFFFu) ? 256 : (int32_t)(b1 >> 16);
+    }
+}
+
+static int proj_common(orb_matcher* m, const orb_proj_query* queries, const uint8_t* q_desc, const float* q_angle, int nq,
+                       const orb_keypoint* kps_un, const uint8_t* desc, const float* u_right, const uint8_t* occupied,
+                       int n, const float* grid4, int chi2, const float* inv_sigma2, int n_levels, MBuf* buf)
+{
+    const size_t sz[12] = {sizeof(ProjQuery) * (size_t)nq, (size_t)32 * nq, (size_t)4 * nq, sizeof(orb_keypoint) * (size_t)n,
+                           (size_t)32 * n, (size_t)4 * n, (size_t)n, (size_t)4 * n + 4, (size_t)4 * nq * n, (size_t)4 * nq,
+                           (size_t)4 * std::max(n, nq) + 4, (size_t)4 * nq};
+    int rc;
+    for (int i = 0; i < 12; i++)
+        if ((rc = buf[i].ensure(sz[i])) != ORB_OK) return rc;
+    hipStream_t st = m->stream;
+    ORB_HIP_TRY(hipMemcpyAsync(buf[0].p, queries, sz[0], hipMemcpyHostToDevice, st));
+    ORB_HIP_TRY(hipMemcpyAsync(buf[1].p, q_desc, sz[1], hipMemcpyHostToDevice, st));
+    if (q_angle) ORB_HIP_TRY(hipMemcpyAsync(buf[2].p, q_angle, sz[2], hipMemcpyHostToDevice, st));
+    ORB_HIP_TRY(hipMemcpyAsync(buf[3].p, kps_un, sz[3], hipMemcpyHostToDevice, st));
+    ORB_HIP_TRY(hipMemcpyAsync(buf[4].p, desc, sz[4], hipMemcpyHostToDevice, st));
+    if (u_right) ORB_HIP_TRY(hipMemcpyAsync(buf[5].p, u_right, sz[5], hipMemcpyHostToDevice, st));
+    if (occupied) ORB_HIP_TRY(hipMemcpyAsync(buf[6].p, occupied, sz[6], hipMemcpyHostToDevice, st));
+    InitGrid g = {grid4[0], grid4[1], grid4[2], grid4[3]};
+    Sigma2Tab sig;
+    for (int i = 0; i < 16; i++) sig.inv[i] = (inv_sigma2 && i < n_levels) ? inv_sigma2[i] : 1.0f;
+    uint32_t* dKeys = (uint32_t*)buf[7].p;
+    int* dNKeys = (int*)((uint8_t*)buf[7].p + (size_t)4 * n);
+    hipLaunchKernelGGL(k_init_grid, dim3(1), dim3(256), 0, st, (const orb_keypoint*)buf[3].p, n, g, 0, dKeys, dNKeys);
+    hipLaunchKernelGGL(k_proj_candidates, dim3(nq), dim3(WAVE), 0, st, (const ProjQuery*)buf[0].p, (const uint8_t*)buf[1].p, nq,
+                       (const orb_keypoint*)buf[3].p, (const uint8_t*)buf[4].p, u_right ? (const float*)buf[5].p : nullptr, dKeys,
+                       dNKeys, g, (uint32_t*)buf[8].p, n, (int*)buf[9].p, chi2, sig);
+    return ORB_OK;
+}
+
+extern "C" int orb_match_projection_best(orb_matcher* m, const orb_proj_query* queries, const uint8_t* q_desc, int nq,
+                                         const orb_keypoint* kps_un, const uint8_t* desc, const float* u_right, int n,
+                                         const float* grid4, int max_dist, int chi2, const float* inv_level_sigma2,
+                                         int n_levels, int32_t* best_idx, int32_t* best_dist)
+{
+    if (!m || nq < 0 || n < 0 || !grid4) return ORB_ERR_INVALID;
+    if (nq > 0 && !best_idx) return ORB_ERR_INVALID;
+    for (int i = 0; i < nq; i++) { best_idx[i] = -1; if (best_dist) best_dist[i] = 256; }
+    if (nq == 0 || n == 0) return ORB_OK;
+    if (!queries || !q_desc || !kps_un || !desc || (chi2 && !inv_level_sigma2)) return ORB_ERR_INVALID;
+    if (nq > 65535 || n > 65535 || n_levels > 16) return ORB_ERR_UNSUPPORTED;
+    ORB_HIP_TRY(hipSetDevice(m->device));
+    MBuf* buf = m->init;
+    int rc = proj_common(m, queries, q_desc, nullptr, nq, kps_un, desc, u_right, nullptr, n, grid4, chi2, inv_level_sigma2,
+                         n_levels, buf);
+    if (rc != ORB_OK) return rc;
+    hipStream_t st = m->stream;
+    int32_t* dBest = (int32_t*)buf[10].p;
+    int32_t* dDist = (int32_t*)buf[11].p;
+    hipLaunchKernelGGL(k_proj_best, dim3(nq), dim3(WAVE), 0, st, (const uint32_t*)buf[8].p, n, (const int*)buf[9].p, nq, max_dist,
+                       dBest, dDist);
+    ORB_HIP_TRY(hipGetLastError());
+    ORB_HIP_TRY(hipMemcpyAsync(best_idx, dBest, (size_t)4 * nq, hipMemcpyDeviceToHost, st));
+    if (best_dist) ORB_HIP_TRY(hipMemcpyAsync(best_dist, dDist, (size_t)4 * nq, hipMemcpyDeviceToHost, st));
+    ORB_HIP_TRY(hipStreamSynchronize(st));
+    return ORB_OK;
+}
+
 extern "C" int orb_match_projection(orb_matcher* m, int mode, const orb_proj_query* queries, const uint8_t* q_desc,
                                     const float* q_angle, int nq, const orb_keypoint* kps_un, const uint8_t* desc,
                                     const float* u_right, const uint8_t* occupied, int n, const float* grid4, float ratio,
@@ -240,7 +336,7 @@ extern "C" int orb_match_projection(orb_matcher* m, int mode, const orb_proj_que
     InitGrid g = {grid4[0], grid4[1], grid4[2], grid4[3]};
     hipLaunchKernelGGL(k_init_grid, dim3(1), dim3(256), 0, st, dK, n, g, 0, dKeys, dNKeys);
     hipLaunchKernelGGL(k_proj_candidates, dim3(nq), dim3(WAVE), 0, st, dQ, dQD, nq, dK, dD, u_right ? dUR : (const float*)nullptr, dKeys, dNKeys, g, dCand, n,
-                       dCandCount);
+                       dCandCount, 0, Sigma2Tab{});
     hipLaunchKernelGGL(k_proj_resolve, dim3(1), dim3(WAVE), 0, st, mode, dQ, dQA, nq, dK, n, dCand, n, dCandCount, ratio,
                        max_dist, check_ori, dOcc, dMatch, dEvents, dNm);
     ORB_HIP_TRY(hipGetLastError());

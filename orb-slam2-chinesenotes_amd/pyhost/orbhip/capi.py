@@ -62,7 +62,7 @@ SYMBOLS = [
     "orb_extract_batch", "orb_extract_batch_device", "orb_extractor_sync", "orb_get_pyramid_level",
     "orb_get_level_counts", "orb_extractor_set_profiling", "orb_extractor_get_stage_ms", "orb_extractor_profiled_frames", "orb_extractor_stream",
     "orb_hamming", "orb_three_maxima", "orb_matcher_create", "orb_matcher_destroy", "orb_matcher_sync",
-    "orb_match_bow", "orb_match_bow_kk", "orb_match_init", "orb_match_projection", "orb_vocab_create", "orb_vocab_destroy", "orb_vocab_level_nodes", "orb_bow_transform",
+    "orb_match_bow", "orb_match_bow_kk", "orb_match_init", "orb_match_projection", "orb_match_projection_best", "orb_vocab_create", "orb_vocab_destroy", "orb_vocab_level_nodes", "orb_bow_transform",
     "orb_bow_transform_device", "orb_distinctive_descriptors", "orb_distinctive_descriptors_device", "orb_bow_assign_device", "orb_match_bow_batch_device",
     "orb_matcher_stream", "orb_stereo_match", "orb_stereo_match_device", "orb_extractor_wait_for", "orb_matcher_wait_for", "orb_last_error", "orb_version",
 ]
@@ -112,6 +112,7 @@ def lib():
                                    vp, C.POINTER(ci)]
     L.orb_match_init.argtypes = [vp, vp, vp, ci, vp, vp, ci, vp, vp, ci, cf, ci, vp, C.POINTER(ci)]
     L.orb_match_projection.argtypes = [vp, ci, vp, vp, vp, ci, vp, vp, vp, vp, ci, vp, cf, ci, ci, vp, C.POINTER(ci)]
+    L.orb_match_projection_best.argtypes = [vp, vp, vp, ci, vp, vp, vp, ci, vp, ci, ci, vp, ci, vp, vp]
     L.orb_vocab_create.argtypes = [ci, vp, vp, vp, vp, ci, ci, C.POINTER(vp)]
     L.orb_vocab_destroy.argtypes = [vp]
     L.orb_vocab_destroy.restype = None
@@ -355,6 +356,21 @@ class Matcher:
                                            _p(u_right), _p(occupied), n, _p(grid), self.nnratio, int(max_dist),
                                            int(self.check_ori), _p(out), C.byref(nm)))
         return nm.value, out[:n]
+
+    def search_by_projection_best(self, q, q_desc, kps_un, desc, u_right, grid, max_dist=50, chi2=False, inv_sigma2=None):
+        """Independent best candidate per projected point (search loops of Fuse x2 / SearchBySim3)."""
+        q = np.ascontiguousarray(q, PROJ_DTYPE); q_desc = np.ascontiguousarray(q_desc, np.uint8)
+        kps_un = np.ascontiguousarray(kps_un); desc = np.ascontiguousarray(desc, np.uint8)
+        u_right = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+        inv_sigma2 = None if inv_sigma2 is None else np.ascontiguousarray(inv_sigma2, np.float32)
+        grid = np.ascontiguousarray(grid, np.float32)
+        nq = q.shape[0]
+        best = np.full(max(nq, 1), -1, np.int32)
+        dist = np.full(max(nq, 1), 256, np.int32)
+        _check(self.L.orb_match_projection_best(self.h, _p(q), _p(q_desc), nq, _p(kps_un), _p(desc), _p(u_right), kps_un.shape[0],
+                                                _p(grid), int(max_dist), int(chi2), _p(inv_sigma2),
+                                                0 if inv_sigma2 is None else inv_sigma2.shape[0], _p(best), _p(dist)))
+        return best[:nq], dist[:nq]
 
     def distinctive_descriptors(self, desc, offsets):
         """MapPoint::ComputeDistinctiveDescriptors for a batch: desc rows offsets[p]:offsets[p+1] belong to point p."""

@@ -78,6 +78,8 @@ def lib():
                                                     C.c_void_p, C.c_void_p, C.c_int] + [C.c_float] * 5 + [C.c_int, C.c_int, C.c_void_p])
         L.orbref_vocab_transform.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.orbref_distinctive.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.orbref_search_by_projection_best.argtypes = ([C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] +
+                                                         [C.c_float] * 4 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p])
         L.orbref_features_in_area.restype = C.c_int
         L.orbref_features_in_area.argtypes = ([C.c_void_p, C.c_int] + [C.c_float] * 7 + [C.c_int] * 2 +
                                               [C.c_void_p, C.c_int])
@@ -331,3 +333,17 @@ def distinctive_descriptors(desc, offsets):
     out = np.zeros(max(n, 1), np.int32)
     lib().orbref_distinctive(_p(desc), _p(offsets), n, _p(out))
     return out[:n]
+
+
+def search_by_projection_best(q, q_desc, kps, desc, u_right, grid, max_dist=50, chi2=False, inv_sigma2=None):
+    """Independent best candidate per projected point (search loops of Fuse x2 / SearchBySim3)."""
+    q = np.ascontiguousarray(q, PROJ_DTYPE); q_desc = np.ascontiguousarray(q_desc, np.uint8)
+    kps = np.ascontiguousarray(kps); desc = np.ascontiguousarray(desc, np.uint8)
+    u_right = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+    inv_sigma2 = None if inv_sigma2 is None else np.ascontiguousarray(inv_sigma2, np.float32)
+    nq = q.shape[0]
+    best = np.full(max(nq, 1), -1, np.int32)
+    dist = np.full(max(nq, 1), 256, np.int32)
+    lib().orbref_search_by_projection_best(_p(q), _p(q_desc), nq, _p(kps), _p(desc), _p(u_right), kps.shape[0],
+                                           *[float(g) for g in grid], int(max_dist), int(chi2), _p(inv_sigma2), _p(best), _p(dist))
+    return best[:nq], dist[:nq]

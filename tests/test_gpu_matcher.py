@@ -310,3 +310,22 @@ def test_search_by_projection_reloc_and_loop_variants(feats, max_dist, ori):
         got_n, got = m.search_by_projection(0, q, qd, qa, kb, db, None, occ, grid, max_dist)
         assert want_n > 50
         assert got_n == want_n and np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("chi2,max_dist", [(True, 50), (False, 50), (False, 100)])
+def test_search_by_projection_best_fuse_and_sim3(feats, chi2, max_dist):
+    grid = (0.0, 0.0, 0.1, 0.1)
+    m = capi.Matcher()
+    inv_sigma2 = (np.float32(1) / (np.float32(1.2) ** np.arange(8, dtype=np.float32)) ** 2).astype(np.float32)
+    for a, b, seed in [(0, 1, 31), (1, 2, 32), (2, 0, 33)]:
+        q, qd, qa, kb, db, ur, occ = _proj_scene(feats, a, b, 1, "map", seed)
+        ur[::7] = 0.0                                           # mvuRight == 0 counts as stereo for the chi2 gate (>= 0)
+        want_i, want_d = oracle.search_by_projection_best(q, qd, kb, db, ur, grid, max_dist, chi2, inv_sigma2)
+        got_i, got_d = m.search_by_projection_best(q, qd, kb, db, ur, grid, max_dist, chi2, inv_sigma2)
+        assert (want_i >= 0).sum() > 100
+        assert np.array_equal(got_i, want_i) and np.array_equal(got_d, want_d)
+    # monocular keyframe (no mvuRight)
+    q, qd, qa, kb, db, ur, occ = _proj_scene(feats, 0, 2, 1, "map", 34)
+    want_i, want_d = oracle.search_by_projection_best(q, qd, kb, db, None, grid, max_dist, chi2, inv_sigma2)
+    got_i, got_d = m.search_by_projection_best(q, qd, kb, db, None, grid, max_dist, chi2, inv_sigma2)
+    assert np.array_equal(got_i, want_i) and np.array_equal(got_d, want_d)
