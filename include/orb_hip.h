@@ -240,6 +240,19 @@ int orb_match_projection_best(orb_matcher* m, const orb_proj_query* queries, con
                               const float* grid4, int max_dist, int chi2, const float* inv_level_sigma2, int n_levels,
                               int32_t* best_idx, int32_t* best_dist);
 
+/* replaces: int ORBmatcher::SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, cv::Mat F12,
+ * vector<pair<size_t,size_t>>& vMatchedPairs, bool bOnlyStereo), reference src/ORBmatcher.cc:1183-1359 (with
+ * CheckDistEpipolarLine :1636-1650).  has_mp[i] != 0 iff GetMapPoint(i) != NULL; u_right = mvuRight (NULL = monocular);
+ * F12 row-major 3x3 floats; (ex, ey) the epipole of :1193-1194 (computed by the caller with the reference's cv::Mat
+ * expressions); scale_factors2 / level_sigma2_2 = pKF2->mvScaleFactors / mvLevelSigma2.  match_12[i1] = idx2 or -1
+ * (the pair list of :1345-1352 is every i1 with match_12[i1] >= 0, ascending); *nmatches = return value. */
+int orb_match_triangulation(orb_matcher* m, const orb_keypoint* kps1, const uint8_t* desc1, const uint8_t* has_mp1,
+                            const float* u_right1, int n1, const orb_featvec* fv1, const orb_keypoint* kps2,
+                            const uint8_t* desc2, const uint8_t* has_mp2, const float* u_right2, int n2,
+                            const orb_featvec* fv2, const float* F12, float ex, float ey, const float* scale_factors2,
+                            const float* level_sigma2_2, int n_levels, int only_stereo, int check_ori, int32_t* match_12,
+                            int* nmatches);
+
 /* Batched device-resident SearchByBoW: pair p matches keyframe kf_index[p] against frame
  * f_index[p] of a feature store that lives in HBM (the Relocalization candidate loop of
  * reference src/Tracking.cc:1471-1492 is the batch axis).  See orb_featstore below. */

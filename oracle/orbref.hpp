@@ -134,6 +134,13 @@ void searchByProjectionBest(const ProjQuery* q, const uint8_t* qDesc, int nq, co
                             const float* uRight, int n, const FrameGrid& grid, int maxDist, bool chi2,
                             const float* invSigma2, int32_t* bestIdx, int32_t* bestDist);
 
+// SearchForTriangulation  src/ORBmatcher.cc:1183-1359 (+ CheckDistEpipolarLine :1636-1650).  F12 row-major 3x3.
+int searchForTriangulation(const KeyPoint* k1, const uint8_t* d1, const uint8_t* hasMP1, const float* uR1, int n1,
+                           const FeatVec& fv1, const KeyPoint* k2, const uint8_t* d2, const uint8_t* hasMP2,
+                           const float* uR2, int n2, const FeatVec& fv2, const float* F12, float ex, float ey,
+                           const float* scaleFactors2, const float* levelSigma2_2, bool onlyStereo, bool checkOri,
+                           std::vector<int32_t>& matches12);
+
 // A DBoW2 vocabulary tree flattened to arrays (node 0 = root; children of node v = children[childBegin[v] ..
 // childBegin[v+1]) in stored order; wordId[v] >= 0 for leaves).
 struct VocabTree {

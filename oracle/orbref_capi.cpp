@@ -241,6 +241,21 @@ void orbref_search_by_projection_best(const ProjQuery* q, const uint8_t* qDesc, 
     searchByProjectionBest(q, qDesc, nq, kps, desc, uRight, n, g, maxDist, chi2 != 0, invSigma2, bestIdx, bestDist);
 }
 
+int orbref_search_for_triangulation(const KeyPoint* k1, const uint8_t* d1, const uint8_t* mp1, const float* ur1, int n1,
+                                    const uint32_t* ids1, const int32_t* offs1, const int32_t* idx1, int nn1,
+                                    const KeyPoint* k2, const uint8_t* d2, const uint8_t* mp2, const float* ur2, int n2,
+                                    const uint32_t* ids2, const int32_t* offs2, const int32_t* idx2, int nn2,
+                                    const float* F12, float ex, float ey, const float* sf2, const float* sig2,
+                                    int onlyStereo, int checkOri, int32_t* m12)
+{
+    std::vector<int32_t> out;
+    const int nm = searchForTriangulation(k1, d1, mp1, ur1, n1, makeFV(ids1, offs1, idx1, nn1), k2, d2, mp2, ur2, n2,
+                                          makeFV(ids2, offs2, idx2, nn2), F12, ex, ey, sf2, sig2, onlyStereo != 0,
+                                          checkOri != 0, out);
+    if (n1) std::memcpy(m12, out.data(), (size_t)n1 * 4);
+    return nm;
+}
+
 // grid query exposed for the grid unit tests: returns count, indices in reference order
 int orbref_features_in_area(const KeyPoint* k, int n, float minX, float minY, float invW, float invH,
                             float x, float y, float r, int minLevel, int maxLevel, int32_t* out, int cap)

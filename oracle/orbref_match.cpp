@@ -482,3 +482,81 @@ void searchByProjectionBest(const ProjQuery* q, const uint8_t* qDesc, int nq, co
 }
 
 }  // namespace orbref
+
+// ------------------------------------------------------------------ SearchForTriangulation (src/ORBmatcher.cc:1183-1359)
+namespace orbref {
+
+static bool checkDistEpipolarLine(const KeyPoint& kp1, const KeyPoint& kp2, const float* F12, const float* levelSigma2)
+{
+    // :1636-1650
+    const float a = kp1.x * F12[0] + kp1.y * F12[3] + F12[6];
+    const float b = kp1.x * F12[1] + kp1.y * F12[4] + F12[7];
+    const float c = kp1.x * F12[2] + kp1.y * F12[5] + F12[8];
+    const float num = a * kp2.x + b * kp2.y + c;
+    const float den = a * a + b * b;
+    if (den == 0) return false;
+    const float dsqr = num * num / den;
+    return dsqr < 3.84 * levelSigma2[kp2.octave];
+}
+
+int searchForTriangulation(const KeyPoint* k1, const uint8_t* d1, const uint8_t* hasMP1, const float* uR1, int n1,
+                           const FeatVec& fv1, const KeyPoint* k2, const uint8_t* d2, const uint8_t* hasMP2,
+                           const float* uR2, int n2, const FeatVec& fv2, const float* F12, float ex, float ey,
+                           const float* scaleFactors2, const float* levelSigma2_2, bool onlyStereo, bool checkOri,
+                           std::vector<int32_t>& matches12)
+{
+    matches12.assign(n1, -1);
+    std::vector<uint8_t> matched2(n2, 0);            // never set by the reference (:1198, :1235): kept for fidelity
+    std::vector<int> rotHist[HISTO_LENGTH];
+    int nmatches = 0;
+    size_t a = 0, b = 0;
+    while (a < fv1.nodeIds.size() && b < fv2.nodeIds.size()) {
+        if (fv1.nodeIds[a] == fv2.nodeIds[b]) {
+            for (int p = fv1.offsets[a]; p < fv1.offsets[a + 1]; p++) {
+                const int idx1 = fv1.indices[p];
+                if (hasMP1[idx1]) continue;
+                const bool stereo1 = uR1 && uR1[idx1] >= 0;
+                if (onlyStereo && !stereo1) continue;
+                const KeyPoint& kp1 = k1[idx1];
+                int bestDist = TH_LOW, bestIdx2 = -1;
+                for (int q = fv2.offsets[b]; q < fv2.offsets[b + 1]; q++) {
+                    const int idx2 = fv2.indices[q];
+                    if (matched2[idx2] || hasMP2[idx2]) continue;
+                    const bool stereo2 = uR2 && uR2[idx2] >= 0;
+                    if (onlyStereo && !stereo2) continue;
+                    const int dist = hamming256(d1 + 32 * (size_t)idx1, d2 + 32 * (size_t)idx2);
+                    if (dist > TH_LOW || dist > bestDist) continue;
+                    const KeyPoint& kp2 = k2[idx2];
+                    if (!stereo1 && !stereo2) {
+                        const float distex = ex - kp2.x, distey = ey - kp2.y;
+                        if (distex * distex + distey * distey < 100 * scaleFactors2[kp2.octave]) continue;
+                    }
+                    if (checkDistEpipolarLine(kp1, kp2, F12, levelSigma2_2)) { bestIdx2 = idx2; bestDist = dist; }
+                }
+                if (bestIdx2 >= 0) {
+                    matches12[idx1] = bestIdx2;
+                    nmatches++;
+                    if (checkOri) rotHist[rotBin(kp1.angle, k2[bestIdx2].angle)].push_back(idx1);
+                }
+            }
+            a++; b++;
+        } else if (fv1.nodeIds[a] < fv2.nodeIds[b]) {
+            a = lowerBound(fv1.nodeIds, fv2.nodeIds[b]);
+        } else {
+            b = lowerBound(fv2.nodeIds, fv1.nodeIds[a]);
+        }
+    }
+    if (checkOri) {
+        int counts[HISTO_LENGTH];
+        for (int i = 0; i < HISTO_LENGTH; i++) counts[i] = (int)rotHist[i].size();
+        int i1 = -1, i2 = -1, i3 = -1;
+        threeMaxima(counts, i1, i2, i3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == i1 || i == i2 || i == i3) continue;
+            for (int idx : rotHist[i]) { matches12[idx] = -1; nmatches--; }
+        }
+    }
+    return nmatches;
+}
+
+}  // namespace orbref

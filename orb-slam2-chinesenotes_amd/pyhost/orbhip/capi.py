@@ -62,7 +62,7 @@ SYMBOLS = [
     "orb_extract_batch", "orb_extract_batch_device", "orb_extractor_sync", "orb_get_pyramid_level",
     "orb_get_level_counts", "orb_extractor_set_profiling", "orb_extractor_get_stage_ms", "orb_extractor_profiled_frames", "orb_extractor_stream",
     "orb_hamming", "orb_three_maxima", "orb_matcher_create", "orb_matcher_destroy", "orb_matcher_sync",
-    "orb_match_bow", "orb_match_bow_kk", "orb_match_init", "orb_match_projection", "orb_match_projection_best", "orb_vocab_create", "orb_vocab_destroy", "orb_vocab_level_nodes", "orb_bow_transform",
+    "orb_match_bow", "orb_match_bow_kk", "orb_match_init", "orb_match_projection", "orb_match_projection_best", "orb_match_triangulation", "orb_vocab_create", "orb_vocab_destroy", "orb_vocab_level_nodes", "orb_bow_transform",
     "orb_bow_transform_device", "orb_distinctive_descriptors", "orb_distinctive_descriptors_device", "orb_bow_assign_device", "orb_match_bow_batch_device",
     "orb_matcher_stream", "orb_stereo_match", "orb_stereo_match_device", "orb_extractor_wait_for", "orb_matcher_wait_for", "orb_last_error", "orb_version",
 ]
@@ -113,6 +113,8 @@ def lib():
     L.orb_match_init.argtypes = [vp, vp, vp, ci, vp, vp, ci, vp, vp, ci, cf, ci, vp, C.POINTER(ci)]
     L.orb_match_projection.argtypes = [vp, ci, vp, vp, vp, ci, vp, vp, vp, vp, ci, vp, cf, ci, ci, vp, C.POINTER(ci)]
     L.orb_match_projection_best.argtypes = [vp, vp, vp, ci, vp, vp, vp, ci, vp, ci, ci, vp, ci, vp, vp]
+    L.orb_match_triangulation.argtypes = [vp, vp, vp, vp, vp, ci, C.POINTER(FeatVecC), vp, vp, vp, vp, ci, C.POINTER(FeatVecC), vp, cf, cf,
+                                          vp, vp, ci, ci, ci, vp, C.POINTER(ci)]
     L.orb_vocab_create.argtypes = [ci, vp, vp, vp, vp, ci, ci, C.POINTER(vp)]
     L.orb_vocab_destroy.argtypes = [vp]
     L.orb_vocab_destroy.restype = None
@@ -371,6 +373,23 @@ class Matcher:
                                                 _p(grid), int(max_dist), int(chi2), _p(inv_sigma2),
                                                 0 if inv_sigma2 is None else inv_sigma2.shape[0], _p(best), _p(dist)))
         return best[:nq], dist[:nq]
+
+    def search_for_triangulation(self, k1, d1, mp1, ur1, fv1, k2, d2, mp2, ur2, fv2, F12, ex, ey, sf2, sig2, only_stereo=False):
+        k1 = np.ascontiguousarray(k1); k2 = np.ascontiguousarray(k2)
+        d1 = np.ascontiguousarray(d1, np.uint8); d2 = np.ascontiguousarray(d2, np.uint8)
+        mp1 = np.ascontiguousarray(mp1, np.uint8); mp2 = np.ascontiguousarray(mp2, np.uint8)
+        ur1 = None if ur1 is None else np.ascontiguousarray(ur1, np.float32)
+        ur2 = None if ur2 is None else np.ascontiguousarray(ur2, np.float32)
+        F12 = np.ascontiguousarray(F12, np.float32); sf2 = np.ascontiguousarray(sf2, np.float32)
+        sig2 = np.ascontiguousarray(sig2, np.float32)
+        n1 = k1.shape[0]
+        out = np.full(max(n1, 1), -1, np.int32)
+        nm = C.c_int(0)
+        a, b = _fv(*fv1), _fv(*fv2)
+        _check(self.L.orb_match_triangulation(self.h, _p(k1), _p(d1), _p(mp1), _p(ur1), n1, C.byref(a), _p(k2), _p(d2), _p(mp2),
+                                              _p(ur2), k2.shape[0], C.byref(b), _p(F12), float(ex), float(ey), _p(sf2), _p(sig2),
+                                              sf2.shape[0], int(only_stereo), int(self.check_ori), _p(out), C.byref(nm)))
+        return nm.value, out[:n1]
 
     def distinctive_descriptors(self, desc, offsets):
         """MapPoint::ComputeDistinctiveDescriptors for a batch: desc rows offsets[p]:offsets[p+1] belong to point p."""

@@ -80,6 +80,9 @@ def lib():
         L.orbref_distinctive.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.orbref_search_by_projection_best.argtypes = ([C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] +
                                                          [C.c_float] * 4 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p])
+        L.orbref_search_for_triangulation.restype = C.c_int
+        L.orbref_search_for_triangulation.argtypes = ([C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int]) * 2 + \
+            [C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.orbref_features_in_area.restype = C.c_int
         L.orbref_features_in_area.argtypes = ([C.c_void_p, C.c_int] + [C.c_float] * 7 + [C.c_int] * 2 +
                                               [C.c_void_p, C.c_int])
@@ -347,3 +350,20 @@ def search_by_projection_best(q, q_desc, kps, desc, u_right, grid, max_dist=50, 
     lib().orbref_search_by_projection_best(_p(q), _p(q_desc), nq, _p(kps), _p(desc), _p(u_right), kps.shape[0],
                                            *[float(g) for g in grid], int(max_dist), int(chi2), _p(inv_sigma2), _p(best), _p(dist))
     return best[:nq], dist[:nq]
+
+
+def search_for_triangulation(k1, d1, mp1, ur1, fv1, k2, d2, mp2, ur2, fv2, F12, ex, ey, sf2, sig2, only_stereo=False,
+                             check_ori=True):
+    k1 = np.ascontiguousarray(k1); k2 = np.ascontiguousarray(k2)
+    d1 = np.ascontiguousarray(d1, np.uint8); d2 = np.ascontiguousarray(d2, np.uint8)
+    mp1 = np.ascontiguousarray(mp1, np.uint8); mp2 = np.ascontiguousarray(mp2, np.uint8)
+    ur1 = None if ur1 is None else np.ascontiguousarray(ur1, np.float32)
+    ur2 = None if ur2 is None else np.ascontiguousarray(ur2, np.float32)
+    F12 = np.ascontiguousarray(F12, np.float32); sf2 = np.ascontiguousarray(sf2, np.float32); sig2 = np.ascontiguousarray(sig2, np.float32)
+    n1 = k1.shape[0]
+    out = np.full(max(n1, 1), -1, np.int32)
+    nm = lib().orbref_search_for_triangulation(_p(k1), _p(d1), _p(mp1), _p(ur1), n1, _p(fv1.node_ids), _p(fv1.offsets),
+                                               _p(fv1.indices), fv1.nnodes, _p(k2), _p(d2), _p(mp2), _p(ur2), k2.shape[0],
+                                               _p(fv2.node_ids), _p(fv2.offsets), _p(fv2.indices), fv2.nnodes, _p(F12),
+                                               float(ex), float(ey), _p(sf2), _p(sig2), int(only_stereo), int(check_ori), _p(out))
+    return nm, out[:n1]

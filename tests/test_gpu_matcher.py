@@ -329,3 +329,36 @@ def test_search_by_projection_best_fuse_and_sim3(feats, chi2, max_dist):
     want_i, want_d = oracle.search_by_projection_best(q, qd, kb, db, None, grid, max_dist, chi2, inv_sigma2)
     got_i, got_d = m.search_by_projection_best(q, qd, kb, db, None, grid, max_dist, chi2, inv_sigma2)
     assert np.array_equal(got_i, want_i) and np.array_equal(got_d, want_d)
+
+
+@pytest.mark.parametrize("only_stereo,ori,mono", [(False, True, False), (True, True, False), (False, False, True)])
+def test_search_for_triangulation(feats, only_stereo, ori, mono):
+    rng = np.random.default_rng(41)
+    m = capi.Matcher(0.6, ori)
+    sf = (np.float32(1.2) ** np.arange(8, dtype=np.float32)).astype(np.float32)
+    sig2 = (sf * sf).astype(np.float32)
+    for a, b in [(0, 1), (1, 2), (3, 0)]:
+        (k1, d1), (k2, d2) = feats[a], feats[b]
+        fv1, t1 = _fv(d1)
+        fv2, t2 = _fv(d2)
+        mp1 = (rng.random(len(k1)) < 0.3).astype(np.uint8)
+        mp2 = (rng.random(len(k2)) < 0.3).astype(np.uint8)
+        ur1 = None if mono else np.where(rng.random(len(k1)) < 0.5, k1["x"] - 10, -1).astype(np.float32)
+        ur2 = None if mono else np.where(rng.random(len(k2)) < 0.5, k2["x"] - 10, -1).astype(np.float32)
+        # a fundamental matrix of a small sideways motion: epipolar lines are (nearly) the image rows
+        F12 = np.array([[0, 0, 0.0004], [0, 0, -1.0], [-0.0003, 1.0, 0.2]], np.float32)
+        ex, ey = np.float32(5000.0), np.float32(240.0)
+        wn, wm = oracle.search_for_triangulation(k1, d1, mp1, ur1, fv1, k2, d2, mp2, ur2, fv2, F12, ex, ey, sf, sig2, only_stereo, ori)
+        gn, gm = m.search_for_triangulation(k1, d1, mp1, ur1, t1, k2, d2, mp2, ur2, t2, F12, ex, ey, sf, sig2, only_stereo)
+        if not only_stereo:
+            assert wn > 30
+        assert gn == wn and np.array_equal(gm, wm)
+    # epipole in the middle of the image: the "too close to the epipole" rule fires for monocular features
+    (k1, d1), (k2, d2) = feats[0], feats[1]
+    fv1, t1 = _fv(d1)
+    fv2, t2 = _fv(d2)
+    z1, z2 = np.zeros(len(k1), np.uint8), np.zeros(len(k2), np.uint8)
+    F12 = np.array([[0, 0, 0.0004], [0, 0, -1.0], [-0.0003, 1.0, 0.2]], np.float32)
+    wn, wm = oracle.search_for_triangulation(k1, d1, z1, None, fv1, k2, d2, z2, None, fv2, F12, 320.0, 240.0, sf * 400, sig2, False, ori)
+    gn, gm = m.search_for_triangulation(k1, d1, z1, None, t1, k2, d2, z2, None, t2, F12, 320.0, 240.0, sf * 400, sig2, False)
+    assert gn == wn and np.array_equal(gm, wm)
