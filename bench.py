@@ -47,6 +47,8 @@ def main():
     ap.add_argument("--no-match", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) or gloo (CPU rehearsal of the N>1 path)")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses GPU 0")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -54,13 +56,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    comm_dev = dev if args.backend == "nccl" else torch.device("cpu")      # where collective tensors live
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     B, W, H = args.frames_per_gpu, args.width, args.height
     ex = capi.Extractor(args.nfeatures, 1.2, 8, 20, 7, device=local_rank)
@@ -68,10 +76,11 @@ def main():
     cap = ex.max_keypoints
 
     # ---- the one collective: rank 0 broadcasts the BRIEF pattern (RCCL over xGMI)
-    pat = torch.zeros(1024, dtype=torch.int8, device=dev)
+    pat = torch.zeros(1024, dtype=torch.int8, device=comm_dev)
     if rank == 0:
         pat.copy_(torch.from_numpy(capi.builtin_pattern()))
     shard.broadcast_pattern(dist, pat, 0)
+    pat = pat.to(dev)
     torch.cuda.synchronize()
     ex.set_pattern_device(pat.data_ptr())
 
@@ -122,8 +131,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    elapsed = shard.max_over_ranks(dist, elapsed, dev)
-    frames_done = shard.sum_over_ranks(dist, B * args.steps, dev)
+    elapsed = shard.max_over_ranks(dist, elapsed, comm_dev)
+    frames_done = shard.sum_over_ranks(dist, B * args.steps, comm_dev)
 
     stage_ms = ex.stage_ms()                       # HIP events on the stream the kernels were launched on
     launch_frames = ex.profiled_frames()           # frames per timed launch (sub-batch 0)
