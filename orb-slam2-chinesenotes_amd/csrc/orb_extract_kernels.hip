@@ -106,10 +106,10 @@ __global__ __launch_bounds__(256) void k_resize_level4(uint8_t* __restrict__ pyr
     uint32_t out = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const int o = sx[i] - sxBase;                     // 0..8 by construction
-        const bool lo = o < 4;
-        const unsigned pu = __builtin_amdgcn_alignbyte(lo ? u1 : u2, lo ? u0 : u1, (unsigned)(o & 3));
-        const unsigned pv = __builtin_amdgcn_alignbyte(lo ? v1 : v2, lo ? v0 : v1, (unsigned)(o & 3));
+        const int o = sx[i] - sxBase;                     // 0..10 by construction (scale <= 2.2); o+1 <= 11
+        const bool lo = o < 4, mid = o < 8;
+        const unsigned pu = __builtin_amdgcn_alignbyte(lo ? u1 : (mid ? u2 : 0u), lo ? u0 : (mid ? u1 : u2), (unsigned)(o & 3));
+        const unsigned pv = __builtin_amdgcn_alignbyte(lo ? v1 : (mid ? v2 : 0u), lo ? v0 : (mid ? v1 : v2), (unsigned)(o & 3));
         const int a0 = (short)(co[i] & 0xffff), a1 = (short)(co[i] >> 16);
         const int h0 = (int)(pu & 0xff) * a0 + (int)((pu >> 8) & 0xff) * a1;
         const int h1 = (int)(pv & 0xff) * a0 + (int)((pv >> 8) & 0xff) * a1;

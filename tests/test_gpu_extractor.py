@@ -117,3 +117,17 @@ def test_two_handles_two_threads():
     for i in range(2):
         rk, rd = ref.extract(imgs[i])
         assert res[i][0].tobytes() == rk.tobytes() and np.array_equal(res[i][1], rd)
+
+
+@pytest.mark.parametrize("w,h,levels", [(160, 120, 8), (100, 100, 8), (97, 64, 6), (70, 70, 3)])
+def test_tiny_images_with_degenerate_levels(w, h, levels):
+    # upper pyramid levels shrink below the 30-px cell grid / the 32-px border (the reference would divide by zero
+    # there): such levels simply yield no keypoints, and the levels that are still valid match the oracle exactly
+    _cmp(synth.synth_frame(1, w, h), nfeatures=300, levels=levels)
+
+
+def test_other_scale_factors_and_thresholds():
+    _cmp(synth.synth_frame(12), nfeatures=800, levels=5, sf=1.5, ini=30, mn=10)
+    _cmp(synth.synth_frame(13), nfeatures=1500, levels=10, sf=1.1, ini=12, mn=5)
+    _cmp(synth.synth_frame(14, 512, 384), nfeatures=600, levels=4, sf=2.0, ini=20, mn=7)
+    _cmp(synth.synth_frame(15, 512, 384), nfeatures=400, levels=3, sf=2.5, ini=20, mn=7)       # generic resize path
