@@ -120,6 +120,61 @@ __global__ __launch_bounds__(256) void k_resize_level4(uint8_t* __restrict__ pyr
 }
 
 // ------------------------------------------------------------------------------------------------
+// Lean form of the same arithmetic (the window kernel above is VALU-issue bound: ~150 vector instructions per
+// 4 pixels, most of them byte-window selects).  Everything that depends only on the output column is moved into
+// a per-thread table built once on the host (xq, 3 x 16 B per 4 pixels):
+//   {baseA, baseB, sel0, sel1} {sel2, sel3, co0, co1} {co2, co3, -, -}
+// baseA/baseB = 4-aligned source byte offsets of the 8-byte windows of pixels (0,1) / (2,3); sel_i = the
+// v_perm_b32 selector that pulls source bytes (o_i, o_i + 1) out of the window straight into a u16 pair;
+// co_i = a0 | a1 << 16.  One v_perm_b32 + one v_dot2_u32_u16 then give the horizontal pass of a row
+// (p0*a0 + p1*a1), and all products fit 24-bit multiplies.  Valid while o_i + 1 <= 7, i.e. scale <= 3.
+typedef unsigned short orb_u16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned resize_px(uint2 wa, uint2 wb, unsigned sel, unsigned co, unsigned b0, unsigned b1)
+{
+    const unsigned pa = __builtin_amdgcn_perm(wa.y, wa.x, sel), pb = __builtin_amdgcn_perm(wb.y, wb.x, sel);
+    const unsigned h0 = __builtin_amdgcn_udot2(__builtin_bit_cast(orb_u16x2, pa), __builtin_bit_cast(orb_u16x2, co), 0u, false);
+    const unsigned h1 = __builtin_amdgcn_udot2(__builtin_bit_cast(orb_u16x2, pb), __builtin_bit_cast(orb_u16x2, co), 0u, false);
+    return ((__umul24(h0 >> 4, b0) >> 16) + (__umul24(h1 >> 4, b1) >> 16) + 2) >> 2;        // <= 255
+}
+
+#define RESIZE_ROWS 4      // output rows per thread: the 40-byte column entry and the index decode are paid once
+
+__global__ __launch_bounds__(256) void k_resize_level4p(uint8_t* __restrict__ pyr, size_t pyrSlab, int srcOff,
+                                                        int srcPitch, int dstOff, int dstPitch, int dh,
+                                                        const uint4* __restrict__ xq, const int2* __restrict__ ytab,
+                                                        int x4n, unsigned invx)
+{
+    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = blockIdx.y;
+    const unsigned yg = (unsigned)(((unsigned long long)idx * invx) >> 32);
+    const unsigned x4 = idx - __umul24(yg, (unsigned)x4n);
+    const unsigned y0 = yg * RESIZE_ROWS;
+    if ((int)y0 >= dh) return;
+    const uint8_t* src = pyr + (size_t)f * pyrSlab + srcOff;
+    uint8_t* dst = pyr + (size_t)f * pyrSlab + dstOff;
+    const uint4 q0 = xq[3 * x4], q1 = xq[3 * x4 + 1];
+    const uint2 q2 = *reinterpret_cast<const uint2*>(xq + 3 * x4 + 2);
+#pragma unroll
+    for (int r = 0; r < RESIZE_ROWS; r++) {
+        const unsigned y = y0 + r;
+        if ((int)y < dh) {
+            const int2 ty = ytab[y];
+            const unsigned b0 = (unsigned)ty.y & 0xffffu, b1 = (unsigned)ty.y >> 16;
+            const unsigned rowA = __umul24((unsigned)ty.x & 0xffffu, (unsigned)srcPitch);
+            const unsigned rowB = __umul24((unsigned)ty.x >> 16, (unsigned)srcPitch);
+            const uint2 wA0 = *reinterpret_cast<const uint2*>(src + (rowA + q0.x)), wA1 = *reinterpret_cast<const uint2*>(src + (rowA + q0.y));
+            const uint2 wB0 = *reinterpret_cast<const uint2*>(src + (rowB + q0.x)), wB1 = *reinterpret_cast<const uint2*>(src + (rowB + q0.y));
+            const unsigned v0 = resize_px(wA0, wB0, q0.z, q1.z, b0, b1);
+            const unsigned v1 = resize_px(wA0, wB0, q0.w, q1.w, b0, b1);
+            const unsigned v2 = resize_px(wA1, wB1, q1.x, q2.x, b0, b1);
+            const unsigned v3 = resize_px(wA1, wB1, q1.y, q2.y, b0, b1);
+            *reinterpret_cast<uint32_t*>(dst + (__umul24(y, (unsigned)dstPitch) + x4 * 4)) = v0 | (v1 << 8) | (v2 << 16) | (v3 << 24);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // launch wrappers (keep <<<>>> syntax inside this translation unit)
 // exact division of idx < 2^31 by d via multiply-high: q = (idx * ceil(2^32/d)) >> 32 is exact while idx*d < 2^32
 static unsigned inv32(int d) { return (unsigned)(((1ull << 32) + d - 1) / d); }
@@ -136,15 +191,22 @@ void orb_launch_copy_level0(hipStream_t st, const uint8_t* src, size_t rowStride
 }
 
 void orb_launch_resize(hipStream_t st, uint8_t* pyr, size_t pyrSlab, const OrbLevelGeom& src,
-                       const OrbLevelGeom& dst, const int2* xtab, const int2* ytab, int nFrames)
+                       const OrbLevelGeom& dst, const int2* xtab, const int2* ytab, const uint4* xq, int nFrames)
 {
     const int x4 = (dst.w + 3) / 4;
     dim3 grid((x4 + 63) / 64, (dst.h + 3) / 4, nFrames);
-    // window form needs sx(dx+3)+1 - (sx(dx) & ~3) <= 11, i.e. 3 + ceil(3*scale) + 1 <= 11; the flattened index
-    // decode (multiply-high) is exact while total * x4 < 2^32.  (An LDS-tiled variant was measured: no faster.)
+    // the flattened index decode (multiply-high) is exact while total * x4 < 2^32; 24-bit multiplies need
+    // rows, pitches and row offsets below 2^24 / 2^32 (any realistic image)
     const double scale = (double)src.w / dst.w;
     const long long total = (long long)x4 * dst.h;
-    if (scale <= 2.2 && total * x4 < (1ll << 32)) {
+    const bool flat = total * x4 < (1ll << 32);
+    if (xq && flat && (long long)src.h * src.pitch < (1ll << 31) && src.pitch < (1 << 24) && dst.h < (1 << 24)) {
+        const long long groups = (long long)x4 * ((dst.h + RESIZE_ROWS - 1) / RESIZE_ROWS);
+        hipLaunchKernelGGL(k_resize_level4p, dim3((unsigned)((groups + 255) / 256), nFrames), dim3(256), 0, st, pyr, pyrSlab,
+                           src.pyrOff, src.pitch, dst.pyrOff, dst.pitch, dst.h, xq, ytab, x4, inv32(x4));
+    }
+    // window form needs sx(dx+3)+1 - (sx(dx) & ~3) <= 11, i.e. 3 + ceil(3*scale) + 1 <= 11
+    else if (scale <= 2.2 && flat) {
         hipLaunchKernelGGL(k_resize_level4, dim3((unsigned)((total + 255) / 256), nFrames), dim3(256), 0, st, pyr, pyrSlab,
                            src.pyrOff, src.pitch, dst.pyrOff, dst.pitch, dst.w, dst.h, xtab, ytab, x4, inv32(x4));
     }

@@ -268,11 +268,34 @@ static int build_geometry(orb_extractor* h, int rows, int cols)
     std::vector<int2> xt, yt, t;
     h->xtabOff.assign(nl, 0);
     h->ytabOff.assign(nl, 0);
+    h->xqOff.assign(nl, -1);
+    std::vector<uint32_t> xq;
     for (int l = 1; l < nl; l++) {
         axis_table(G.L[l - 1].w, G.L[l].w, true, t);
         while (t.size() % 4) t.push_back(t.back());           // k_resize_level4 reads four entries at a time
         h->xtabOff[l] = xt.size();                             // stays a multiple of 4 -> 32-byte aligned
         xt.insert(xt.end(), t.begin(), t.end());
+        {   // per-thread (4 px) table of k_resize_level4p: window bases, v_perm selectors, coefficient pairs
+            std::vector<uint32_t> q;
+            bool ok = true;
+            for (size_t i = 0; i + 3 < t.size() && ok; i += 4) {
+                const int baseA = t[i].x & ~3, baseB = t[i + 2].x & ~3;
+                uint32_t sel[4];
+                for (int k = 0; k < 4; k++) {
+                    const int o = t[i + k].x - (k < 2 ? baseA : baseB);
+                    if (o < 0 || o > 6) { ok = false; break; }
+                    sel[k] = (uint32_t)o | (0x0cu << 8) | ((uint32_t)(o + 1) << 16) | (0x0cu << 24);
+                }
+                const uint32_t e[12] = {(uint32_t)baseA, (uint32_t)baseB, sel[0], sel[1], sel[2], sel[3], (uint32_t)t[i].y,
+                                        (uint32_t)t[i + 1].y, (uint32_t)t[i + 2].y, (uint32_t)t[i + 3].y, 0u, 0u};
+                q.insert(q.end(), e, e + 12);
+            }
+            for (const int2& e : t) ok = ok && (e.y & 0x8000) == 0 && e.y >= 0;        // coefficients are 0..2048
+            if (ok) {
+                h->xqOff[l] = (long long)(xq.size() / 4);
+                xq.insert(xq.end(), q.begin(), q.end());
+            }
+        }
         axis_table(G.L[l - 1].h, G.L[l].h, false, t);
         h->ytabOff[l] = yt.size();
         yt.insert(yt.end(), t.begin(), t.end());
@@ -282,6 +305,10 @@ static int build_geometry(orb_extractor* h, int rows, int cols)
         if ((rc = h->dYtab.ensure(yt.size() * sizeof(int2))) != ORB_OK) return rc;
         ORB_HIP_TRY(hipMemcpyAsync(h->dXtab.p, xt.data(), xt.size() * sizeof(int2), hipMemcpyHostToDevice, h->stream));
         ORB_HIP_TRY(hipMemcpyAsync(h->dYtab.p, yt.data(), yt.size() * sizeof(int2), hipMemcpyHostToDevice, h->stream));
+        if (!xq.empty()) {
+            if ((rc = h->dXq.ensure(xq.size() * 4)) != ORB_OK) return rc;
+            ORB_HIP_TRY(hipMemcpyAsync(h->dXq.p, xq.data(), xq.size() * 4, hipMemcpyHostToDevice, h->stream));
+        }
     }
     ORB_HIP_TRY(hipStreamSynchronize(h->stream));     // host vectors go out of scope
     h->framesCap = 0;                                  // slabs changed size: re-allocate lazily
@@ -358,7 +385,7 @@ extern "C" void orb_extractor_destroy(orb_extractor* h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    DevBuf* bufs[] = {&h->dPattern, &h->dCells, &h->dXtab, &h->dYtab, &h->dPath, &h->dPyr, &h->dCand, &h->dKpl,
+    DevBuf* bufs[] = {&h->dPattern, &h->dCells, &h->dXtab, &h->dYtab, &h->dXq, &h->dPath, &h->dPyr, &h->dCand, &h->dKpl,
                       &h->dCandCount, &h->dKpCount, &h->dErr, &h->dImgs, &h->dKps, &h->dDesc, &h->dCounts,
                       &h->dStereo, &h->dStereoIn};
     for (DevBuf* b : bufs) b->release();
@@ -513,7 +540,8 @@ extern "C" int orb_extract_batch_device(orb_extractor* h, const uint8_t* d_imgs,
                                G.L[0].pitch, n);
         for (int l = 1; l < G.nlevels; l++)
             orb_launch_resize(ss, spyr, h->pyrSlab, G.L[l - 1], G.L[l], (const int2*)h->dXtab.p + h->xtabOff[l],
-                              (const int2*)h->dYtab.p + h->ytabOff[l], n);
+                              (const int2*)h->dYtab.p + h->ytabOff[l],
+                              h->xqOff[l] >= 0 ? (const uint4*)h->dXq.p + h->xqOff[l] : nullptr, n);
         if (prof) ORB_HIP_TRY(hipEventRecord(pe[1], ss));
         orb_launch_fast_cells(ss, G, spyr, h->pyrSlab, (const OrbCell*)h->dCells.p, (int)h->cells.size(),
                               (const uint32_t*)h->dPath.p, scand, h->candSlab, scc, serr, h->prm.ini_th_fast,

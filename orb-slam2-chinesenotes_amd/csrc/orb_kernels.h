@@ -5,7 +5,7 @@
 void orb_launch_copy_level0(hipStream_t st, const uint8_t* src, size_t rowStride, size_t frameStride,
                             uint8_t* pyr, size_t pyrSlab, int w, int h, int pitch, int nFrames);
 void orb_launch_resize(hipStream_t st, uint8_t* pyr, size_t pyrSlab, const OrbLevelGeom& src,
-                       const OrbLevelGeom& dst, const int2* xtab, const int2* ytab, int nFrames);
+                       const OrbLevelGeom& dst, const int2* xtab, const int2* ytab, const uint4* xq, int nFrames);
 void orb_launch_fast_cells(hipStream_t st, const OrbGeom& G, const uint8_t* pyr, size_t pyrSlab,
                            const OrbCell* cells, int nCells, const uint32_t* pathTab, unsigned long long* cand,
                            size_t candSlab, int* candCount, int* errFlags, int iniTh, int minTh, int maxItems,

@@ -24,24 +24,41 @@ def kname(n):
 
 
 def pmc(d, counter):
-    rows = list(csv.DictReader(open(glob.glob(d + "/*/*counter_collection.csv")[0])))
     agg = collections.defaultdict(list)
-    for r in rows:
-        if r["Counter_Name"] == counter:
-            agg[kname(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    csvs = glob.glob(d + "/*/*counter_collection.csv") + glob.glob(d + "/*counter_collection.csv")
+    if csvs:
+        for r in csv.DictReader(open(csvs[0])):
+            if r["Counter_Name"] == counter:
+                agg[kname(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    else:                                           # rocprofv3's default rocpd (sqlite) output
+        import sqlite3
+        db = sqlite3.connect(glob.glob(d + "/*.db")[0])
+        for name, val in db.execute("select kernel_name, value from counters_collection where counter_name = ?", (counter,)):
+            agg[kname(name)].append(float(val))
     return {k: sum(v) / len(v) for k, v in agg.items()}
+
+
+def kernel_stats(d):
+    """[(kernel, calls, avg_ns, total_ns, percent)] from kernel_stats.csv or the rocpd database."""
+    csvs = glob.glob(d + "/*/*kernel_stats.csv") + glob.glob(d + "/*kernel_stats.csv")
+    if csvs:
+        return [(r["Name"], int(r["Calls"]), float(r["AverageNs"]), float(r["TotalDurationNs"]), float(r["Percentage"]))
+                for r in csv.DictReader(open(csvs[0]))]
+    import sqlite3
+    db = sqlite3.connect(glob.glob(d + "/*.db")[0])
+    rows = list(db.execute("select name, count(*), avg(duration), sum(duration) from kernels group by name"))
+    tot = sum(r[3] for r in rows) or 1.0
+    return sorted([(n, c, a, t, 100.0 * t / tot) for n, c, a, t in rows], key=lambda r: -r[3])
 
 
 def main():
     stats_dir, fetch_dir, write_dir, frames, out = sys.argv[1:6]
     frames = int(frames)
-    stats = list(csv.DictReader(open(glob.glob(stats_dir + "/*/*kernel_stats.csv")[0])))
     with open(out + "_kernel_stats.csv", "w") as f:
         f.write("kernel,calls,avg_us,total_ms,percent\n")
-        for r in stats:
-            if kname(r["Name"]).startswith("k_"):
-                f.write("%s,%s,%.2f,%.3f,%s\n" % (kname(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e3,
-                                                   float(r["TotalDurationNs"]) / 1e6, r["Percentage"]))
+        for name, calls, avg, tot, pct in kernel_stats(stats_dir):
+            if kname(name).startswith("k_"):
+                f.write("%s,%d,%.2f,%.3f,%.2f\n" % (kname(name), calls, avg / 1e3, tot / 1e6, pct))
     fetch, write = pmc(fetch_dir, "FETCH_SIZE"), pmc(write_dir, "WRITE_SIZE")
     res = {"frames_per_launch": frames, "unit": "bytes per launch (avg over launches)",
            "note": "FETCH_SIZE/WRITE_SIZE in KiB x1024; FETCH doubled only for 16-B/lane kernels (gfx950 correction); "
