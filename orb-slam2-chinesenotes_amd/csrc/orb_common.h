@@ -58,3 +58,30 @@ struct OrbCell {                // one FAST cell ROI (reference :826-861), 12 by
 #define ORB_KEY_ROOT_SHIFT 58
 #define ORB_KEY_PATH_SHIFT 34
 #define ORB_KEY_PATH_LEVELS 12
+
+// XCD-aware decode of a 1-D grid (frames x items).  Workgroups are dealt round-robin over the 8 XCDs of an
+// MI355X (observed placement, MI355X_MICROARCH.md; used for speed only, never for correctness), and each XCD has
+// its own 4 MiB L2.  Mapping id -> frame = 8 * (id / (8 * perFrame)) + id % 8 keeps every workgroup of a frame on
+// ONE XCD, so overlapping patch / ROI reads of a frame (0.95 MB pyramid) hit that XCD's L2 instead of being
+// fetched up to 8 times.  Grid size: perFrame * 8 * ceil(nFrames / 8); invPerFrame = ceil(2^32 / perFrame),
+// exact while (id >> 3) * perFrame < 2^32 (checked by orb_xcd_grid on the host).
+#ifdef __HIPCC__
+__device__ __forceinline__ bool orb_xcd_decode(unsigned id, unsigned perFrame, unsigned invPerFrame, int nFrames,
+                                               int& frame, int& item)
+{
+    const unsigned xcd = id & 7u, j = id >> 3;
+    const unsigned grp = __umulhi(j, invPerFrame);
+    item = (int)(j - grp * perFrame);
+    frame = (int)(grp * 8u + xcd);
+    return frame < nFrames;
+}
+#endif
+// host side: number of workgroups, or 0 when the batch is too large for the 32-bit decode
+static inline unsigned orb_xcd_grid(unsigned perFrame, int nFrames, unsigned* invPerFrame)
+{
+    const unsigned long long groups = ((unsigned long long)nFrames + 7) / 8;
+    const unsigned long long total = groups * 8ull * perFrame;
+    if (perFrame == 0 || total >= (1ull << 31) || groups * perFrame * (unsigned long long)perFrame >= (1ull << 32)) return 0;
+    *invPerFrame = (unsigned)(((1ull << 32) + perFrame - 1) / perFrame);
+    return (unsigned)total;
+}

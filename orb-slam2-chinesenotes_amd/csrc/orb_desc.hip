@@ -50,11 +50,17 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
     return a;
 }
 
+// wave64 integer sum with DPP (row_shr 1,2,4,8, row_bcast 15/31; no LDS round trips): total in every lane
+#define ORB_DPP_ADD(v, ctrl, rmask) v += __builtin_amdgcn_update_dpp(0, v, ctrl, rmask, 0xf, false)
 __device__ __forceinline__ int wave_sum(int v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    ORB_DPP_ADD(v, 0x111, 0xf);
+    ORB_DPP_ADD(v, 0x112, 0xf);
+    ORB_DPP_ADD(v, 0x114, 0xf);
+    ORB_DPP_ADD(v, 0x118, 0xf);
+    ORB_DPP_ADD(v, 0x142, 0xa);
+    ORB_DPP_ADD(v, 0x143, 0xc);
+    return __builtin_amdgcn_readlane(v, 63);
 }
 
 // 7-tap row blur at the 4 byte positions 4q..4q+3 of a row, from the 12-byte window (d0,d1,d2) =
@@ -76,15 +82,23 @@ __global__ __launch_bounds__(WAVE) void k_orient_desc(const OrbGeom G, const uin
                                                       size_t pyrSlab, const uint32_t* __restrict__ kpl,
                                                       const int* __restrict__ kpCount,
                                                       const int8_t* __restrict__ pattern,
+                                                      const uint4* __restrict__ angTab,
                                                       orb_keypoint* __restrict__ kpsOut,
                                                       uint8_t* __restrict__ descOut, int cap,
-                                                      int32_t* __restrict__ countsOut, int* __restrict__ errFlags)
+                                                      int32_t* __restrict__ countsOut, int* __restrict__ errFlags,
+                                                      int nFrames, unsigned invPerFrame)
 {
     __shared__ uint32_t Praw[1 + PW * PDW + 1];       // one dword of slack on both sides (edge quads)
     __shared__ uint16_t H[PW * HP];
     uint32_t* Pdw = Praw + 1;
     const int lane = threadIdx.x;
-    const int slot = blockIdx.x, f = blockIdx.y;
+    int slot, f;
+    if (invPerFrame) {                                 // 1-D XCD-aware grid: a frame's keypoints share one L2
+        if (!orb_xcd_decode(blockIdx.x, (unsigned)G.kpSlab, invPerFrame, nFrames, f, slot)) return;
+    } else {
+        slot = blockIdx.x;
+        f = blockIdx.y;
+    }
     int level = 0;
     while (level + 1 < G.nlevels && slot >= G.L[level + 1].kpBase) level++;
     const OrbLevelGeom& L = G.L[level];
@@ -129,36 +143,52 @@ __global__ __launch_bounds__(WAVE) void k_orient_desc(const OrbGeom G, const uin
     __syncthreads();
     const uint8_t* P = reinterpret_cast<const uint8_t*>(Pdw) + xoff;     // P[r*PB + c] = patch (row r, column c)
 
-    // ---- IC_Angle (:78-105): two lanes per patch row (left / right half incl. centre on the left)
+    // ---- IC_Angle (:78-105): two lanes per patch row v = -15..15 (u = -15..0 and u = 1..16).  The 16 bytes of a
+    // half row are funnel-shifted into 4 dwords and reduced with v_dot4_u32_u8 against a per-(|v|, half) table of
+    // byte masks (1 inside the circular patch |u| <= umax[|v|]) and byte weights (u + 15 inside, 0 outside):
+    //   s0 = sum I,  s1 = sum (u + 15) I   =>   m10 += s1 - 15 s0,  m01 += v s0       (exact integers)
     int m10 = 0, m01 = 0;
     if (lane < 62) {
-        const int v = (lane >> 1) - 15;
-        const int d = (int)(G.umaxPacked >> (4 * (v < 0 ? -v : v))) & 15;
-        const uint8_t* row = P + (PR + v) * PB + PR;
-        const int ub = (lane & 1) ? 1 : -d, ue = (lane & 1) ? d : 0;
-        int s0 = 0, s1 = 0;
-        for (int u = ub; u <= ue; u++) {
-            const int val = row[u];
-            s0 += val;
-            s1 += u * val;
-        }
-        m10 = s1;
-        m01 = v * s0;
+        const int v = (lane >> 1) - 15, hh = lane & 1;
+        const uint4* t = angTab + ((v < 0 ? -v : v) * 2 + hh) * 2;
+        const uint4 mk = t[0], wt = t[1];
+        const int b0 = xoff + PR - 15;                  // LDS byte of u = -15
+        const unsigned sh = (unsigned)b0 & 3u;
+        const uint32_t* p = Pdw + (PR + v) * PDW + (b0 >> 2) + 4 * hh;
+        const unsigned d0 = p[0], d1 = p[1], d2 = p[2], d3 = p[3], d4 = p[4];
+        const unsigned n0 = __builtin_amdgcn_alignbyte(d1, d0, sh), n1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+        const unsigned n2 = __builtin_amdgcn_alignbyte(d3, d2, sh), n3 = __builtin_amdgcn_alignbyte(d4, d3, sh);
+        const unsigned s0 = __builtin_amdgcn_udot4(n0, mk.x, __builtin_amdgcn_udot4(n1, mk.y,
+                            __builtin_amdgcn_udot4(n2, mk.z, __builtin_amdgcn_udot4(n3, mk.w, 0u, false), false), false), false);
+        const unsigned s1 = __builtin_amdgcn_udot4(n0, wt.x, __builtin_amdgcn_udot4(n1, wt.y,
+                            __builtin_amdgcn_udot4(n2, wt.z, __builtin_amdgcn_udot4(n3, wt.w, 0u, false), false), false), false);
+        m10 = (int)s1 - 15 * (int)s0;
+        m01 = v * (int)s0;
     }
     m10 = wave_sum(m10);
     m01 = wave_sum(m01);
     const float angle = fast_atan2_deg((float)m01, (float)m10);
 
-    // ---- horizontal 7-tap pass: H[r][b] for LDS byte positions b = 0..43 (patch column b - xoff)
-    for (int idx = lane; idx < PW * 11; idx += WAVE) {
-        const int r = idx / 11, q = idx - r * 11;
-        const uint32_t* p = Pdw + r * PDW + q - 1;
-        unsigned o[4];
-        hblur4(p[0], p[1], p[2], o);
-        uint2 w;
-        w.x = o[0] | (o[1] << 16);
-        w.y = o[2] | (o[3] << 16);
-        *reinterpret_cast<uint2*>(&H[r * HP + 4 * q]) = w;
+    // ---- horizontal 7-tap pass: H[r][b] for LDS byte positions b = 0..43 (patch column b - xoff).
+    // Static mapping (lane -> quad q, row phase rp; rows rp, rp+5, ...): every LDS address is base + constant,
+    // so the unrolled loop carries no index arithmetic (this kernel is VALU-issue bound).
+    {
+        const int rp = lane / 11, q = lane - rp * 11;          // 5 row phases x 11 quads = 55 lanes
+        if (rp < 5) {
+            const uint32_t* p = Pdw + rp * PDW + q - 1;
+            uint16_t* hrow = &H[rp * HP + 4 * q];
+#pragma unroll
+            for (int i = 0; i < 9; i++) {
+                if (i < 8 || rp < PW - 40) {                      // rows 40..42 exist for phases 0..2 only
+                    unsigned o[4];
+                    hblur4(p[i * 5 * PDW], p[i * 5 * PDW + 1], p[i * 5 * PDW + 2], o);
+                    uint2 w;
+                    w.x = o[0] | (o[1] << 16);
+                    w.y = o[2] | (o[3] << 16);
+                    *reinterpret_cast<uint2*>(hrow + i * 5 * HP) = w;
+                }
+            }
+        }
     }
     __syncthreads();
 
@@ -206,10 +236,16 @@ __global__ __launch_bounds__(WAVE) void k_orient_desc(const OrbGeom G, const uin
 }
 
 void orb_launch_orient_desc(hipStream_t st, const OrbGeom& G, const uint8_t* pyr, size_t pyrSlab,
-                            const uint32_t* kpl, const int* kpCount, const int8_t* pattern,
+                            const uint32_t* kpl, const int* kpCount, const int8_t* pattern, const uint4* angTab,
                             orb_keypoint* kps, uint8_t* desc, int cap, int32_t* counts, int* errFlags,
                             int nFrames)
 {
-    hipLaunchKernelGGL(k_orient_desc, dim3(G.kpSlab, nFrames), dim3(WAVE), 0, st, G, pyr, pyrSlab, kpl, kpCount,
-                       pattern, kps, desc, cap, counts, errFlags);
+    unsigned inv = 0;
+    const unsigned wgs = orb_xcd_grid((unsigned)G.kpSlab, nFrames, &inv);
+    if (wgs)
+        hipLaunchKernelGGL(k_orient_desc, dim3(wgs), dim3(WAVE), 0, st, G, pyr, pyrSlab, kpl, kpCount, pattern, angTab, kps,
+                           desc, cap, counts, errFlags, nFrames, inv);
+    else
+        hipLaunchKernelGGL(k_orient_desc, dim3(G.kpSlab, nFrames), dim3(WAVE), 0, st, G, pyr, pyrSlab, kpl, kpCount,
+                           pattern, angTab, kps, desc, cap, counts, errFlags, nFrames, 0u);
 }

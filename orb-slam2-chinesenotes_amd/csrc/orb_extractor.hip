@@ -374,6 +374,21 @@ extern "C" int orb_extractor_create(const orb_extractor_params* p, int device_id
     if (rc == ORB_OK) {
         if (hipMemcpy(h->dPattern.p, ORB_BRIEF_PATTERN_XY, 1024, hipMemcpyHostToDevice) != hipSuccess) rc = ORB_ERR_HIP;
     }
+    if (rc == ORB_OK) rc = h->dAngTab.ensure(16 * 2 * 32);
+    if (rc == ORB_OK) {
+        // IC_Angle tables (k_orient_desc): per (|v|, half row) 16 mask bytes (1 inside |u| <= umax[|v|]) and
+        // 16 weight bytes (u + 15 inside, 0 outside) for u = -15 + 16*half + byte
+        uint8_t tab[16][2][32];
+        for (int a = 0; a < 16; a++)
+            for (int hh = 0; hh < 2; hh++)
+                for (int b = 0; b < 16; b++) {
+                    const int u = -15 + 16 * hh + b;
+                    const bool in = std::abs(u) <= h->umax[a];
+                    tab[a][hh][b] = in ? 1 : 0;
+                    tab[a][hh][16 + b] = in ? (uint8_t)(u + 15) : 0;
+                }
+        if (hipMemcpy(h->dAngTab.p, tab, sizeof(tab), hipMemcpyHostToDevice) != hipSuccess) rc = ORB_ERR_HIP;
+    }
     if (rc != ORB_OK) { orb_extractor_destroy(h); return rc; }
     h->patternPtr = (const int8_t*)h->dPattern.p;
     *out = h;
@@ -385,7 +400,7 @@ extern "C" void orb_extractor_destroy(orb_extractor* h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    DevBuf* bufs[] = {&h->dPattern, &h->dCells, &h->dXtab, &h->dYtab, &h->dXq, &h->dPath, &h->dPyr, &h->dCand, &h->dKpl,
+    DevBuf* bufs[] = {&h->dPattern, &h->dAngTab, &h->dCells, &h->dXtab, &h->dYtab, &h->dXq, &h->dPath, &h->dPyr, &h->dCand, &h->dKpl,
                       &h->dCandCount, &h->dKpCount, &h->dErr, &h->dImgs, &h->dKps, &h->dDesc, &h->dCounts,
                       &h->dStereo, &h->dStereoIn};
     for (DevBuf* b : bufs) b->release();
@@ -549,7 +564,7 @@ extern "C" int orb_extract_batch_device(orb_extractor* h, const uint8_t* d_imgs,
         if (prof) ORB_HIP_TRY(hipEventRecord(pe[2], ss));
         orb_launch_quadtree(ss, G, scand, h->candSlab, scc, skpl, skc, serr, h->sortCap, h->nodeCap, n);
         if (prof) ORB_HIP_TRY(hipEventRecord(pe[3], ss));
-        orb_launch_orient_desc(ss, G, spyr, h->pyrSlab, skpl, skc, h->patternPtr, d_kps + (size_t)cap * f0,
+        orb_launch_orient_desc(ss, G, spyr, h->pyrSlab, skpl, skc, h->patternPtr, (const uint4*)h->dAngTab.p, d_kps + (size_t)cap * f0,
                                d_desc + (size_t)ORB_DESC_BYTES * cap * f0, cap, d_counts + f0, serr, n);
         if (prof) {
             ORB_HIP_TRY(hipEventRecord(pe[4], ss));

@@ -53,7 +53,7 @@ struct orb_extractor {
     int fastMaxItemsUnused = 0;                      // largest (quads per row) x (zone rows) over the FAST cells
 
     // device memory
-    DevBuf dPattern, dCells, dXtab, dYtab, dXq, dPath;   // constants
+    DevBuf dPattern, dAngTab, dCells, dXtab, dYtab, dXq, dPath;   // constants
     std::vector<size_t> xtabOff, ytabOff;       // per level offsets (in int2 units)
     std::vector<long long> xqOff;               // per level offset into dXq (uint4 units), -1 = level not eligible
     DevBuf dPyr, dCand, dKpl, dCandCount, dKpCount, dErr;   // per-batch scratch

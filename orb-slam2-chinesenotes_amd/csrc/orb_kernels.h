@@ -15,6 +15,6 @@ void orb_launch_quadtree(hipStream_t st, const OrbGeom& G, unsigned long long* c
                          const int* candCount, uint32_t* kpl, int* kpCount, int* errFlags, int sortCap,
                          int nodeCap, int nFrames);
 void orb_launch_orient_desc(hipStream_t st, const OrbGeom& G, const uint8_t* pyr, size_t pyrSlab,
-                            const uint32_t* kpl, const int* kpCount, const int8_t* pattern,
+                            const uint32_t* kpl, const int* kpCount, const int8_t* pattern, const uint4* angTab,
                             orb_keypoint* kps, uint8_t* desc, int cap, int32_t* counts, int* errFlags,
                             int nFrames);
