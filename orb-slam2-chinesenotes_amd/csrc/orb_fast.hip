@@ -56,6 +56,12 @@ __device__ __forceinline__ unsigned pk_sub_i16(unsigned a, unsigned b)
     asm("v_pk_sub_i16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
     return d;
 }
+__device__ __forceinline__ unsigned pk_add_u16(unsigned a, unsigned b)
+{
+    unsigned d;
+    asm("v_pk_add_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
 __device__ __forceinline__ unsigned pk_max_i16(unsigned a, unsigned b)
 {
     unsigned d;
@@ -163,6 +169,7 @@ __global__ __launch_bounds__(WAVE) void k_fast_cells(const OrbGeom G, const uint
     // Only the 4 even k are used here (rows y, y+-2, y+-3: 11 dword reads instead of 21); pairs with
     // U <= lowTh in both pixels score 0 (never a corner at either threshold) and skip the exact V (about 5 in 6 pairs).
     const int lowTh = min(iniTh, minTh);
+    const unsigned thK = (unsigned)(0x7fff - lowTh) * 0x10001u;
     const int nItems = nq * zh;
     const unsigned invq = ((1u << 20) + nq - 1) / nq;
     int nA = 0, nB = 0;                                            // wave-uniform queue lengths
@@ -199,12 +206,11 @@ __global__ __launch_bounds__(WAVE) void k_fast_cells(const OrbGeom G, const uint
                 const unsigned mhi = pk_min3(pk_max2(r0, r8), pk_max2(r4, r12), pk_min2(pk_max2(r2, r10), pk_max2(r6, r14)));
                 u[h] = pk_max_i16(pk_sub_i16(cc, mlo), pk_sub_i16(mhi, cc));                  // U per 16-bit half (signed)
             }
-            // zone membership of the four pixels; a pair is queued if one of its in-zone pixels has U > lowTh
-            const int c0x = 4 * q;
-            const bool in0 = c0x >= zLo && c0x < zHi, in1 = c0x + 1 >= zLo && c0x + 1 < zHi;
-            const bool in2 = c0x + 2 >= zLo && c0x + 2 < zHi, in3 = c0x + 3 >= zLo && c0x + 3 < zHi;
-            pa = (in0 && (int)(short)(u[0] & 0xffff) > lowTh) || (in1 && (int)(short)(u[0] >> 16) > lowTh);
-            pb = (in2 && (int)(short)(u[1] & 0xffff) > lowTh) || (in3 && (int)(short)(u[1] >> 16) > lowTh);
+            // a pair is queued if one of its pixels has U > lowTh: adding 0x7fff - lowTh to a signed half in
+            // [-255, 255] sets bit 15 exactly then.  Pixels of a neighbouring cell inside an edge quad may queue
+            // a pair needlessly; phase B zeroes their scores, so zone membership is not tested here.
+            pa = (pk_add_u16(u[0], thK) & 0x80008000u) != 0;
+            pb = (pk_add_u16(u[1], thK) & 0x80008000u) != 0;
         }
         const unsigned long long ba = __ballot(pa), bb = __ballot(pb);
         const unsigned long long lt = (1ull << lane) - 1;
@@ -257,13 +263,16 @@ __global__ __launch_bounds__(WAVE) void k_fast_cells(const OrbGeom G, const uint
     uint16_t* queue = reinterpret_cast<uint16_t*>(tileDw);
     const uint8_t* smap = reinterpret_cast<const uint8_t*>(smapDw);
     const int mine = __popcll(cmask);
-    int incl = mine;
-#pragma unroll
-    for (int o = 1; o < WAVE; o <<= 1) {
-        const int v = __shfl_up(incl, o);
-        if (lane >= o) incl += v;
-    }
-    const int nCand = __shfl(incl, WAVE - 1);
+    int incl = mine;                                               // inclusive wave scan with DPP (no LDS round trips)
+#define ORB_DPP_ADD(v, ctrl, rmask) v += __builtin_amdgcn_update_dpp(0, v, ctrl, rmask, 0xf, false)
+    ORB_DPP_ADD(incl, 0x111, 0xf);
+    ORB_DPP_ADD(incl, 0x112, 0xf);
+    ORB_DPP_ADD(incl, 0x114, 0xf);
+    ORB_DPP_ADD(incl, 0x118, 0xf);
+    ORB_DPP_ADD(incl, 0x142, 0xa);
+    ORB_DPP_ADD(incl, 0x143, 0xc);
+#undef ORB_DPP_ADD
+    const int nCand = __builtin_amdgcn_readlane(incl, WAVE - 1);
     if (nCand == 0) return;
     if (nCand > 2 * tileDwords) {                                  // cannot happen: the tile region holds 2 B per zone pixel
         if (lane == 0) atomicOr(&errFlags[f], 16);
@@ -301,12 +310,12 @@ __global__ __launch_bounds__(WAVE) void k_fast_cells(const OrbGeom G, const uint
                 const uint8_t* s = smap + (ent >> 8) * FT_PITCH + (ent & 0xff);
                 const int S = s[0];
                 if (S > th) {
-                    const int sc = S - 1;
-                    int m = 0;
-#define NB(o) { const int v = s[o]; m = max(m, v > th ? v - 1 : 0); }
-                    NB(-1) NB(1) NB(-FT_PITCH - 1) NB(-FT_PITCH) NB(-FT_PITCH + 1) NB(FT_PITCH - 1) NB(FT_PITCH) NB(FT_PITCH + 1)
-#undef NB
-                    k = sc > m;
+                    // sc = S-1 must exceed max(0, scores of the neighbours above th); a neighbour at or below th
+                    // is below S anyway, so this is S > max(1, raw neighbour values)
+                    const int m0 = max(max((int)s[-FT_PITCH - 1], (int)s[-FT_PITCH]), (int)s[-FT_PITCH + 1]);
+                    const int m1 = max(max((int)s[-1], (int)s[1]), 1);
+                    const int m2 = max(max((int)s[FT_PITCH - 1], (int)s[FT_PITCH]), (int)s[FT_PITCH + 1]);
+                    k = S > max(max(m0, m1), m2);
                 }
             }
             if (k) keep |= 1ull << it;
@@ -317,7 +326,7 @@ __global__ __launch_bounds__(WAVE) void k_fast_cells(const OrbGeom G, const uint
 
     int base0 = 0;
     if (lane == 0) base0 = atomicAdd(&candCount[f * ORB_MAX_LEVELS + cell.level], total);
-    base0 = __shfl(base0, 0);
+    base0 = __builtin_amdgcn_readfirstlane(base0);
     if (base0 + total > L.candCap) {                               // cannot happen: candCap is the NMS bound
         if (lane == 0) atomicOr(&errFlags[f], 1);
         return;
