@@ -76,12 +76,13 @@ __device__ __forceinline__ bool orb_xcd_decode(unsigned id, unsigned perFrame, u
     return frame < nFrames;
 }
 #endif
-// host side: number of workgroups, or 0 when the batch is too large for the 32-bit decode
+// host side: number of workgroups, or 0 (use the plain 2-D grid) when perFrame < 2 (its inverse does not fit 32 bits)
+// or the batch is too large for the 32-bit decode
 static inline unsigned orb_xcd_grid(unsigned perFrame, int nFrames, unsigned* invPerFrame)
 {
     const unsigned long long groups = ((unsigned long long)nFrames + 7) / 8;
     const unsigned long long total = groups * 8ull * perFrame;
-    if (perFrame == 0 || total >= (1ull << 31) || groups * perFrame * (unsigned long long)perFrame >= (1ull << 32)) return 0;
+    if (perFrame < 2 || total >= (1ull << 31) || groups * perFrame * (unsigned long long)perFrame >= (1ull << 32)) return 0;
     *invPerFrame = (unsigned)(((1ull << 32) + perFrame - 1) / perFrame);
     return (unsigned)total;
 }

@@ -121,7 +121,8 @@ __global__ __launch_bounds__(WAVE) void k_fast_cells(const OrbGeom G, const uint
                                                      const uint32_t* __restrict__ pathTab,
                                                      unsigned long long* __restrict__ cand, size_t candSlab,
                                                      int* __restrict__ candCount, int* __restrict__ errFlags,
-                                                     int iniTh, int minTh, int maxItems, int pdw, int rowsMax, int tileDwords)
+                                                     int iniTh, int minTh, int maxItems, int pdw, int rowsMax, int tileDwords,
+                                                     int nCells, int nFrames, unsigned invPerFrame)
 {
     // dynamic LDS: [pad | tile (>= 2 bytes per zone pixel: it later holds the candidate queue) | pad | score map | pair queues]
     extern __shared__ uint32_t fsm[];
@@ -130,8 +131,14 @@ __global__ __launch_bounds__(WAVE) void k_fast_cells(const OrbGeom G, const uint
     uint16_t* pairQ = reinterpret_cast<uint16_t*>(smapDw + rowsMax * pdw);   // [2][maxItems]
     const int FT_PDW = pdw, FT_PITCH = 4 * pdw;
     const int lane = threadIdx.x;
-    const int f = blockIdx.y;
-    const OrbCell cell = cells[blockIdx.x];
+    int f, ci;
+    if (invPerFrame) {                                             // 1-D XCD-aware grid: a frame's cells share one L2
+        if (!orb_xcd_decode(blockIdx.x, (unsigned)nCells, invPerFrame, nFrames, f, ci)) return;
+    } else {
+        f = blockIdx.y;
+        ci = blockIdx.x;
+    }
+    const OrbCell cell = cells[ci];
     const OrbLevelGeom& L = G.L[cell.level];
     const uint8_t* img = pyr + (size_t)f * pyrSlab + L.pyrOff;
 
@@ -361,6 +368,9 @@ void orb_launch_fast_cells(hipStream_t st, const OrbGeom& G, const uint8_t* pyr,
     if (nCells == 0) return;
     const int tileDwords = std::max(rowsMax * pdw, (maxZonePx + 1) / 2);
     const size_t lds = (size_t)4 * (FT_PAD + tileDwords + FT_PAD + rowsMax * pdw) + (size_t)4 * maxItems;
-    hipLaunchKernelGGL(k_fast_cells, dim3(nCells, nFrames), dim3(WAVE), lds, st, G, pyr, pyrSlab, cells, pathTab, cand,
-                       candSlab, candCount, errFlags, iniTh, minTh, maxItems, pdw, rowsMax, tileDwords);
+    unsigned inv = 0;
+    const unsigned wgs = orb_xcd_grid((unsigned)nCells, nFrames, &inv);
+    hipLaunchKernelGGL(k_fast_cells, wgs ? dim3(wgs) : dim3(nCells, nFrames), dim3(WAVE), lds, st, G, pyr, pyrSlab, cells,
+                       pathTab, cand, candSlab, candCount, errFlags, iniTh, minTh, maxItems, pdw, rowsMax, tileDwords, nCells,
+                       nFrames, inv);
 }
