@@ -322,9 +322,7 @@ static int ensure_scratch(orb_extractor* h, int nFrames)
     if ((rc = h->dPyr.ensure(h->pyrSlab * nFrames + 256)) != ORB_OK) return rc;   // + slack: window loads overrun a row by <= 11 B
     if ((rc = h->dCand.ensure(h->candSlab * 8 * nFrames)) != ORB_OK) return rc;
     if ((rc = h->dKpl.ensure((size_t)h->G.kpSlab * 4 * nFrames)) != ORB_OK) return rc;
-    if ((rc = h->dCandCount.ensure((size_t)ORB_MAX_LEVELS * 4 * nFrames)) != ORB_OK) return rc;
-    if ((rc = h->dKpCount.ensure((size_t)ORB_MAX_LEVELS * 4 * nFrames)) != ORB_OK) return rc;
-    if ((rc = h->dErr.ensure((size_t)4 * nFrames)) != ORB_OK) return rc;
+    if ((rc = h->dStat.ensure(orb_extractor::statInts(nFrames) * 4)) != ORB_OK) return rc;
     h->framesCap = nFrames;
     return ORB_OK;
 }
@@ -363,13 +361,6 @@ extern "C" int orb_extractor_create(const orb_extractor_params* p, int device_id
     for (int k = 0; k < orb_extractor::kProfSlots; k++)
         for (int i = 0; i < 5; i++) (void)hipEventCreate(&h->ev[k][i]);
     (void)hipEventCreateWithFlags(&h->waitEv, hipEventDisableTiming);
-    (void)hipEventCreateWithFlags(&h->forkEv, hipEventDisableTiming);
-    for (int i = 0; i < orb_extractor::kMaxSub; i++) {
-        (void)hipStreamCreateWithFlags(&h->sub[i], hipStreamNonBlocking);
-        (void)hipEventCreateWithFlags(&h->joinEv[i], hipEventDisableTiming);
-    }
-    if (const char* e = getenv("ORB_SUBBATCHES")) h->maxSub = std::max(1, std::min((int)orb_extractor::kMaxSub, atoi(e)));
-    if (const char* e = getenv("ORB_SUBBATCH_MIN")) h->minSubFrames = std::max(1, atoi(e));
     int rc = h->dPattern.ensure(1024);
     if (rc == ORB_OK) {
         if (hipMemcpy(h->dPattern.p, ORB_BRIEF_PATTERN_XY, 1024, hipMemcpyHostToDevice) != hipSuccess) rc = ORB_ERR_HIP;
@@ -401,18 +392,14 @@ extern "C" void orb_extractor_destroy(orb_extractor* h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     DevBuf* bufs[] = {&h->dPattern, &h->dAngTab, &h->dCells, &h->dXtab, &h->dYtab, &h->dXq, &h->dPath, &h->dPyr, &h->dCand, &h->dKpl,
-                      &h->dCandCount, &h->dKpCount, &h->dErr, &h->dImgs, &h->dKps, &h->dDesc, &h->dCounts,
+                      &h->dStat, &h->dImgs, &h->dKps, &h->dDesc, &h->dCounts,
                       &h->dStereo, &h->dStereoIn};
     for (DevBuf* b : bufs) b->release();
     for (int k = 0; k < orb_extractor::kProfSlots; k++)
         for (int i = 0; i < 5; i++)
             if (h->ev[k][i]) (void)hipEventDestroy(h->ev[k][i]);
     if (h->waitEv) (void)hipEventDestroy(h->waitEv);
-    if (h->forkEv) (void)hipEventDestroy(h->forkEv);
-    for (int i = 0; i < orb_extractor::kMaxSub; i++) {
-        if (h->sub[i]) { (void)hipStreamSynchronize(h->sub[i]); (void)hipStreamDestroy(h->sub[i]); }
-        if (h->joinEv[i]) (void)hipEventDestroy(h->joinEv[i]);
-    }
+    if (h->hStage) (void)hipHostFree(h->hStage);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -526,58 +513,62 @@ extern "C" int orb_extract_batch_device(orb_extractor* h, const uint8_t* d_imgs,
     hipStream_t st = h->stream;
     uint8_t* pyr = (uint8_t*)h->dPyr.p;
 
-    // Frames are independent, and the stages are bound by different units (pyramid: memory latency,
-    // FAST: VALU issue, descriptors: LDS), so a large batch is cut into sub-batches that run the whole
-    // chain on separate streams and overlap each other's stages.  Stage events are recorded around
-    // sub-batch 0 only (h->profFrames = frames in it).
-    int nSub = 1;
-    if (h->maxSub > 1 && nFrames >= 2 * h->minSubFrames) nSub = std::min(h->maxSub, nFrames / h->minSubFrames);
-    if (nSub > 1) {
-        ORB_HIP_TRY(hipEventRecord(h->forkEv, st));
-        for (int s = 0; s < nSub; s++) ORB_HIP_TRY(hipStreamWaitEvent(h->sub[s], h->forkEv, 0));
-    }
+    // (Cutting a large batch into sub-batches on several streams was measured: no gain, every kernel already fills
+    // the chip -- one stream, one launch chain.)
+    h->lastFrames = nFrames;                                   // fixes the layout of the status block
+    h->statFetched = false;
+    const int n = nFrames;
+    int* scc = h->candCountP();
+    int* skc = h->kpCountP();
+    int* serr = h->errP();
+    unsigned long long* scand = (unsigned long long*)h->dCand.p;
+    uint32_t* skpl = (uint32_t*)h->dKpl.p;
+    const bool prof = h->profiling;
     hipEvent_t* pe = h->ev[h->profCount % orb_extractor::kProfSlots];
-    for (int s = 0; s < nSub; s++) {
-        const int f0 = (int)((long long)nFrames * s / nSub), f1 = (int)((long long)nFrames * (s + 1) / nSub);
-        const int n = f1 - f0;
-        hipStream_t ss = nSub > 1 ? h->sub[s] : st;
-        const bool prof = h->profiling && s == 0;
-        uint8_t* spyr = pyr + h->pyrSlab * f0;
-        unsigned long long* scand = (unsigned long long*)h->dCand.p + h->candSlab * f0;
-        int* scc = (int*)h->dCandCount.p + (size_t)ORB_MAX_LEVELS * f0;
-        int* skc = (int*)h->dKpCount.p + (size_t)ORB_MAX_LEVELS * f0;
-        int* serr = (int*)h->dErr.p + f0;
-        uint32_t* skpl = (uint32_t*)h->dKpl.p + (size_t)G.kpSlab * f0;
-        ORB_HIP_TRY(hipMemsetAsync(scc, 0, (size_t)ORB_MAX_LEVELS * 4 * n, ss));
-        ORB_HIP_TRY(hipMemsetAsync(serr, 0, (size_t)4 * n, ss));
-        if (prof) ORB_HIP_TRY(hipEventRecord(pe[0], ss));
-        orb_launch_copy_level0(ss, d_imgs + frameStride * f0, rowStride, frameStride, spyr, h->pyrSlab, G.L[0].w, G.L[0].h,
-                               G.L[0].pitch, n);
-        for (int l = 1; l < G.nlevels; l++)
-            orb_launch_resize(ss, spyr, h->pyrSlab, G.L[l - 1], G.L[l], (const int2*)h->dXtab.p + h->xtabOff[l],
-                              (const int2*)h->dYtab.p + h->ytabOff[l],
-                              h->xqOff[l] >= 0 ? (const uint4*)h->dXq.p + h->xqOff[l] : nullptr, n);
-        if (prof) ORB_HIP_TRY(hipEventRecord(pe[1], ss));
-        orb_launch_fast_cells(ss, G, spyr, h->pyrSlab, (const OrbCell*)h->dCells.p, (int)h->cells.size(),
-                              (const uint32_t*)h->dPath.p, scand, h->candSlab, scc, serr, h->prm.ini_th_fast,
-                              h->prm.min_th_fast, h->fastMaxItems, h->fastPdw, h->fastRows, h->fastMaxZone, n);
-        if (prof) ORB_HIP_TRY(hipEventRecord(pe[2], ss));
-        orb_launch_quadtree(ss, G, scand, h->candSlab, scc, skpl, skc, serr, h->sortCap, h->nodeCap, n);
-        if (prof) ORB_HIP_TRY(hipEventRecord(pe[3], ss));
-        orb_launch_orient_desc(ss, G, spyr, h->pyrSlab, skpl, skc, h->patternPtr, (const uint4*)h->dAngTab.p, d_kps + (size_t)cap * f0,
-                               d_desc + (size_t)ORB_DESC_BYTES * cap * f0, cap, d_counts + f0, serr, n);
-        if (prof) {
-            ORB_HIP_TRY(hipEventRecord(pe[4], ss));
-            h->profCount++;
-            h->profFrames = n;
-        }
-        if (nSub > 1) {
-            ORB_HIP_TRY(hipEventRecord(h->joinEv[s], ss));
-            ORB_HIP_TRY(hipStreamWaitEvent(st, h->joinEv[s], 0));
-        }
+    ORB_HIP_TRY(hipMemsetAsync(h->dStat.p, 0, orb_extractor::statInts(n) * 4, st));
+    if (prof) ORB_HIP_TRY(hipEventRecord(pe[0], st));
+    orb_launch_copy_level0(st, d_imgs, rowStride, frameStride, pyr, h->pyrSlab, G.L[0].w, G.L[0].h, G.L[0].pitch, n);
+    for (int l = 1; l < G.nlevels; l++)
+        orb_launch_resize(st, pyr, h->pyrSlab, G.L[l - 1], G.L[l], (const int2*)h->dXtab.p + h->xtabOff[l],
+                          (const int2*)h->dYtab.p + h->ytabOff[l],
+                          h->xqOff[l] >= 0 ? (const uint4*)h->dXq.p + h->xqOff[l] : nullptr, n);
+    if (prof) ORB_HIP_TRY(hipEventRecord(pe[1], st));
+    orb_launch_fast_cells(st, G, pyr, h->pyrSlab, (const OrbCell*)h->dCells.p, (int)h->cells.size(),
+                          (const uint32_t*)h->dPath.p, scand, h->candSlab, scc, serr, h->prm.ini_th_fast,
+                          h->prm.min_th_fast, h->fastMaxItems, h->fastPdw, h->fastRows, h->fastMaxZone, n);
+    if (prof) ORB_HIP_TRY(hipEventRecord(pe[2], st));
+    orb_launch_quadtree(st, G, scand, h->candSlab, scc, skpl, skc, serr, h->sortCap, h->nodeCap, n);
+    if (prof) ORB_HIP_TRY(hipEventRecord(pe[3], st));
+    orb_launch_orient_desc(st, G, pyr, h->pyrSlab, skpl, skc, h->patternPtr, (const uint4*)h->dAngTab.p, d_kps, d_desc, cap,
+                           d_counts, serr, n);
+    if (prof) {
+        ORB_HIP_TRY(hipEventRecord(pe[4], st));
+        h->profCount++;
+        h->profFrames = n;
     }
     ORB_HIP_TRY(hipGetLastError());
-    h->lastFrames = nFrames;
+    return ORB_OK;
+}
+
+// host-side part of a sync: interpret the status block (already in h->hStat)
+static int check_status(orb_extractor* h)
+{
+    const int n = h->lastFrames;
+    const int* err = h->hStat.data();
+    const int* cand = err + n;
+    if (!h->sortCapFixed) {                            // adapt the quadtree's LDS sort capacity to the data
+        int mx = 0;
+        for (size_t i = 0; i < (size_t)ORB_MAX_LEVELS * n; i++) mx = std::max(mx, cand[i]);
+        int want = 1024;
+        while (want < mx && want < 4096) want <<= 1;
+        while (want > 256 && orb_quadtree_lds_bytes(want, h->nodeCap) > 60 * 1024) want >>= 1;
+        if (want > h->sortCap) h->sortCap = want;
+    }
+    for (int f = 0; f < n; f++)
+        if (err[f]) {
+            orb_set_error("device-side overflow flag 0x%x on frame %d (1 candidates, 2 nodes, 4 output cap)", err[f], f);
+            return (err[f] & 4) ? ORB_ERR_CAPACITY : ORB_ERR_INTERNAL;
+        }
     return ORB_OK;
 }
 
@@ -586,30 +577,29 @@ extern "C" int orb_extractor_sync(orb_extractor* h)
     if (!h) return ORB_ERR_INVALID;
     ORB_HIP_TRY(hipSetDevice(h->device));
     ORB_HIP_TRY(hipStreamSynchronize(h->stream));
-    if (h->lastFrames > 0) {
-        h->hErr.resize(h->lastFrames);
-        ORB_HIP_TRY(hipMemcpy(h->hErr.data(), h->dErr.p, (size_t)4 * h->lastFrames, hipMemcpyDeviceToHost));
-        if (!h->sortCapFixed) {                        // adapt the quadtree's LDS sort capacity to the data
-            h->hErr.resize((size_t)ORB_MAX_LEVELS * h->lastFrames);
-            ORB_HIP_TRY(hipMemcpy(h->hErr.data(), h->dCandCount.p, (size_t)4 * ORB_MAX_LEVELS * h->lastFrames, hipMemcpyDeviceToHost));
-            int mx = 0;
-            for (size_t i = 0; i < h->hErr.size(); i++) mx = std::max(mx, h->hErr[i]);
-            int want = 1024;
-            while (want < mx && want < 4096) want <<= 1;
-            while (want > 256 && orb_quadtree_lds_bytes(want, h->nodeCap) > 60 * 1024) want >>= 1;
-            if (want > h->sortCap) h->sortCap = want;
-            h->hErr.resize(h->lastFrames);
-            ORB_HIP_TRY(hipMemcpy(h->hErr.data(), h->dErr.p, (size_t)4 * h->lastFrames, hipMemcpyDeviceToHost));
-        }
-        for (int f = 0; f < h->lastFrames; f++)
-            if (h->hErr[f]) {
-                orb_set_error("device-side overflow flag 0x%x on frame %d (1 candidates, 2 nodes, 4 output cap)", h->hErr[f], f);
-                return (h->hErr[f] & 4) ? ORB_ERR_CAPACITY : ORB_ERR_INTERNAL;
-            }
+    if (h->lastFrames > 0 && !h->statFetched) {
+        h->hStat.resize(orb_extractor::statInts(h->lastFrames));
+        ORB_HIP_TRY(hipMemcpy(h->hStat.data(), h->dStat.p, h->hStat.size() * 4, hipMemcpyDeviceToHost));
+        h->statFetched = true;
+        return check_status(h);
     }
     return ORB_OK;
 }
 
+static int ensure_stage(orb_extractor* h, size_t bytes)
+{
+    if (bytes <= h->hStageBytes) return ORB_OK;
+    if (h->hStage) { (void)hipHostFree(h->hStage); h->hStage = nullptr; h->hStageBytes = 0; }
+    ORB_HIP_TRY(hipHostMalloc(&h->hStage, bytes, hipHostMallocDefault));
+    h->hStageBytes = bytes;
+    return ORB_OK;
+}
+
+// Host-buffer entry: H2D, the launch chain, and ONE round trip back.  Status words, keypoints and descriptors are
+// fetched with three asynchronous copies into pinned staging followed by a single stream synchronisation (the
+// capacity-sized slabs are copied whole; 66 KB per frame at nFeatures = 1000), then the valid prefixes are
+// memcpy'd into the caller's (pageable) buffers.  Batches whose slabs exceed kStageLimit fall back to
+// count-then-copy per frame.
 extern "C" int orb_extract_batch(orb_extractor* h, const uint8_t* imgs, int nFrames, int rows, int cols,
                                  size_t rowStride, size_t frameStride, orb_keypoint* kps, uint8_t* desc, int cap,
                                  int32_t* counts)
@@ -628,24 +618,59 @@ extern "C" int orb_extract_batch(orb_extractor* h, const uint8_t* imgs, int nFra
     if ((rc = h->dKps.ensure(sizeof(orb_keypoint) * (size_t)cap * nFrames)) != ORB_OK) return rc;
     if ((rc = h->dDesc.ensure((size_t)ORB_DESC_BYTES * cap * nFrames)) != ORB_OK) return rc;
     if ((rc = h->dCounts.ensure((size_t)4 * nFrames)) != ORB_OK) return rc;
-    for (int f = 0; f < nFrames; f++)
-        ORB_HIP_TRY(hipMemcpy2DAsync((uint8_t*)h->dImgs.p + imgBytes * f, cols, imgs + frameStride * f, rowStride,
-                                     cols, rows, hipMemcpyHostToDevice, h->stream));
+    if (rowStride == (size_t)cols && (frameStride == imgBytes || nFrames == 1)) {
+        // contiguous frames: one linear copy (a 2-D copy of an odd width such as 1241 takes a slow row-wise path)
+        ORB_HIP_TRY(hipMemcpyAsync(h->dImgs.p, imgs, imgBytes * nFrames, hipMemcpyHostToDevice, h->stream));
+    } else {
+        for (int f = 0; f < nFrames; f++) {
+            if (rowStride == (size_t)cols)
+                ORB_HIP_TRY(hipMemcpyAsync((uint8_t*)h->dImgs.p + imgBytes * f, imgs + frameStride * f, imgBytes,
+                                           hipMemcpyHostToDevice, h->stream));
+            else
+                ORB_HIP_TRY(hipMemcpy2DAsync((uint8_t*)h->dImgs.p + imgBytes * f, cols, imgs + frameStride * f, rowStride,
+                                             cols, rows, hipMemcpyHostToDevice, h->stream));
+        }
+    }
     rc = orb_extract_batch_device(h, (const uint8_t*)h->dImgs.p, nFrames, rows, cols, cols, imgBytes,
                                   (orb_keypoint*)h->dKps.p, (uint8_t*)h->dDesc.p, cap, (int32_t*)h->dCounts.p);
     if (rc != ORB_OK) return rc;
-    ORB_HIP_TRY(hipMemcpyAsync(counts, h->dCounts.p, (size_t)4 * nFrames, hipMemcpyDeviceToHost, h->stream));
-    if ((rc = orb_extractor_sync(h)) != ORB_OK) return rc;
+    if (h->lastFrames == 0) {                                  // nothing was launched
+        for (int f = 0; f < nFrames; f++) counts[f] = 0;
+        return ORB_OK;
+    }
+    const size_t kStageLimit = (size_t)96 << 20;
+    const size_t statB = orb_extractor::statInts(nFrames) * 4, cntB = (size_t)4 * nFrames;
+    const size_t kpB = sizeof(orb_keypoint) * (size_t)cap * nFrames, dsB = (size_t)ORB_DESC_BYTES * cap * nFrames;
+    const bool whole = statB + cntB + kpB + dsB <= kStageLimit;
+    if ((rc = ensure_stage(h, whole ? statB + cntB + kpB + dsB : statB + cntB)) != ORB_OK) return rc;
+    uint8_t* stg = (uint8_t*)h->hStage;
+    ORB_HIP_TRY(hipMemcpyAsync(stg, h->dStat.p, statB, hipMemcpyDeviceToHost, h->stream));
+    ORB_HIP_TRY(hipMemcpyAsync(stg + statB, h->dCounts.p, cntB, hipMemcpyDeviceToHost, h->stream));
+    if (whole) {
+        ORB_HIP_TRY(hipMemcpyAsync(stg + statB + cntB, h->dKps.p, kpB, hipMemcpyDeviceToHost, h->stream));
+        ORB_HIP_TRY(hipMemcpyAsync(stg + statB + cntB + kpB, h->dDesc.p, dsB, hipMemcpyDeviceToHost, h->stream));
+    }
+    ORB_HIP_TRY(hipStreamSynchronize(h->stream));
+    h->hStat.assign((const int*)stg, (const int*)stg + orb_extractor::statInts(nFrames));
+    h->statFetched = true;
+    std::memcpy(counts, stg + statB, cntB);
+    if ((rc = check_status(h)) != ORB_OK) return rc;
     for (int f = 0; f < nFrames; f++) {
         const int n = counts[f];
         if (n <= 0) continue;
-        ORB_HIP_TRY(hipMemcpyAsync(kps + (size_t)cap * f, (orb_keypoint*)h->dKps.p + (size_t)cap * f,
-                                   sizeof(orb_keypoint) * n, hipMemcpyDeviceToHost, h->stream));
-        ORB_HIP_TRY(hipMemcpyAsync(desc + (size_t)ORB_DESC_BYTES * cap * f,
-                                   (uint8_t*)h->dDesc.p + (size_t)ORB_DESC_BYTES * cap * f,
-                                   (size_t)ORB_DESC_BYTES * n, hipMemcpyDeviceToHost, h->stream));
+        if (whole) {
+            std::memcpy(kps + (size_t)cap * f, stg + statB + cntB + sizeof(orb_keypoint) * (size_t)cap * f, sizeof(orb_keypoint) * n);
+            std::memcpy(desc + (size_t)ORB_DESC_BYTES * cap * f, stg + statB + cntB + kpB + (size_t)ORB_DESC_BYTES * cap * f,
+                        (size_t)ORB_DESC_BYTES * n);
+        } else {
+            ORB_HIP_TRY(hipMemcpyAsync(kps + (size_t)cap * f, (orb_keypoint*)h->dKps.p + (size_t)cap * f,
+                                       sizeof(orb_keypoint) * n, hipMemcpyDeviceToHost, h->stream));
+            ORB_HIP_TRY(hipMemcpyAsync(desc + (size_t)ORB_DESC_BYTES * cap * f,
+                                       (uint8_t*)h->dDesc.p + (size_t)ORB_DESC_BYTES * cap * f,
+                                       (size_t)ORB_DESC_BYTES * n, hipMemcpyDeviceToHost, h->stream));
+        }
     }
-    ORB_HIP_TRY(hipStreamSynchronize(h->stream));
+    if (!whole) ORB_HIP_TRY(hipStreamSynchronize(h->stream));
     return ORB_OK;
 }
 
@@ -682,11 +707,11 @@ extern "C" int orb_get_level_counts(orb_extractor* h, int frame, int32_t* kept, 
     ORB_HIP_TRY(hipStreamSynchronize(h->stream));
     int32_t buf[ORB_MAX_LEVELS];
     if (kept) {
-        ORB_HIP_TRY(hipMemcpy(buf, (const int*)h->dKpCount.p + (size_t)ORB_MAX_LEVELS * frame, sizeof(buf), hipMemcpyDeviceToHost));
+        ORB_HIP_TRY(hipMemcpy(buf, h->kpCountP() + (size_t)ORB_MAX_LEVELS * frame, sizeof(buf), hipMemcpyDeviceToHost));
         for (int l = 0; l < h->prm.nlevels; l++) kept[l] = buf[l];
     }
     if (cands) {
-        ORB_HIP_TRY(hipMemcpy(buf, (const int*)h->dCandCount.p + (size_t)ORB_MAX_LEVELS * frame, sizeof(buf), hipMemcpyDeviceToHost));
+        ORB_HIP_TRY(hipMemcpy(buf, h->candCountP() + (size_t)ORB_MAX_LEVELS * frame, sizeof(buf), hipMemcpyDeviceToHost));
         for (int l = 0; l < h->prm.nlevels; l++) cands[l] = buf[l];
     }
     return ORB_OK;

@@ -29,11 +29,8 @@ struct orb_extractor {
     hipStream_t stream = nullptr;
     static const int kProfSlots = 64;
     hipEvent_t ev[kProfSlots][5];           // ring of per-batch stage boundaries
-    hipEvent_t waitEv = nullptr, forkEv = nullptr;
-    static const int kMaxSub = 8;
-    hipStream_t sub[kMaxSub] = {};
-    hipEvent_t joinEv[kMaxSub] = {};
-    int maxSub = 1, minSubFrames = 32, profFrames = 0;   // sub-batching measured: no gain on MI355X (kernels already fill the chip)
+    hipEvent_t waitEv = nullptr;
+    int profFrames = 0;
     bool profiling = false;
     int profCount = 0;                      // batches recorded since profiling was (re)enabled
 
@@ -50,17 +47,26 @@ struct orb_extractor {
     int sortCap = 4096, nodeCap = 0, maxKp = 0;
     bool sortCapFixed = false;
     int fastMaxItems = 64, fastPdw = 18, fastRows = 66, fastMaxZone = 3600;   // LDS sizing of k_fast_cells
-    int fastMaxItemsUnused = 0;                      // largest (quads per row) x (zone rows) over the FAST cells
 
     // device memory
     DevBuf dPattern, dAngTab, dCells, dXtab, dYtab, dXq, dPath;   // constants
     std::vector<size_t> xtabOff, ytabOff;       // per level offsets (in int2 units)
     std::vector<long long> xqOff;               // per level offset into dXq (uint4 units), -1 = level not eligible
-    DevBuf dPyr, dCand, dKpl, dCandCount, dKpCount, dErr;   // per-batch scratch
+    DevBuf dPyr, dCand, dKpl;                   // per-batch scratch
+    // per-batch status words, ONE allocation so that one memset clears it and one copy fetches it:
+    // [err: n][FAST candidates per level: 8n][keypoints per level: 8n] for the n frames of the current batch
+    DevBuf dStat;
+    int* errP() const { return (int*)dStat.p; }
+    int* candCountP() const { return (int*)dStat.p + lastFrames; }
+    int* kpCountP() const { return (int*)dStat.p + (size_t)(1 + ORB_MAX_LEVELS) * lastFrames; }
+    static size_t statInts(int n) { return (size_t)(1 + 2 * ORB_MAX_LEVELS) * n; }
     DevBuf dImgs, dKps, dDesc, dCounts;         // staging for the host-buffer API
     DevBuf dStereo, dStereoIn;                  // stereo search: (SAD, index) pairs; host-API staging
     const int8_t* patternPtr = nullptr;         // device pointer in use (own copy or caller's)
     int framesCap = 0, lastFrames = 0;
-    std::vector<int> hErr;
+    std::vector<int> hStat;                     // host copy of dStat (orb_extractor_sync)
+    bool statFetched = false;
+    void* hStage = nullptr;                     // pinned staging of the host-buffer API
+    size_t hStageBytes = 0;
 };
 
