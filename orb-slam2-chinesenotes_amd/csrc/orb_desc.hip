@@ -197,13 +197,17 @@ __global__ __launch_bounds__(WAVE) void k_orient_desc(const OrbGeom G, const uin
     float a, b;
     orb_sincos(rad, &a, &b);
     // blurred sample at pattern point (px,py) rotated by the keypoint angle (GET_VALUE, :132-134)
-    const uint16_t* Hc = H + xoff + PR;                // Hc[row*HP + ic] = row-blurred patch at column 21+ic
+    // cvRound(float) = round half to even = what adding 1.5 * 2^23 does to the mantissa (|value| < 2^22): the low
+    // bits of the sum ARE the integer (biased by 0x4B400000), so rounding costs one v_add_f32 per coordinate and the
+    // biases fold into one wave-uniform constant of the LDS index (all arithmetic mod 2^32).
+    const unsigned kBias = 0x4B400000u;
+    const unsigned idxC = (unsigned)((PR - 3) * HP + xoff + PR) - kBias * (unsigned)HP - kBias;
     auto sample = [&](int pxi, int pyi) -> int {
         const float px = (float)pxi, py = (float)pyi;
         const float fr = __fadd_rn(__fmul_rn(px, b), __fmul_rn(py, a));
         const float fc = __fsub_rn(__fmul_rn(px, a), __fmul_rn(py, b));
-        const int ir = __float2int_rn(fr), ic = __float2int_rn(fc);
-        const uint16_t* h = Hc + (PR + ir - 3) * HP + ic;
+        const unsigned br = __float_as_uint(__fadd_rn(fr, 12582912.f)), bc = __float_as_uint(__fadd_rn(fc, 12582912.f));
+        const uint16_t* h = H + (int)(br * (unsigned)HP + bc + idxC);      // = H[(21 + ir - 3) * HP + xoff + 21 + ic]
         const int acc = 18 * (h[0] + h[6 * HP]) + 34 * (h[HP] + h[5 * HP]) + 49 * (h[2 * HP] + h[4 * HP]) + 55 * h[3 * HP];
         return min(255, (acc + 32768) >> 16);
     };
