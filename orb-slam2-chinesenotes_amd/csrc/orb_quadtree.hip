@@ -1,7 +1,7 @@
 // orb_quadtree.hip -- quadtree keypoint distribution on gfx950.
 // Reference: ORBextractor::DistributeOctTree src/ORBextractor.cc:562-792, ExtractorNode::DivideNode :436-495.
 //
-// One 256-thread workgroup per (frame, level).
+// One 256-thread workgroup per (frame, level); grid (frames, levels), see k_quadtree.
 //
 // The reference splits std::list nodes and copies key vectors.  Here every candidate carries its
 // quadrant path (k_fast_cells), so after ONE sort by key every node of the tree -- at any depth --
@@ -126,12 +126,15 @@ __device__ int qt_scan(int* a, int n, int* part)
     if (t < 64) {                                      // T == 256: each of 64 lanes owns 4 partials
         const int q0 = part[4 * t], q1 = part[4 * t + 1], q2 = part[4 * t + 2], q3 = part[4 * t + 3];
         const int mine = q0 + q1 + q2 + q3;
-        int incl = mine;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int v = __shfl_up(incl, o);
-            if (t >= o) incl += v;
-        }
+        int incl = mine;                               // inclusive wave scan with DPP (row_shr 1,2,4,8, row_bcast 15/31)
+#define ORB_DPP_ADD(v, ctrl, rmask) v += __builtin_amdgcn_update_dpp(0, v, ctrl, rmask, 0xf, false)
+        ORB_DPP_ADD(incl, 0x111, 0xf);
+        ORB_DPP_ADD(incl, 0x112, 0xf);
+        ORB_DPP_ADD(incl, 0x114, 0xf);
+        ORB_DPP_ADD(incl, 0x118, 0xf);
+        ORB_DPP_ADD(incl, 0x142, 0xa);
+        ORB_DPP_ADD(incl, 0x143, 0xc);
+#undef ORB_DPP_ADD
         const int ex = incl - mine;
         part[4 * t] = ex; part[4 * t + 1] = ex + q0; part[4 * t + 2] = ex + q0 + q1; part[4 * t + 3] = ex + q0 + q1 + q2;
         if (t == 63) part[T] = incl;
@@ -371,7 +374,10 @@ __global__ __launch_bounds__(256) void k_quadtree(const OrbGeom G, unsigned long
     int* part = vb + nodeCap;
     __shared__ int sh[8];                              // size, prevCount, state (0 full pass, 1 careful, 2 done), inB, prevInB, tstar
 
-    const int level = blockIdx.x, f = blockIdx.y;
+    // grid = (frames, levels): workgroups are dealt round-robin over the 8 XCDs in linear order, so with the frame
+    // index fastest every XCD gets the same mix of levels (level fastest would send ALL level-0 workgroups, the
+    // longest ones, to one XCD), and the big levels are dispatched first (longest-processing-time-first).
+    const int level = blockIdx.y, f = blockIdx.x;
     const OrbLevelGeom& L = G.L[level];
     const int tid = threadIdx.x, T = blockDim.x;
     int n = candCount[f * ORB_MAX_LEVELS + level];
@@ -400,6 +406,6 @@ void orb_launch_quadtree(hipStream_t st, const OrbGeom& G, unsigned long long* c
                          int nodeCap, int nFrames)
 {
     const size_t lds = orb_quadtree_lds_bytes(sortCap, nodeCap);
-    hipLaunchKernelGGL(k_quadtree, dim3(G.nlevels, nFrames), dim3(256), lds, st, G, cand, candSlab, candCount,
+    hipLaunchKernelGGL(k_quadtree, dim3(nFrames, G.nlevels), dim3(256), lds, st, G, cand, candSlab, candCount,
                        kpl, kpCount, errFlags, sortCap, nodeCap);
 }
