@@ -6,6 +6,7 @@
 // a window query are a contiguous range per column ix, already in the reference's iteration order (ix outer, iy
 // inner, insertion order inside a cell).
 #pragma once
+#include "orb_block_sort.h"
 #include "orb_common.h"
 
 #define GRID_COLS 64
@@ -18,33 +19,6 @@ static __device__ __forceinline__ void load_desc8(const uint8_t* p, uint32_t v[8
     const uint4 lo = reinterpret_cast<const uint4*>(p)[0], hi = reinterpret_cast<const uint4*>(p)[1];
     v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w;
     v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
-}
-
-// ascending bitonic sort (all merges ascending, virtual +inf padding), one workgroup
-static __device__ void block_sort_u32(uint32_t* a, int n)
-{
-    int np2 = 1;
-    while (np2 < n) np2 <<= 1;
-    for (int k = 2; k <= np2; k <<= 1) {
-        for (int i = threadIdx.x; i < np2; i += blockDim.x) {
-            const int p = i ^ (k - 1);
-            if (p > i && p < n) {
-                const uint32_t x = a[i], y = a[p];
-                if (x > y) { a[i] = y; a[p] = x; }
-            }
-        }
-        __syncthreads();
-        for (int j = k >> 2; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < np2; i += blockDim.x) {
-                const int p = i ^ j;
-                if (p > i && p < n) {
-                    const uint32_t x = a[i], y = a[p];
-                    if (x > y) { a[i] = y; a[p] = x; }
-                }
-            }
-            __syncthreads();
-        }
-    }
 }
 
 // keys[k] = cell<<16 | index for the level-0 keypoints of frame 2 that fall inside the grid
@@ -67,7 +41,7 @@ static __global__ __launch_bounds__(256) void k_init_grid(const orb_keypoint* __
     }
     __syncthreads();
     const int n = cnt;
-    block_sort_u32(keys, n);                                       // global memory, one workgroup
+    orb_block_sort(keys, n);                                       // global memory, one workgroup
     if (threadIdx.x == 0) *nKeys = n;
 }
 

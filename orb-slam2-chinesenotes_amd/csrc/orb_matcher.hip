@@ -17,6 +17,7 @@
 #include <new>
 #include <vector>
 
+#include "orb_block_sort.h"
 #include "orb_matcher_internal.h"
 
 #pragma clang fp contract(off)
@@ -160,33 +161,6 @@ __device__ __forceinline__ unsigned wave_umin_dpp(unsigned v)
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
-// ascending bitonic sort of a[0..n) (u32) by the whole block, virtual +inf padding
-__device__ void block_sort_u32(uint32_t* a, int n)
-{
-    int np2 = 1;
-    while (np2 < n) np2 <<= 1;
-    for (int k = 2; k <= np2; k <<= 1) {
-        for (int i = threadIdx.x; i < np2; i += blockDim.x) {
-            const int p = i ^ (k - 1);
-            if (p > i && p < n) {
-                const uint32_t x = a[i], y = a[p];
-                if (x > y) { a[i] = y; a[p] = x; }
-            }
-        }
-        __syncthreads();
-        for (int j = k >> 2; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < np2; i += blockDim.x) {
-                const int p = i ^ j;
-                if (p > i && p < n) {
-                    const uint32_t x = a[i], y = a[p];
-                    if (x > y) { a[i] = y; a[p] = x; }
-                }
-            }
-            __syncthreads();
-        }
-    }
-}
-
 // One side's feature vector as CSR in LDS: keys = (node << 16 | index), sorted -> node-major, ascending
 // index inside a node (DBoW2's push order); start[node] / cnt[node] from the run boundaries.
 __device__ void build_csr(const uint16_t* __restrict__ nodeOf, int n, int nNodes, uint32_t* keys, uint16_t* start,
@@ -198,7 +172,7 @@ __device__ void build_csr(const uint16_t* __restrict__ nodeOf, int n, int nNodes
         keys[i] = ((nd < (unsigned)nNodes ? nd : 0xFFFFu) << 16) | (unsigned)i;   // node-less features sort last
     }
     __syncthreads();
-    block_sort_u32(keys, n);
+    orb_block_sort(keys, n);
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         const unsigned nd = keys[i] >> 16;
         if (nd < (unsigned)nNodes && (i == 0 || (keys[i - 1] >> 16) != nd)) start[nd] = (uint16_t)i;

@@ -14,6 +14,7 @@
 //     reverse(children in creation order) ++ (untouched single-key nodes in old order);
 //   * the careful phase sorts (size, seq) with the block bitonic sort, divides ALL candidates
 //     in parallel, and a scan of the size gains finds where the reference's `break` (:758) falls.
+#include "orb_block_sort.h"
 #include "orb_kernels.h"
 
 struct QtNode {
@@ -48,69 +49,6 @@ __device__ __forceinline__ int3 qt_cuts(const unsigned long long* keys, const Qt
         c.z = qt_lower(keys, c.y, nd.hi, nd.depth, 3);
     }
     return c;
-}
-
-// ascending bitonic sort of a[0..n) for arbitrary n (all merges ascending, virtual +inf padding).
-// The sort is latency-bound (one dependent LDS round trip + barrier per step), so the steps are arranged to need
-// few round trips: a step is indexed by PAIR (no idle half of the threads) and a thread loads all its operands
-// before it stores any; the steps with partner distance 2 and 1 (and the whole k = 2, 4 stages) run in registers
-// on 4 consecutive elements per thread.
-#define QT_CX(x, y) { if (x > y) { const unsigned long long t_ = x; x = y; y = t_; } }
-
-// steps on groups of 4 consecutive elements: first = true runs stages k = 2 and k = 4, else the j = 2, 1 tail
-__device__ __forceinline__ void qt_sort_local4(unsigned long long* a, int n, int np2, bool first)
-{
-    for (int g = threadIdx.x * 4; g < np2; g += blockDim.x * 4) {
-        if (g < n) {
-            const unsigned long long inf = ~0ull;
-            unsigned long long v0 = a[g], v1 = g + 1 < n ? a[g + 1] : inf, v2 = g + 2 < n ? a[g + 2] : inf,
-                               v3 = g + 3 < n ? a[g + 3] : inf;
-            if (first) {
-                QT_CX(v0, v1) QT_CX(v2, v3)            // k = 2
-                QT_CX(v0, v3) QT_CX(v1, v2)            // k = 4 flip
-                QT_CX(v0, v1) QT_CX(v2, v3)            // k = 4, j = 1
-            } else {
-                QT_CX(v0, v2) QT_CX(v1, v3)            // j = 2
-                QT_CX(v0, v1) QT_CX(v2, v3)            // j = 1
-            }
-            a[g] = v0;                                 // +inf never moves below a real key
-            if (g + 1 < n) a[g + 1] = v1;
-            if (g + 2 < n) a[g + 2] = v2;
-            if (g + 3 < n) a[g + 3] = v3;
-        }
-    }
-    __syncthreads();
-}
-
-// one compare-exchange step over all pairs; flip: partner = i ^ (2d - 1) (d = k/2), else partner = i | d
-__device__ __forceinline__ void qt_sort_step(unsigned long long* a, int n, int half, int d, bool flip)
-{
-    const int T = blockDim.x;
-    for (int t = threadIdx.x; t < half; t += 2 * T) {
-        const int t1 = t + T;
-        const int i0 = ((t & ~(d - 1)) << 1) | (t & (d - 1)), i1 = ((t1 & ~(d - 1)) << 1) | (t1 & (d - 1));
-        const int p0 = flip ? i0 ^ (2 * d - 1) : i0 | d, p1 = flip ? i1 ^ (2 * d - 1) : i1 | d;
-        const bool ok0 = p0 < n, ok1 = t1 < half && p1 < n;
-        unsigned long long x0 = 0, y0 = 0, x1 = 0, y1 = 0;
-        if (ok0) { x0 = a[i0]; y0 = a[p0]; }
-        if (ok1) { x1 = a[i1]; y1 = a[p1]; }
-        if (ok0 && x0 > y0) { a[i0] = y0; a[p0] = x0; }
-        if (ok1 && x1 > y1) { a[i1] = y1; a[p1] = x1; }
-    }
-    __syncthreads();
-}
-
-__device__ void qt_sort_u64(unsigned long long* a, int n)
-{
-    int np2 = 4;
-    while (np2 < n) np2 <<= 1;
-    const int half = np2 >> 1;
-    qt_sort_local4(a, n, np2, true);
-    for (int k = 8; k <= np2; k <<= 1) {
-        qt_sort_step(a, n, half, k >> 1, true);
-        for (int j = k >> 2; j >= 4; j >>= 1) qt_sort_step(a, n, half, j, false);
-        qt_sort_local4(a, n, np2, false);
-    }
 }
 
 // in-place exclusive scan of a[0..n) by the whole block; returns the total.  part = int[blockDim.x+1].
@@ -159,7 +97,7 @@ __device__ __forceinline__ void qt_body(unsigned long long* keys, int n, const O
     int& sh_prevInB = sh[4]; int& sh_tstar = sh[5];
     const int tid = threadIdx.x, T = blockDim.x;
     __syncthreads();
-    qt_sort_u64(keys, n);
+    orb_block_sort(keys, n);
 
     const int N = L.quota;
     // ---- roots (reference :575-612): empty roots vanish, single-key roots are bNoMore
@@ -251,7 +189,7 @@ __device__ __forceinline__ void qt_body(unsigned long long* keys, int n, const O
             __syncthreads();
         } else {
             // ---------------- careful phase (:703-765): largest first, stop as soon as size >= N
-            qt_sort_u64(prev, pc);                     // ascending (size, seq); processed from the back (:711-713)
+            orb_block_sort(prev, pc);                    // ascending (size, seq); processed from the back (:711-713)
             for (int t = tid; t < pc; t += T) {
                 const int idx = (int)(prev[pc - 1 - t] & 0xFFFFFF);
                 const QtNode nd = cur[idx];
