@@ -161,27 +161,69 @@ __device__ __forceinline__ unsigned wave_umin_dpp(unsigned v)
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
-// One side's feature vector as CSR in LDS: keys = (node << 16 | index), sorted -> node-major, ascending
-// index inside a node (DBoW2's push order); start[node] / cnt[node] from the run boundaries.
-__device__ void build_csr(const uint16_t* __restrict__ nodeOf, int n, int nNodes, uint32_t* keys, uint16_t* start,
-                          uint16_t* cnt)
+// One side's feature vector as CSR in LDS: keys[start[node] .. start[node] + cnt[node]) = (node << 16 | index) with
+// ascending index inside a node (DBoW2's push order).  A counting sort -- six barrier steps instead of the ~45 of a
+// bitonic network over ~1000 keys, which used to be 40 % of this latency-bound kernel:
+//   1 histogram of the nodes with LDS atomics (the returned slot is an arbitrary order inside the node)
+//   2 exclusive scan of the histogram by one wave (DPP)            -> start[], cnt[]
+//   3 scatter the indices to tmp[start[node] + slot]
+//   4 rank every index inside its node's segment (segments are ~10 long; O(m) per feature) -> keys[]
+// Features whose node is not in [0, nNodes) take no part (they are in no feature vector).
+#define ORB_CSR_MAXPT 4        // features per thread: cap <= 4096, 1024 threads
+__device__ void build_csr(const uint16_t* __restrict__ nodeOf, int n, int nNodes, uint32_t* keys, uint32_t* tmp,
+                          uint32_t* cntw, uint16_t* start, uint16_t* cnt)
 {
-    for (int t = threadIdx.x; t < nNodes; t += blockDim.x) { start[t] = 0xFFFF; cnt[t] = 0; }
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const unsigned nd = nodeOf[i];
-        keys[i] = ((nd < (unsigned)nNodes ? nd : 0xFFFFu) << 16) | (unsigned)i;   // node-less features sort last
+    const int T = blockDim.x, tid = threadIdx.x;
+    for (int t = tid; t < nNodes; t += T) cntw[t] = 0;
+    __syncthreads();
+    unsigned nd[ORB_CSR_MAXPT], slot[ORB_CSR_MAXPT];
+#pragma unroll
+    for (int m = 0; m < ORB_CSR_MAXPT; m++) {
+        const int i = tid + m * T;
+        nd[m] = 0xFFFFu;
+        slot[m] = 0;
+        if (i < n) {
+            const unsigned v = nodeOf[i];
+            if (v < (unsigned)nNodes) { nd[m] = v; slot[m] = atomicAdd(&cntw[v], 1u); }
+        }
     }
     __syncthreads();
-    orb_block_sort(keys, n);
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const unsigned nd = keys[i] >> 16;
-        if (nd < (unsigned)nNodes && (i == 0 || (keys[i - 1] >> 16) != nd)) start[nd] = (uint16_t)i;
+    if (tid < 64) {                                    // exclusive scan over the nodes: lane owns a contiguous chunk
+        const int C = (nNodes + 63) / 64;
+        const int b = min(tid * C, nNodes), e = min(b + C, nNodes);
+        int sum = 0;
+        for (int t = b; t < e; t++) sum += (int)cntw[t];
+        int incl = sum;
+#define ORB_DPP_ADD(v, ctrl, rmask) v += __builtin_amdgcn_update_dpp(0, v, ctrl, rmask, 0xf, false)
+        ORB_DPP_ADD(incl, 0x111, 0xf);
+        ORB_DPP_ADD(incl, 0x112, 0xf);
+        ORB_DPP_ADD(incl, 0x114, 0xf);
+        ORB_DPP_ADD(incl, 0x118, 0xf);
+        ORB_DPP_ADD(incl, 0x142, 0xa);
+        ORB_DPP_ADD(incl, 0x143, 0xc);
+#undef ORB_DPP_ADD
+        int run = incl - sum;
+        for (int t = b; t < e; t++) {
+            const int c = (int)cntw[t];
+            start[t] = (uint16_t)run;
+            cnt[t] = (uint16_t)c;
+            run += c;
+        }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const unsigned nd = keys[i] >> 16;
-        if (nd < (unsigned)nNodes && (i + 1 == n || (keys[i + 1] >> 16) != nd)) cnt[nd] = (uint16_t)(i + 1 - start[nd]);
-    }
+#pragma unroll
+    for (int m = 0; m < ORB_CSR_MAXPT; m++)
+        if (nd[m] != 0xFFFFu) tmp[start[nd[m]] + slot[m]] = (uint32_t)(tid + m * T);
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < ORB_CSR_MAXPT; m++)
+        if (nd[m] != 0xFFFFu) {
+            const unsigned i = (unsigned)(tid + m * T);
+            const int s0 = start[nd[m]], c = cnt[nd[m]];
+            int rank = 0;
+            for (int j = 0; j < c; j++) rank += tmp[s0 + j] < i;
+            keys[s0 + rank] = (nd[m] << 16) | i;
+        }
     __syncthreads();
 }
 
@@ -199,11 +241,13 @@ __global__ __launch_bounds__(1024) void k_match_bow(const BowSide* __restrict__ 
                                                     int32_t* __restrict__ nmatchesOut)
 {
     extern __shared__ uint32_t msm[];
-    // carve-up: keysA[cap] keysB[cap] (u32) | startA cntA startB cntB [nNodes] (u16) | res[cap] (i16) |
-    //           bin[cap] takenB[cap] (u8)
+    // carve-up: keysA[cap] keysB[cap] tmp[cap] cntw[nNodes] (u32) | startA cntA startB cntB [nNodes] (u16) |
+    //           res[cap] (i16) | bin[cap] takenB[cap] (u8)
     uint32_t* keysA = msm;
     uint32_t* keysB = keysA + capLds;
-    uint16_t* startA = reinterpret_cast<uint16_t*>(keysB + capLds);
+    uint32_t* tmp = keysB + capLds;
+    uint32_t* cntw = tmp + capLds;
+    uint16_t* startA = reinterpret_cast<uint16_t*>(cntw + nNodes);
     uint16_t* cntA = startA + nNodes;
     uint16_t* startB = cntA + nNodes;
     uint16_t* cntB = startB + nNodes;
@@ -213,18 +257,25 @@ __global__ __launch_bounds__(1024) void k_match_bow(const BowSide* __restrict__ 
     __shared__ int hist[HISTO_LENGTH];
     __shared__ int keepBins[3];
     __shared__ int nm;
+    __shared__ int nextNode;
 
     const BowSide A = sidesA[blockIdx.x], B = sidesB[blockIdx.x];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nWaves = blockDim.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int nRes = KK ? A.n : B.n;
     for (int i = tid; i < nRes; i += blockDim.x) { res[i] = -1; bin[i] = 0xFF; }
     for (int i = tid; i < B.n; i += blockDim.x) takenB[i] = (KK && B.valid && !B.valid[i]) ? 1 : 0;   // :750
     if (tid < HISTO_LENGTH) hist[tid] = 0;
-    if (tid == 0) nm = 0;
-    build_csr(A.nodeOf, A.n, nNodes, keysA, startA, cntA);
-    build_csr(B.nodeOf, B.n, nNodes, keysB, startB, cntB);
+    if (tid == 0) { nm = 0; nextNode = 0; }
+    build_csr(A.nodeOf, A.n, nNodes, keysA, tmp, cntw, startA, cntA);
+    build_csr(B.nodeOf, B.n, nNodes, keysB, tmp, cntw, startB, cntB);
 
-    for (int node = wave; node < nNodes; node += nWaves) {
+    // nodes differ a lot in size: waves take the next node from a shared counter instead of a fixed stride
+    // (a fixed stride left the slowest wave 2.6x behind the fastest)
+    while (true) {
+        int node = 0;
+        if (lane == 0) node = atomicAdd(&nextNode, 1);
+        node = __builtin_amdgcn_readfirstlane(node);
+        if (node >= nNodes) break;
         const int na = cntA[node], nb = cntB[node];
         if (na == 0 || nb == 0) continue;
         const int a0 = startA[node], b0 = startB[node];
@@ -374,7 +425,7 @@ __global__ void k_fill_sides(orb_featstore S, const int32_t* __restrict__ kfInde
 // ------------------------------------------------------------------ host side
 static size_t match_lds_bytes(int capLds, int nNodes)
 {
-    return (size_t)capLds * (4 + 4 + 2 + 1 + 1) + (size_t)nNodes * 8 + 16;
+    return (size_t)capLds * (4 + 4 + 4 + 2 + 1 + 1) + (size_t)nNodes * (4 + 8) + 16;
 }
 
 extern "C" int orb_matcher_create(int device_id, orb_matcher** out)
