@@ -7,6 +7,7 @@
 //   (k_quadtree lives in orb_quadtree.hip)
 //   (k_orient_desc lives in orb_desc.hip)
 // Every kernel takes blockIdx.y (or .z) = frame: batched frames are independent.
+#include <cstdlib>
 #include "orb_kernels.h"
 
 #pragma clang fp contract(off)
@@ -155,22 +156,31 @@ __global__ __launch_bounds__(256) void k_resize_level4p(uint8_t* __restrict__ py
     uint8_t* dst = pyr + (size_t)f * pyrSlab + dstOff;
     const uint4 q0 = xq[3 * x4], q1 = xq[3 * x4 + 1];
     const uint2 q2 = *reinterpret_cast<const uint2*>(xq + 3 * x4 + 2);
+    // all loads of the 4 rows are issued before the first use (the kernel is latency-bound, not issue-bound:
+    // row-by-row code left the vector ALU 31 % busy); rows past the end are clamped for the loads, skipped for the store
+    int2 ty[RESIZE_ROWS];
+#pragma unroll
+    for (int r = 0; r < RESIZE_ROWS; r++) ty[r] = ytab[min(y0 + r, (unsigned)dh - 1u)];
+    uint2 wA0[RESIZE_ROWS], wA1[RESIZE_ROWS], wB0[RESIZE_ROWS], wB1[RESIZE_ROWS];
+#pragma unroll
+    for (int r = 0; r < RESIZE_ROWS; r++) {
+        const unsigned rowA = __umul24((unsigned)ty[r].x & 0xffffu, (unsigned)srcPitch);
+        const unsigned rowB = __umul24((unsigned)ty[r].x >> 16, (unsigned)srcPitch);
+        wA0[r] = *reinterpret_cast<const uint2*>(src + (rowA + q0.x));
+        wA1[r] = *reinterpret_cast<const uint2*>(src + (rowA + q0.y));
+        wB0[r] = *reinterpret_cast<const uint2*>(src + (rowB + q0.x));
+        wB1[r] = *reinterpret_cast<const uint2*>(src + (rowB + q0.y));
+    }
 #pragma unroll
     for (int r = 0; r < RESIZE_ROWS; r++) {
         const unsigned y = y0 + r;
-        if ((int)y < dh) {
-            const int2 ty = ytab[y];
-            const unsigned b0 = (unsigned)ty.y & 0xffffu, b1 = (unsigned)ty.y >> 16;
-            const unsigned rowA = __umul24((unsigned)ty.x & 0xffffu, (unsigned)srcPitch);
-            const unsigned rowB = __umul24((unsigned)ty.x >> 16, (unsigned)srcPitch);
-            const uint2 wA0 = *reinterpret_cast<const uint2*>(src + (rowA + q0.x)), wA1 = *reinterpret_cast<const uint2*>(src + (rowA + q0.y));
-            const uint2 wB0 = *reinterpret_cast<const uint2*>(src + (rowB + q0.x)), wB1 = *reinterpret_cast<const uint2*>(src + (rowB + q0.y));
-            const unsigned v0 = resize_px(wA0, wB0, q0.z, q1.z, b0, b1);
-            const unsigned v1 = resize_px(wA0, wB0, q0.w, q1.w, b0, b1);
-            const unsigned v2 = resize_px(wA1, wB1, q1.x, q2.x, b0, b1);
-            const unsigned v3 = resize_px(wA1, wB1, q1.y, q2.y, b0, b1);
+        const unsigned b0 = (unsigned)ty[r].y & 0xffffu, b1 = (unsigned)ty[r].y >> 16;
+        const unsigned v0 = resize_px(wA0[r], wB0[r], q0.z, q1.z, b0, b1);
+        const unsigned v1 = resize_px(wA0[r], wB0[r], q0.w, q1.w, b0, b1);
+        const unsigned v2 = resize_px(wA1[r], wB1[r], q1.x, q2.x, b0, b1);
+        const unsigned v3 = resize_px(wA1[r], wB1[r], q1.y, q2.y, b0, b1);
+        if ((int)y < dh)
             *reinterpret_cast<uint32_t*>(dst + (__umul24(y, (unsigned)dstPitch) + x4 * 4)) = v0 | (v1 << 8) | (v2 << 16) | (v3 << 24);
-        }
     }
 }
 
@@ -202,7 +212,8 @@ void orb_launch_resize(hipStream_t st, uint8_t* pyr, size_t pyrSlab, const OrbLe
     const bool flat = total * x4 < (1ll << 32);
     if (xq && flat && (long long)src.h * src.pitch < (1ll << 31) && src.pitch < (1 << 24) && dst.h < (1 << 24)) {
         const long long groups = (long long)x4 * ((dst.h + RESIZE_ROWS - 1) / RESIZE_ROWS);
-        hipLaunchKernelGGL(k_resize_level4p, dim3((unsigned)((groups + 255) / 256), nFrames), dim3(256), 0, st, pyr, pyrSlab,
+        static const int bs = getenv("ORB_RESIZE_BS") ? atoi(getenv("ORB_RESIZE_BS")) : 256;
+        hipLaunchKernelGGL(k_resize_level4p, dim3((unsigned)((groups + bs - 1) / bs), nFrames), dim3(bs), 0, st, pyr, pyrSlab,
                            src.pyrOff, src.pitch, dst.pyrOff, dst.pitch, dst.h, xq, ytab, x4, inv32(x4));
     }
     // window form needs sx(dx+3)+1 - (sx(dx) & ~3) <= 11, i.e. 3 + ceil(3*scale) + 1 <= 11
