@@ -171,3 +171,19 @@ def test_c4_full_batch_512_properties_and_sampled_parity():
         rk, rd = ref.extract(imgs[i])
         assert outs[i][0].tobytes() == rk.tobytes() and np.array_equal(outs[i][1], rd), "frame %d" % i
     ex.close()
+
+
+def test_full_hd_1920x1080_3000_features():
+    # 64 x 36 FAST cells on level 0, > 1024 candidates per level (global-memory sort path of the quadtree on first use)
+    _cmp(synth.synth_frame(77, 1920, 1080), nfeatures=3000)
+
+
+def test_unsupported_geometry_is_reported_not_crashed():
+    ex = capi.Extractor()
+    img = np.zeros((100, 4200), np.uint8)                       # level 0 wider than the supported 4095 px
+    with pytest.raises(capi.OrbError) as e:
+        ex.extract(img)
+    assert e.value.code == -5                                   # ORB_ERR_UNSUPPORTED
+    k, d = ex.extract(synth.synth_frame(3))                     # the handle stays usable
+    assert len(k) > 900
+    ex.close()
