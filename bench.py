@@ -39,6 +39,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--pipeline", type=int, default=1,
+                    help="number of independent (extractor, matcher, output buffers) lanes that consecutive steps alternate "
+                         "between; lanes run on their own streams, so step k+1 overlaps step k")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames-per-gpu", type=int, default=512)
     ap.add_argument("--width", type=int, default=640)
@@ -102,18 +105,41 @@ def main():
                  node_of=d_nodeof.data_ptr(), cap=cap, n_frames=B)
     torch.cuda.synchronize()
 
+    # ---- lanes: lane 0 is (ex, mt, the buffers above); further lanes (--pipeline P) have their own extractor, matcher
+    # and output buffers and share the read-only inputs.  Consecutive steps alternate between lanes, each lane on its
+    # own streams, so the latency-bound stages of one step (pyramid, quadtree, matcher) overlap the issue-bound stages
+    # (FAST, descriptors) of the next.
+    lanes = [dict(ex=ex, mt=mt, kps=d_kps, desc=d_desc, counts=d_counts, nodeof=d_nodeof, match=d_match, nm=d_nm, store=store)]
+    for _ in range(1, max(1, args.pipeline)):
+        lex = capi.Extractor(args.nfeatures, 1.2, 8, 20, 7, device=local_rank)
+        lex.set_pattern_device(pat.data_ptr())
+        lmt = capi.Matcher(0.7, True, device=local_rank)
+        ln = dict(ex=lex, mt=lmt, kps=torch.zeros_like(d_kps), desc=torch.zeros_like(d_desc), counts=torch.zeros_like(d_counts),
+                  nodeof=torch.zeros_like(d_nodeof), match=torch.zeros_like(d_match), nm=torch.zeros_like(d_nm))
+        ln["store"] = dict(desc=ln["desc"].data_ptr(), kps=ln["kps"].data_ptr(), valid=d_valid.data_ptr(),
+                           counts=ln["counts"].data_ptr(), node_of=ln["nodeof"].data_ptr(), cap=cap, n_frames=B)
+        lanes.append(ln)
+    torch.cuda.synchronize()
+    step_no = [0]
+
     def step():
-        ex.wait_for(mt.stream)                     # outputs of the previous step are still being matched
-        ex.extract_batch_device(d_imgs.data_ptr(), B, H, W, W, W * H, d_kps.data_ptr(), d_desc.data_ptr(), cap,
-                                d_counts.data_ptr())
+        ln = lanes[step_no[0] % len(lanes)]
+        step_no[0] += 1
+        lx, lm = ln["ex"], ln["mt"]
+        lx.wait_for(lm.stream)                     # this lane's outputs of its previous step are still being matched
+        lx.extract_batch_device(d_imgs.data_ptr(), B, H, W, W, W * H, ln["kps"].data_ptr(), ln["desc"].data_ptr(), cap,
+                                ln["counts"].data_ptr())
         if not args.no_match:
-            mt.wait_for(ex.stream)
-            mt.bow_assign_device(d_desc.data_ptr(), d_counts.data_ptr(), B, cap, d_cent.data_ptr(), d_nodeof.data_ptr())
-            mt.match_bow_batch_device(store, kf_idx.data_ptr(), f_idx.data_ptr(), B, d_match.data_ptr(), d_nm.data_ptr())
+            lm.wait_for(lx.stream)
+            lm.bow_assign_device(ln["desc"].data_ptr(), ln["counts"].data_ptr(), B, cap, d_cent.data_ptr(),
+                                 ln["nodeof"].data_ptr())
+            lm.match_bow_batch_device(ln["store"], kf_idx.data_ptr(), f_idx.data_ptr(), B, ln["match"].data_ptr(),
+                                      ln["nm"].data_ptr())
 
     def full_sync():
-        ex.sync()
-        mt.sync()
+        for ln in lanes:
+            ln["ex"].sync()
+            ln["mt"].sync()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):

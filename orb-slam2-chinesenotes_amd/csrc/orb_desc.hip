@@ -117,6 +117,13 @@ __global__ __launch_bounds__(WAVE) void k_orient_desc(const OrbGeom G, const uin
     if (k >= cnt[level] || off + k >= cap) return;
 
     const uint32_t packed = kpl[(size_t)f * G.kpSlab + slot];
+    // constant-table loads are issued here, long before their use, so that their latency hides behind the patch
+    // staging (one wave per workgroup: nothing else would cover it)
+    const char4* pat4 = reinterpret_cast<const char4*>(pattern);
+    const char4 q0 = pat4[lane], q1 = pat4[64 + lane], q2 = pat4[128 + lane], q3 = pat4[192 + lane];
+    const int angV = (min(lane, 61) >> 1) - 15, angH = lane & 1;
+    const uint4* angT = angTab + ((angV < 0 ? -angV : angV) * 2 + angH) * 2;
+    const uint4 mk = angT[0], wt = angT[1];
     const int x0 = (int)(packed >> 20), y0 = (int)(packed >> 8) & 0xFFF;
     const int resp = (int)(packed & 0xFF);
     const uint8_t* img = pyr + (size_t)f * pyrSlab + L.pyrOff;
@@ -149,9 +156,7 @@ __global__ __launch_bounds__(WAVE) void k_orient_desc(const OrbGeom G, const uin
     //   s0 = sum I,  s1 = sum (u + 15) I   =>   m10 += s1 - 15 s0,  m01 += v s0       (exact integers)
     int m10 = 0, m01 = 0;
     if (lane < 62) {
-        const int v = (lane >> 1) - 15, hh = lane & 1;
-        const uint4* t = angTab + ((v < 0 ? -v : v) * 2 + hh) * 2;
-        const uint4 mk = t[0], wt = t[1];
+        const int v = angV, hh = angH;
         const int b0 = xoff + PR - 15;                  // LDS byte of u = -15
         const unsigned sh = (unsigned)b0 & 3u;
         const uint32_t* p = Pdw + (PR + v) * PDW + (b0 >> 2) + 4 * hh;
@@ -211,8 +216,6 @@ __global__ __launch_bounds__(WAVE) void k_orient_desc(const OrbGeom G, const uin
         const int acc = 18 * (h[0] + h[6 * HP]) + 34 * (h[HP] + h[5 * HP]) + 49 * (h[2 * HP] + h[4 * HP]) + 55 * h[3 * HP];
         return min(255, (acc + 32768) >> 16);
     };
-    const char4* pat4 = reinterpret_cast<const char4*>(pattern);
-    const char4 q0 = pat4[lane], q1 = pat4[64 + lane], q2 = pat4[128 + lane], q3 = pat4[192 + lane];
     const unsigned long long w0 = __ballot(sample(q0.x, q0.y) < sample(q0.z, q0.w));
     const unsigned long long w1 = __ballot(sample(q1.x, q1.y) < sample(q1.z, q1.w));
     const unsigned long long w2 = __ballot(sample(q2.x, q2.y) < sample(q2.z, q2.w));
