@@ -78,7 +78,7 @@ __device__ __forceinline__ void hblur4(unsigned d0, unsigned d1, unsigned d2, un
     out[3] = __builtin_amdgcn_udot4(d2, K1, __builtin_amdgcn_udot4(d1, K0, 0u, false), false);
 }
 
-__global__ __launch_bounds__(WAVE) void k_orient_desc(const OrbGeom G, const uint8_t* __restrict__ pyr,
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_orient_desc(const OrbGeom G, const uint8_t* __restrict__ pyr,
                                                       size_t pyrSlab, const uint32_t* __restrict__ kpl,
                                                       const int* __restrict__ kpCount,
                                                       const int8_t* __restrict__ pattern,
@@ -88,9 +88,13 @@ __global__ __launch_bounds__(WAVE) void k_orient_desc(const OrbGeom G, const uin
                                                       int32_t* __restrict__ countsOut, int* __restrict__ errFlags,
                                                       int nFrames, unsigned invPerFrame)
 {
-    __shared__ uint32_t Praw[1 + PW * PDW + 1];       // one dword of slack on both sides (edge quads)
-    __shared__ uint16_t H[PW * HP];
-    uint32_t* Pdw = Praw + 1;
+    // ONE LDS region: first the raw patch (2 KB, dword rows with one dword of slack on both sides), later the
+    // row-blurred patch H (4 KB, u16) written over it once every lane holds its blur outputs in registers.
+    // 4.1 KB per workgroup instead of 6.2 KB lets the wave-slot limit (32 per CU), not LDS, set the occupancy.
+    __shared__ uint32_t ldsBuf[(PW * HP * 2) / 4];
+    static_assert(PW * HP * 2 >= (1 + PW * PDW + 1) * 4, "H must cover the raw patch");
+    uint32_t* Pdw = ldsBuf + 1;
+    uint16_t* H = reinterpret_cast<uint16_t*>(ldsBuf);
     const int lane = threadIdx.x;
     int slot, f;
     if (invPerFrame) {                                 // 1-D XCD-aware grid: a frame's keypoints share one L2
@@ -148,7 +152,6 @@ __global__ __launch_bounds__(WAVE) void k_orient_desc(const OrbGeom G, const uin
         }
     }
     __syncthreads();
-    const uint8_t* P = reinterpret_cast<const uint8_t*>(Pdw) + xoff;     // P[r*PB + c] = patch (row r, column c)
 
     // ---- IC_Angle (:78-105): two lanes per patch row v = -15..15 (u = -15..0 and u = 1..16).  The 16 bytes of a
     // half row are funnel-shifted into 4 dwords and reduced with v_dot4_u32_u8 against a per-(|v|, half) table of
@@ -179,20 +182,25 @@ __global__ __launch_bounds__(WAVE) void k_orient_desc(const OrbGeom G, const uin
     // so the unrolled loop carries no index arithmetic (this kernel is VALU-issue bound).
     {
         const int rp = lane / 11, q = lane - rp * 11;          // 5 row phases x 11 quads = 55 lanes
+        uint2 hv[9];
         if (rp < 5) {
             const uint32_t* p = Pdw + rp * PDW + q - 1;
-            uint16_t* hrow = &H[rp * HP + 4 * q];
 #pragma unroll
             for (int i = 0; i < 9; i++) {
                 if (i < 8 || rp < PW - 40) {                      // rows 40..42 exist for phases 0..2 only
                     unsigned o[4];
                     hblur4(p[i * 5 * PDW], p[i * 5 * PDW + 1], p[i * 5 * PDW + 2], o);
-                    uint2 w;
-                    w.x = o[0] | (o[1] << 16);
-                    w.y = o[2] | (o[3] << 16);
-                    *reinterpret_cast<uint2*>(hrow + i * 5 * HP) = w;
+                    hv[i].x = o[0] | (o[1] << 16);
+                    hv[i].y = o[2] | (o[3] << 16);
                 }
             }
+        }
+        __syncthreads();                                       // every read of the raw patch is done: H may overwrite it
+        if (rp < 5) {
+            uint16_t* hrow = &H[rp * HP + 4 * q];
+#pragma unroll
+            for (int i = 0; i < 9; i++)
+                if (i < 8 || rp < PW - 40) *reinterpret_cast<uint2*>(hrow + i * 5 * HP) = hv[i];
         }
     }
     __syncthreads();
