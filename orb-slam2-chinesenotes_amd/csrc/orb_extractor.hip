@@ -158,7 +158,7 @@ static int build_geometry(orb_extractor* h, int rows, int cols)
                     if (c.w < 7 || c.h < 7) continue;                    // cv::FAST finds nothing in such a ROI
                     {   // k_fast_cells works on quads of 4 aligned columns: items = quads per row x zone rows
                         const int xoff = c.x0 & 3, zLo = xoff + 3, zHi = zLo + c.w - 6;
-                        const int items = ((zHi >> 2) + 1 - ((zLo - 1) >> 2)) * (c.h - 6);
+                        const int items = (((zHi - 1) >> 2) + 1 - (zLo >> 2)) * (c.h - 6);    // quads covering [zLo, zHi)
                         if (items > 1024) {                              // <= 16 quad steps per lane
                             orb_set_error("FAST cell %dx%d too large for the kernel", c.w, c.h);
                             return ORB_ERR_UNSUPPORTED;

@@ -161,12 +161,19 @@ __global__ __launch_bounds__(WAVE) void k_fast_cells(const OrbGeom G, const uint
     }
     const int zw = cell.w - 6, zh = cell.h - 6;                    // detection zone: tile rows [3,3+zh), cols [zLo,zHi)
     const int zLo = xoff + 3, zHi = zLo + zw;
-    const int qLo = (zLo - 1) >> 2, qHi = (zHi >> 2) + 1;          // quads covering cols [zLo-1, zHi]
+    // Quads [qLo, qHi) cover the zone columns [zLo, zHi); the halo columns zLo-1 and zHi (and the rows above and
+    // below the zone) only ever read as score 0 by the NMS -- cv::FAST scores nothing outside the ROI interior -- so
+    // they are zeroed here instead of being run through the detector (one quad per row less for 3 alignments in 4).
+    const int qLo = zLo >> 2, qHi = ((zHi - 1) >> 2) + 1;
     const int nq = qHi - qLo;
-    // rows just above / below the zone read as score 0 by the NMS
-    for (int i = lane; i < 2 * nq; i += WAVE) {
-        const int row = (i < nq) ? 2 : 3 + zh, q = qLo + (i < nq ? i : i - nq);
+    const int hLo = (zLo - 1) >> 2, hHi = (zHi >> 2) + 1, nh = hHi - hLo;        // halo-inclusive quad range
+    for (int i = lane; i < 2 * nh; i += WAVE) {
+        const int row = (i < nh) ? 2 : 3 + zh, q = hLo + (i < nh ? i : i - nh);
         smapDw[row * FT_PDW + q] = 0;
+    }
+    for (int i = lane; i < 2 * zh; i += WAVE) {                                   // left / right halo quads of the zone rows
+        const int row = 3 + (i >> 1), q = (i & 1) ? hHi - 1 : hLo;
+        if (q < qLo || q >= qHi) smapDw[row * FT_PDW + q] = 0;
     }
     __syncthreads();
 
