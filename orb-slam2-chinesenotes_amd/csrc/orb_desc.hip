@@ -9,6 +9,7 @@
 // vertical pass only at the 512 sampled points.  The blurred level is never written to HBM.
 // Four __ballot()s of 64 comparisons ARE the 256-bit descriptor.
 #include "orb_kernels.h"
+#include "orb_wave.h"
 
 #pragma clang fp contract(off)
 
@@ -48,19 +49,6 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
     if (x < 0) a = __fsub_rn(180.f, a);
     if (y < 0) a = __fsub_rn(360.f, a);
     return a;
-}
-
-// wave64 integer sum with DPP (row_shr 1,2,4,8, row_bcast 15/31; no LDS round trips): total in every lane
-#define ORB_DPP_ADD(v, ctrl, rmask) v += __builtin_amdgcn_update_dpp(0, v, ctrl, rmask, 0xf, false)
-__device__ __forceinline__ int wave_sum(int v)
-{
-    ORB_DPP_ADD(v, 0x111, 0xf);
-    ORB_DPP_ADD(v, 0x112, 0xf);
-    ORB_DPP_ADD(v, 0x114, 0xf);
-    ORB_DPP_ADD(v, 0x118, 0xf);
-    ORB_DPP_ADD(v, 0x142, 0xa);
-    ORB_DPP_ADD(v, 0x143, 0xc);
-    return __builtin_amdgcn_readlane(v, 63);
 }
 
 // 7-tap row blur at the 4 byte positions 4q..4q+3 of a row, from the 12-byte window (d0,d1,d2) =
@@ -173,8 +161,8 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
         m10 = (int)s1 - 15 * (int)s0;
         m01 = v * (int)s0;
     }
-    m10 = wave_sum(m10);
-    m01 = wave_sum(m01);
+    m10 = orb_wave_sum(m10);
+    m01 = orb_wave_sum(m01);
     const float angle = fast_atan2_deg((float)m01, (float)m10);
 
     // ---- horizontal 7-tap pass: H[r][b] for LDS byte positions b = 0..43 (patch column b - xoff).

@@ -7,7 +7,6 @@
 //   (k_quadtree lives in orb_quadtree.hip)
 //   (k_orient_desc lives in orb_desc.hip)
 // Every kernel takes blockIdx.y (or .z) = frame: batched frames are independent.
-#include <cstdlib>
 #include "orb_kernels.h"
 
 #pragma clang fp contract(off)
@@ -212,8 +211,7 @@ void orb_launch_resize(hipStream_t st, uint8_t* pyr, size_t pyrSlab, const OrbLe
     const bool flat = total * x4 < (1ll << 32);
     if (xq && flat && (long long)src.h * src.pitch < (1ll << 31) && src.pitch < (1 << 24) && dst.h < (1 << 24)) {
         const long long groups = (long long)x4 * ((dst.h + RESIZE_ROWS - 1) / RESIZE_ROWS);
-        static const int bs = getenv("ORB_RESIZE_BS") ? atoi(getenv("ORB_RESIZE_BS")) : 256;
-        hipLaunchKernelGGL(k_resize_level4p, dim3((unsigned)((groups + bs - 1) / bs), nFrames), dim3(bs), 0, st, pyr, pyrSlab,
+        hipLaunchKernelGGL(k_resize_level4p, dim3((unsigned)((groups + 255) / 256), nFrames), dim3(256), 0, st, pyr, pyrSlab,
                            src.pyrOff, src.pitch, dst.pyrOff, dst.pitch, dst.h, xq, ytab, x4, inv32(x4));
     }
     // window form needs sx(dx+3)+1 - (sx(dx) & ~3) <= 11, i.e. 3 + ceil(3*scale) + 1 <= 11

@@ -19,6 +19,7 @@
 #include <algorithm>
 
 #include "orb_kernels.h"
+#include "orb_wave.h"
 
 #define WAVE 64
 #define FT_PAD 4                       // dwords of slack around the tile (edge quads read one dword outside)
@@ -277,15 +278,7 @@ __global__ __launch_bounds__(WAVE) void k_fast_cells(const OrbGeom G, const uint
     uint16_t* queue = reinterpret_cast<uint16_t*>(tileDw);
     const uint8_t* smap = reinterpret_cast<const uint8_t*>(smapDw);
     const int mine = __popcll(cmask);
-    int incl = mine;                                               // inclusive wave scan with DPP (no LDS round trips)
-#define ORB_DPP_ADD(v, ctrl, rmask) v += __builtin_amdgcn_update_dpp(0, v, ctrl, rmask, 0xf, false)
-    ORB_DPP_ADD(incl, 0x111, 0xf);
-    ORB_DPP_ADD(incl, 0x112, 0xf);
-    ORB_DPP_ADD(incl, 0x114, 0xf);
-    ORB_DPP_ADD(incl, 0x118, 0xf);
-    ORB_DPP_ADD(incl, 0x142, 0xa);
-    ORB_DPP_ADD(incl, 0x143, 0xc);
-#undef ORB_DPP_ADD
+    const int incl = orb_wave_scan_incl(mine);
     const int nCand = __builtin_amdgcn_readlane(incl, WAVE - 1);
     if (nCand == 0) return;
     if (nCand > 2 * tileDwords) {                                  // cannot happen: the tile region holds 2 B per zone pixel

@@ -7,6 +7,7 @@
 // inner, insertion order inside a cell).
 #pragma once
 #include "orb_block_sort.h"
+#include "orb_wave.h"
 #include "orb_common.h"
 
 #define GRID_COLS 64
@@ -55,10 +56,4 @@ static __device__ __forceinline__ int lower_key(const uint32_t* keys, int n, uin
     return lo;
 }
 
-static __device__ __forceinline__ unsigned wave_min_u(unsigned v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = min(v, (unsigned)__shfl_xor((int)v, o));
-    return v;
-}
 

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "orb_block_sort.h"
+#include "orb_wave.h"
 #include "orb_matcher_internal.h"
 
 #pragma clang fp contract(off)
@@ -76,13 +77,6 @@ __device__ __forceinline__ void load_desc(const uint8_t* p, uint32_t v[8])
     const uint4 lo = reinterpret_cast<const uint4*>(p)[0], hi = reinterpret_cast<const uint4*>(p)[1];
     v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w;
     v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
-}
-
-__device__ __forceinline__ unsigned wave_min_u32(unsigned v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = min(v, (unsigned)__shfl_xor((int)v, o));
-    return v;
 }
 
 // rotation-histogram bin (reference :634-641): factor is 1/HISTO_LENGTH, so only bins 0..12 occur
@@ -147,20 +141,6 @@ struct BowSide {
     int n;
 };
 
-// ---- wave64 unsigned-min reduction with DPP (row_shr 1,2,4,8, row_bcast 15/31): result in lane 63
-#define ORB_DPP_UMIN(v, ctrl, rmask, bmask) \
-    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)0xFFFFFFFF, (int)(v), ctrl, rmask, bmask, false))
-__device__ __forceinline__ unsigned wave_umin_dpp(unsigned v)
-{
-    ORB_DPP_UMIN(v, 0x111, 0xf, 0xf);
-    ORB_DPP_UMIN(v, 0x112, 0xf, 0xf);
-    ORB_DPP_UMIN(v, 0x114, 0xf, 0xf);
-    ORB_DPP_UMIN(v, 0x118, 0xf, 0xf);
-    ORB_DPP_UMIN(v, 0x142, 0xa, 0xf);
-    ORB_DPP_UMIN(v, 0x143, 0xc, 0xf);
-    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
-}
-
 // One side's feature vector as CSR in LDS: keys[start[node] .. start[node] + cnt[node]) = (node << 16 | index) with
 // ascending index inside a node (DBoW2's push order).  A counting sort -- six barrier steps instead of the ~45 of a
 // bitonic network over ~1000 keys, which used to be 40 % of this latency-bound kernel:
@@ -193,15 +173,7 @@ __device__ void build_csr(const uint16_t* __restrict__ nodeOf, int n, int nNodes
         const int b = min(tid * C, nNodes), e = min(b + C, nNodes);
         int sum = 0;
         for (int t = b; t < e; t++) sum += (int)cntw[t];
-        int incl = sum;
-#define ORB_DPP_ADD(v, ctrl, rmask) v += __builtin_amdgcn_update_dpp(0, v, ctrl, rmask, 0xf, false)
-        ORB_DPP_ADD(incl, 0x111, 0xf);
-        ORB_DPP_ADD(incl, 0x112, 0xf);
-        ORB_DPP_ADD(incl, 0x114, 0xf);
-        ORB_DPP_ADD(incl, 0x118, 0xf);
-        ORB_DPP_ADD(incl, 0x142, 0xa);
-        ORB_DPP_ADD(incl, 0x143, 0xc);
-#undef ORB_DPP_ADD
+        const int incl = orb_wave_scan_incl(sum);
         int run = incl - sum;
         for (int t = b; t < e; t++) {
             const int c = (int)cntw[t];
@@ -309,8 +281,8 @@ __global__ __launch_bounds__(1024) void k_match_bow(const BowSide* __restrict__ 
                         for (int w = 0; w < 8; w++) d += __popc(dB[w] ^ (uint32_t)__builtin_amdgcn_readlane((int)dA[w], p));
                     }
                     const unsigned mine = (d << 16) | (unsigned)lane;
-                    const unsigned m1 = wave_umin_dpp(mine);
-                    const unsigned m2 = wave_umin_dpp(mine == m1 ? 0xFFFFFFFFu : mine);
+                    const unsigned m1 = orb_wave_umin(mine);
+                    const unsigned m2 = orb_wave_umin(mine == m1 ? 0xFFFFFFFFu : mine);
                     const int best1 = (int)(m1 >> 16), best2 = (int)(m2 >> 16);      // 256 when nothing is left
                     const bool pass = KK ? (best1 < TH_LOW) : (best1 <= TH_LOW);      // :772 vs :625
                     if (pass && (float)best1 < __fmul_rn(ratio, (float)best2)) {
@@ -346,8 +318,8 @@ __global__ __launch_bounds__(1024) void k_match_bow(const BowSide* __restrict__ 
                         }
                     }
                     const unsigned mine = (d << 16) | (unsigned)q;
-                    const unsigned m1 = wave_umin_dpp(mine);
-                    const unsigned m2 = wave_umin_dpp(mine == m1 ? 0xFFFFFFFFu : mine);
+                    const unsigned m1 = orb_wave_umin(mine);
+                    const unsigned m2 = orb_wave_umin(mine == m1 ? 0xFFFFFFFFu : mine);
                     const unsigned d1 = m1 >> 16, d2 = min(256u, m2 >> 16);
                     if (d1 < (best >> 16)) { second = min(best >> 16, d2); best = m1; }
                     else second = min(second, d1);

@@ -117,8 +117,8 @@ __global__ __launch_bounds__(WAVE) void k_init_resolve(const orb_keypoint* __res
                 const int dist = (int)(rec & 0xFFFFu);
                 if (!(matchedDist[i2] <= dist)) mine = ((unsigned)dist << 16) | (unsigned)(q - base);   // :1094
             }
-            const unsigned m1 = wave_min_u(mine);
-            const unsigned m2 = wave_min_u(mine == m1 ? 0xFFFFFFFFu : mine);
+            const unsigned m1 = orb_wave_umin(mine);
+            const unsigned m2 = orb_wave_umin(mine == m1 ? 0xFFFFFFFFu : mine);
             if (m1 != 0xFFFFFFFFu) {
                 const unsigned d1 = m1 >> 16;
                 const unsigned d2 = (m2 == 0xFFFFFFFFu) ? 0xFFFFFFFFu : (m2 >> 16);
@@ -161,8 +161,7 @@ __global__ __launch_bounds__(WAVE) void k_init_resolve(const orb_keypoint* __res
     // the reference's running count (++ on accept, -- on steal) equals the number of live matches
     int alive = 0;
     for (int i = lane; i < n1; i += WAVE) alive += (m12[i] >= 0);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) alive += __shfl_xor(alive, o);
+    alive = orb_wave_sum(alive);
     int nmatches = alive;
     if (checkOri) {
         int i1 = -1, i2 = -1, i3 = -1;
@@ -182,8 +181,7 @@ __global__ __launch_bounds__(WAVE) void k_init_resolve(const orb_keypoint* __res
             const int b = binOf[i];
             if (b != 0xFF && b != i1 && b != i2 && b != i3 && m12[i] >= 0) { m12[i] = -1; dropped++; }   // :1163-1167
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) dropped += __shfl_xor(dropped, o);
+        dropped = orb_wave_sum(dropped);
         nmatches -= dropped;
     }
     __threadfence_block();

@@ -201,8 +201,7 @@ __global__ __launch_bounds__(WAVE) void k_proj_resolve(int mode, const ProjQuery
             const int b = (int)(ev >> 16);
             if (b != i1 && b != i2 && b != i3) { matchCur[ev & 0xFFFFu] = -2; dropped++; }       // :285-293
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) dropped += __shfl_xor(dropped, o);
+        dropped = orb_wave_sum(dropped);
         nmatches -= dropped;
     }
     if (lane == 0) *nmatchesOut = nmatches;

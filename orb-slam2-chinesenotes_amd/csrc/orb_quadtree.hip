@@ -16,6 +16,7 @@
 //     in parallel, and a scan of the size gains finds where the reference's `break` (:758) falls.
 #include "orb_block_sort.h"
 #include "orb_kernels.h"
+#include "orb_wave.h"
 
 struct QtNode {
     int lo, hi;      // key range in the sorted candidate array
@@ -64,15 +65,7 @@ __device__ int qt_scan(int* a, int n, int* part)
     if (t < 64) {                                      // T == 256: each of 64 lanes owns 4 partials
         const int q0 = part[4 * t], q1 = part[4 * t + 1], q2 = part[4 * t + 2], q3 = part[4 * t + 3];
         const int mine = q0 + q1 + q2 + q3;
-        int incl = mine;                               // inclusive wave scan with DPP (row_shr 1,2,4,8, row_bcast 15/31)
-#define ORB_DPP_ADD(v, ctrl, rmask) v += __builtin_amdgcn_update_dpp(0, v, ctrl, rmask, 0xf, false)
-        ORB_DPP_ADD(incl, 0x111, 0xf);
-        ORB_DPP_ADD(incl, 0x112, 0xf);
-        ORB_DPP_ADD(incl, 0x114, 0xf);
-        ORB_DPP_ADD(incl, 0x118, 0xf);
-        ORB_DPP_ADD(incl, 0x142, 0xa);
-        ORB_DPP_ADD(incl, 0x143, 0xc);
-#undef ORB_DPP_ADD
+        const int incl = orb_wave_scan_incl(mine);
         const int ex = incl - mine;
         part[4 * t] = ex; part[4 * t + 1] = ex + q0; part[4 * t + 2] = ex + q0 + q1; part[4 * t + 3] = ex + q0 + q1 + q2;
         if (t == 63) part[T] = incl;
