@@ -165,30 +165,31 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     m01 = orb_wave_sum(m01);
     const float angle = fast_atan2_deg((float)m01, (float)m10);
 
-    // ---- horizontal 7-tap pass: H[r][b] for LDS byte positions b = 0..43 (patch column b - xoff).
-    // Static mapping (lane -> quad q, row phase rp; rows rp, rp+5, ...): every LDS address is base + constant,
-    // so the unrolled loop carries no index arithmetic (this kernel is VALU-issue bound).
+    // ---- horizontal 7-tap pass.  The rotated pattern stays within 18 px of the keypoint (|x|,|y| <= 13), so only
+    // LDS bytes xoff+3 .. xoff+39 are ever sampled: 10 quads starting at q0 = (xoff+3)/4.  Static mapping lane ->
+    // (row phase rp of 6, quad): rows rp, rp+6, ... in 8 unrolled steps whose LDS addresses are base + constant
+    // (no index arithmetic; this kernel is VALU-issue bound).
     {
-        const int rp = lane / 11, q = lane - rp * 11;          // 5 row phases x 11 quads = 55 lanes
-        uint2 hv[9];
-        if (rp < 5) {
+        const int rp = lane / 10, q = ((xoff + 3) >> 2) + (lane - rp * 10);     // 6 row phases x 10 quads = 60 lanes
+        uint2 hv[8];
+        if (rp < 6) {
             const uint32_t* p = Pdw + rp * PDW + q - 1;
 #pragma unroll
-            for (int i = 0; i < 9; i++) {
-                if (i < 8 || rp < PW - 40) {                      // rows 40..42 exist for phases 0..2 only
+            for (int i = 0; i < 8; i++) {
+                if (i < 7 || rp < PW - 42) {                      // row 42 exists for phase 0 only
                     unsigned o[4];
-                    hblur4(p[i * 5 * PDW], p[i * 5 * PDW + 1], p[i * 5 * PDW + 2], o);
+                    hblur4(p[i * 6 * PDW], p[i * 6 * PDW + 1], p[i * 6 * PDW + 2], o);
                     hv[i].x = o[0] | (o[1] << 16);
                     hv[i].y = o[2] | (o[3] << 16);
                 }
             }
         }
         __syncthreads();                                       // every read of the raw patch is done: H may overwrite it
-        if (rp < 5) {
+        if (rp < 6) {
             uint16_t* hrow = &H[rp * HP + 4 * q];
 #pragma unroll
-            for (int i = 0; i < 9; i++)
-                if (i < 8 || rp < PW - 40) *reinterpret_cast<uint2*>(hrow + i * 5 * HP) = hv[i];
+            for (int i = 0; i < 8; i++)
+                if (i < 7 || rp < PW - 42) *reinterpret_cast<uint2*>(hrow + i * 6 * HP) = hv[i];
         }
     }
     __syncthreads();
