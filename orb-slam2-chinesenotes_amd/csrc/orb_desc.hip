@@ -203,13 +203,14 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     // bits of the sum ARE the integer (biased by 0x4B400000), so rounding costs one v_add_f32 per coordinate and the
     // biases fold into one wave-uniform constant of the LDS index (all arithmetic mod 2^32).
     const unsigned kBias = 0x4B400000u;
-    const unsigned idxC = (unsigned)((PR - 3) * HP + xoff + PR) - kBias * (unsigned)HP - kBias;
+    // row index through a 24-bit multiply-add: the low 24 bits of the biased row are 0x400000 + ir
+    const unsigned idxC = (unsigned)((PR - 3) * HP + xoff + PR) - 0x400000u * (unsigned)HP - kBias;
     auto sample = [&](int pxi, int pyi) -> int {
         const float px = (float)pxi, py = (float)pyi;
         const float fr = __fadd_rn(__fmul_rn(px, b), __fmul_rn(py, a));
         const float fc = __fsub_rn(__fmul_rn(px, a), __fmul_rn(py, b));
         const unsigned br = __float_as_uint(__fadd_rn(fr, 12582912.f)), bc = __float_as_uint(__fadd_rn(fc, 12582912.f));
-        const uint16_t* h = H + (int)(br * (unsigned)HP + bc + idxC);      // = H[(21 + ir - 3) * HP + xoff + 21 + ic]
+        const uint16_t* h = H + (int)(__umul24(br, (unsigned)HP) + (bc + idxC));   // = H[(21 + ir - 3) * HP + xoff + 21 + ic]
         const int acc = 18 * (h[0] + h[6 * HP]) + 34 * (h[HP] + h[5 * HP]) + 49 * (h[2 * HP] + h[4 * HP]) + 55 * h[3 * HP];
         return min(255, (acc + 32768) >> 16);
     };
