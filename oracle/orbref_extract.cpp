@@ -526,6 +526,9 @@ void Extractor::extract(const uint8_t* img, int rows, int cols, size_t stride,
         const int minBX = kEdge - 3, minBY = minBX;
         const int maxBX = im.w - kEdge + 3, maxBY = im.h - kEdge + 3;
         std::vector<Candidate> cands = cellCandidates(level);
+        // portrait levels (box more than twice as tall as wide): the reference's nIni rounds to 0 and it divides by
+        // zero; defined here as "the level yields nothing", candidates included
+        if ((int)std::round((float)(maxBX - minBX) / (maxBY - minBY)) <= 0) cands.clear();
         levelCandidates[level] = (int)cands.size();
         std::vector<Candidate> kept = distribute(cands, minBX, maxBX, minBY, maxBY, mnFeaturesPerLevel[level]);
         const int scaledPatch = (int)(kPatchSize * mvScaleFactor[level]);

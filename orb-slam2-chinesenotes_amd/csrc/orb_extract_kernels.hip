@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void k_copy_level0(const uint8_t* __restrict__
     // flattened (row, 16-byte column) index: every lane of every wave has work (a 640-px row is only 40 columns)
     const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int f = blockIdx.y;
-    const int y = (int)(((unsigned long long)idx * invx) >> 32);
+    const int y = invx ? (int)(((unsigned long long)idx * invx) >> 32) : (int)idx;     // invx == 0: one item per row
     const int x16 = (int)idx - y * x16n;
     if (y >= h) return;
     const uint8_t* s = src + (size_t)f * frameStride + (size_t)y * rowStride + (size_t)x16 * 16;
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void k_resize_level4(uint8_t* __restrict__ pyr
     // flattened (row, pixel quad) index so that every lane has work whatever the level width
     const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int f = blockIdx.y;
-    const int y = (int)(((unsigned long long)idx * invx) >> 32);
+    const int y = invx ? (int)(((unsigned long long)idx * invx) >> 32) : (int)idx;     // invx == 0: one item per row
     const int x4 = (int)idx - y * x4n;
     if (y >= dh) return;
     const uint8_t* src = pyr + (size_t)f * pyrSlab + srcOff;
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void k_resize_level4p(uint8_t* __restrict__ py
 {
     const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int f = blockIdx.y;
-    const unsigned yg = (unsigned)(((unsigned long long)idx * invx) >> 32);
+    const unsigned yg = invx ? (unsigned)(((unsigned long long)idx * invx) >> 32) : idx;   // invx == 0: one quad per row
     const unsigned x4 = idx - __umul24(yg, (unsigned)x4n);
     const unsigned y0 = yg * RESIZE_ROWS;
     if ((int)y0 >= dh) return;
@@ -186,7 +186,8 @@ __global__ __launch_bounds__(256) void k_resize_level4p(uint8_t* __restrict__ py
 // ------------------------------------------------------------------------------------------------
 // launch wrappers (keep <<<>>> syntax inside this translation unit)
 // exact division of idx < 2^31 by d via multiply-high: q = (idx * ceil(2^32/d)) >> 32 is exact while idx*d < 2^32
-static unsigned inv32(int d) { return (unsigned)(((1ull << 32) + d - 1) / d); }
+// d == 1 has no 32-bit inverse: 0 tells the kernels that a row holds a single item (index == row)
+static unsigned inv32(int d) { return d <= 1 ? 0u : (unsigned)(((1ull << 32) + d - 1) / d); }
 
 void orb_launch_copy_level0(hipStream_t st, const uint8_t* src, size_t rowStride, size_t frameStride,
                             uint8_t* pyr, size_t pyrSlab, int w, int h, int pitch, int nFrames)

@@ -126,6 +126,13 @@ def test_tiny_images_with_degenerate_levels(w, h, levels):
     _cmp(synth.synth_frame(1, w, h), nfeatures=300, levels=levels)
 
 
+def test_levels_that_shrink_to_a_few_pixels():
+    # 9 levels at scale 1.75 take a 119x123 image down to 4x4, 2x2 and 1x1: rows of a single pixel quad once broke the
+    # flattened index decode of the pyramid kernels (no 32-bit reciprocal of 1) and faulted
+    _cmp(synth.synth_frame(5004, 119, 123), nfeatures=1000, levels=9, sf=1.75, ini=40, mn=12)
+    _cmp(synth.synth_frame(5005, 64, 64), nfeatures=200, levels=8, sf=1.5)
+
+
 def test_other_scale_factors_and_thresholds():
     _cmp(synth.synth_frame(12), nfeatures=800, levels=5, sf=1.5, ini=30, mn=10)
     _cmp(synth.synth_frame(13), nfeatures=1500, levels=10, sf=1.1, ini=12, mn=5)
@@ -187,3 +194,30 @@ def test_unsupported_geometry_is_reported_not_crashed():
     k, d = ex.extract(synth.synth_frame(3))                     # the handle stays usable
     assert len(k) > 900
     ex.close()
+
+
+def test_randomized_geometry_and_parameter_sweep():
+    """40 seeded random (size, nfeatures, levels, scale factor, thresholds) combinations, each bit-exact against the
+    oracle stage by stage: exercises odd widths/heights, degenerate upper levels, every resize path, cell grids with
+    remainders, quadtrees with 1..15 roots and quotas from a handful to thousands."""
+    rng = np.random.default_rng(20261004)
+    done = 0
+    for t in range(40):
+        w = int(rng.integers(90, 1400))
+        h = int(rng.integers(80, 1000))
+        if w > 14 * h:                                            # the extractor supports aspect ratios up to 15:1
+            w = 14 * h
+        nf = int(rng.choice([150, 400, 1000, 2000, 3500]))
+        levels = int(rng.integers(2, 11))
+        sf = float(rng.choice([1.1, 1.15, 1.2, 1.25, 1.3, 1.5, 1.75, 2.0]))
+        ini = int(rng.integers(8, 45))
+        mn = int(rng.integers(3, ini + 1))
+        img = synth.synth_frame(5000 + t, w, h)
+        try:
+            _cmp(img, nfeatures=nf, levels=levels, ini=ini, mn=mn, sf=sf)
+            done += 1
+        except capi.OrbError as e:                                # outside the supported envelope: must say so, not crash
+            assert e.code == -5, (w, h, nf, levels, sf, ini, mn, str(e))
+        except AssertionError as e:
+            raise AssertionError("config %d: %dx%d nfeatures=%d levels=%d sf=%g ini=%d min=%d: %s" % (t, w, h, nf, levels, sf, ini, mn, e))
+    assert done >= 30
