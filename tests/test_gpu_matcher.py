@@ -362,3 +362,145 @@ def test_search_for_triangulation(feats, only_stereo, ori, mono):
     wn, wm = oracle.search_for_triangulation(k1, d1, z1, None, fv1, k2, d2, z2, None, fv2, F12, 320.0, 240.0, sf * 400, sig2, False, ori)
     gn, gm = m.search_for_triangulation(k1, d1, z1, None, t1, k2, d2, z2, None, t2, F12, 320.0, 240.0, sf * 400, sig2, False)
     assert gn == wn and np.array_equal(gm, wm)
+
+
+def _rand_feature_sets(rng, na, nb, clustered):
+    """Two descriptor sets with planted near-duplicates; `clustered` squeezes them into few vocabulary nodes."""
+    def rnd(n):
+        d = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+        if clustered and n:
+            proto = rng.integers(0, 256, size=(3, 32), dtype=np.uint8)          # 3 tight clusters -> few, big nodes
+            d = proto[rng.integers(0, 3, n)] ^ (rng.integers(0, 256, size=(n, 32), dtype=np.uint8) & rng.integers(0, 256, size=(n, 32), dtype=np.uint8) & 0x11)
+        return d
+    da = rnd(na)
+    db = rnd(nb)
+    m = min(na, nb)
+    if m:
+        idx = rng.permutation(m)[: max(1, m * 2 // 3)]
+        flips = np.zeros((len(idx), 32), np.uint8)
+        for r in range(len(idx)):
+            for b in rng.integers(0, 256, rng.integers(0, 40)):
+                flips[r, b >> 3] ^= np.uint8(1 << (b & 7))
+        db[idx] = da[idx] ^ flips
+    aa = rng.uniform(0, 360, na).astype(np.float32)
+    ab = rng.uniform(0, 360, nb).astype(np.float32)
+    if m:
+        ab[idx] = (aa[idx] + rng.choice([0.0, 0.0, 0.0, 90.0], len(idx)).astype(np.float32) + rng.uniform(-3, 3, len(idx)).astype(np.float32)) % np.float32(360.0)
+    return da, aa, db, ab
+
+
+def test_search_by_bow_randomized_sizes():
+    """Both SearchByBoW variants on seeded random feature sets: sizes 0, 1, around the wave width, thousands; few big
+    vocabulary nodes (general > 64 path) and many small ones; random valid flags, ratios and orientation checks."""
+    rng = np.random.default_rng(77)
+    sizes = [0, 1, 2, 5, 63, 64, 65, 130, 500, 1000, 2600]
+    checked = 0
+    for t in range(36):
+        na, nb = int(rng.choice(sizes)), int(rng.choice(sizes))
+        clustered = bool(rng.integers(0, 3) == 0) and max(na, nb) <= 1000
+        ratio, ori = float(rng.choice([0.6, 0.7, 0.75, 0.9])), bool(rng.integers(0, 2))
+        da, aa, db, ab = _rand_feature_sets(rng, na, nb, clustered)
+        fva, ta = _fv(da)
+        fvb, tb = _fv(db)
+        va = (rng.random(na) < 0.7).astype(np.uint8)
+        vb = (rng.random(nb) < 0.7).astype(np.uint8)
+        m = capi.Matcher(ratio, ori)
+        wn, w = oracle.search_by_bow(da, aa, va, fva, db, ab, fvb, ratio, ori)
+        gn, g = m.search_by_bow(da, aa, va, ta, db, ab, tb)
+        assert gn == wn and np.array_equal(g, w), ("KF-F", t, na, nb, clustered, ratio, ori)
+        wn2, w2 = oracle.search_by_bow_kk(da, aa, va, fva, db, ab, vb, fvb, ratio, ori)
+        gn2, g2 = m.search_by_bow_kk(da, aa, va, ta, db, ab, vb, tb)
+        assert gn2 == wn2 and np.array_equal(g2, w2), ("KF-KF", t, na, nb, clustered, ratio, ori)
+        checked += wn + wn2
+    assert checked > 500                                           # the planted duplicates do get matched
+
+
+def _rand_keypoints(rng, n, w=640, h=480, level0_frac=0.5):
+    k = np.zeros(n, oracle.KP_DTYPE if hasattr(oracle, "KP_DTYPE") else capi.KP_DTYPE)
+    k["x"] = rng.uniform(16, w - 16, n).astype(np.float32)
+    k["y"] = rng.uniform(16, h - 16, n).astype(np.float32)
+    k["octave"] = np.where(rng.random(n) < level0_frac, 0, rng.integers(1, 8, n)).astype(np.int32)
+    k["size"] = 31.0
+    k["angle"] = rng.uniform(0, 360, n).astype(np.float32)
+    k["response"] = rng.integers(8, 200, n).astype(np.float32)
+    k["class_id"] = -1
+    return k
+
+
+def test_search_for_initialization_randomized_sizes():
+    """SearchForInitialization on seeded random keypoint sets: 0 / 1 / wave-width / thousands of features, dense
+    clusters (many candidates per window, match stealing), windows from 5 to 300 px, shifted grids."""
+    rng = np.random.default_rng(99)
+    sizes = [0, 1, 3, 63, 64, 65, 200, 900, 2100]
+    total = 0
+    for t in range(24):
+        n1, n2 = int(rng.choice(sizes)), int(rng.choice(sizes))
+        window = int(rng.choice([5, 20, 100, 300]))
+        ratio, ori = float(rng.choice([0.7, 0.9])), bool(rng.integers(0, 2))
+        d1, a1, d2, a2 = _rand_feature_sets(rng, n1, n2, False)
+        k1, k2 = _rand_keypoints(rng, n1), _rand_keypoints(rng, n2)
+        k1["angle"], k2["angle"] = a1, a2
+        m12 = min(n1, n2)
+        if m12:                                                    # planted duplicates sit near each other
+            k2["x"][:m12] = np.clip(k1["x"][:m12] + rng.uniform(-window, window, m12).astype(np.float32) * 0.7, 0, 639)
+            k2["y"][:m12] = np.clip(k1["y"][:m12] + rng.uniform(-window, window, m12).astype(np.float32) * 0.7, 0, 479)
+            k2["octave"][:m12] = 0
+            k1["octave"][:m12] = 0
+        if t % 5 == 4 and n2 > 10:                                 # one crowded spot: dozens of candidates per window
+            k2["x"][: n2 // 2] = np.float32(320) + rng.uniform(-8, 8, n2 // 2).astype(np.float32)
+            k2["y"][: n2 // 2] = np.float32(240) + rng.uniform(-8, 8, n2 // 2).astype(np.float32)
+        grid = GRID_640 if t % 3 else (-9.5, -4.25, 64.0 / 660.0, 48.0 / 490.0)
+        prev_ref = np.ascontiguousarray(np.stack([k1["x"], k1["y"]], axis=1), dtype=np.float32).reshape(n1, 2)
+        prev_gpu = prev_ref.copy()
+        m = capi.Matcher(ratio, ori)
+        wn, w = oracle.search_for_init(k1, d1, k2, d2, grid, prev_ref, window, ratio, ori)
+        gn, g = m.search_for_initialization(k1, d1, k2, d2, grid, prev_gpu, window)
+        assert gn == wn and np.array_equal(g, w) and prev_gpu.tobytes() == prev_ref.tobytes(), (t, n1, n2, window, ratio, ori)
+        total += wn
+    assert total > 200
+
+
+def test_projection_family_and_triangulation_randomized_subsets(feats):
+    """The SearchByProjection family, its best-candidate form and SearchForTriangulation on random SUBSETS of the
+    scene features: query / feature counts of 0, 1, 63..65 and ~1000, all modes, with and without stereo."""
+    rng = np.random.default_rng(123)
+    grid = (0.0, 0.0, 0.1, 0.1)
+    sizes = [0, 1, 2, 63, 64, 65, 300, 1000]
+    inv_sigma2 = (np.float32(1) / (np.float32(1.2) ** np.arange(8, dtype=np.float32)) ** 2).astype(np.float32)
+    sf = (np.float32(1.2) ** np.arange(8, dtype=np.float32)).astype(np.float32)
+    sig2 = (sf * sf).astype(np.float32)
+    total = 0
+    for t in range(20):
+        a, b = int(rng.integers(0, 3)), int(rng.integers(0, 3))
+        mode = int(rng.integers(0, 2))
+        level_mode = ["neither", "forward", "backward"][int(rng.integers(0, 3))] if mode == 0 else "map"
+        q, qd, qa, kb, db, ur, occ = _proj_scene(feats, a, b, mode, level_mode, 500 + t)
+        nq, n = min(int(rng.choice(sizes)), len(q)), min(int(rng.choice(sizes)), len(kb))
+        qs = np.sort(rng.permutation(len(q))[:nq])
+        fs = np.sort(rng.permutation(len(kb))[:n])
+        q, qd, qa = q[qs].copy(), np.ascontiguousarray(qd[qs]), np.ascontiguousarray(qa[qs])
+        kb, db, ur, occ = kb[fs].copy(), np.ascontiguousarray(db[fs]), np.ascontiguousarray(ur[fs]), np.ascontiguousarray(occ[fs])
+        ori = bool(rng.integers(0, 2))
+        m = capi.Matcher(0.8, ori)
+        wn, w = oracle.search_by_projection(mode, q, qd, qa, kb, db, ur, occ, grid, 0.8, ori)
+        gn, g = m.search_by_projection(mode, q, qd, qa, kb, db, ur, occ, grid)
+        assert gn == wn and np.array_equal(g, w), ("projection", t, mode, level_mode, nq, n, ori)
+        chi2 = bool(rng.integers(0, 2))
+        wi, wd = oracle.search_by_projection_best(q, qd, kb, db, ur, grid, 64, chi2, inv_sigma2)
+        gi, gd = m.search_by_projection_best(q, qd, kb, db, ur, grid, 64, chi2, inv_sigma2)
+        assert np.array_equal(gi, wi) and np.array_equal(gd, wd), ("best", t, nq, n, chi2)
+        total += wn + int((wi >= 0).sum())
+        # triangulation between the two subsets (frame a features restricted to the query subset)
+        (k1, d1) = feats[a]
+        k1, d1 = k1[qs].copy(), np.ascontiguousarray(d1[qs])
+        fv1, t1 = _fv(d1)
+        fv2, t2 = _fv(db)
+        mp1 = (rng.random(len(k1)) < 0.3).astype(np.uint8)
+        mp2 = (rng.random(len(kb)) < 0.3).astype(np.uint8)
+        F12 = np.array([[0, 0, 0.0004], [0, 0, -1.0], [-0.0003, 1.0, 0.2]], np.float32)
+        mt = capi.Matcher(0.6, ori)
+        twn, twm = oracle.search_for_triangulation(k1, d1, mp1, None, fv1, kb, db, mp2, None, fv2, F12, 5000.0, 240.0, sf, sig2, False, ori)
+        tgn, tgm = mt.search_for_triangulation(k1, d1, mp1, None, t1, kb, db, mp2, None, t2, F12, 5000.0, 240.0, sf, sig2, False)
+        assert tgn == twn and np.array_equal(tgm, twm), ("triangulation", t, nq, n, ori)
+        total += twn
+    assert total > 100
