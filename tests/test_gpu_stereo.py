@@ -48,3 +48,22 @@ def test_stereo_no_right_features_and_swapped_baseline():
     wu, wz = oracle.stereo_matches(rl, rr, kl, dl, kr, dr, 10.0, 40.0)
     gu, gz = capi.stereo_match(exl, exr, kl, dl, kr, dr, 10.0, 40.0)
     assert gu.tobytes() == wu.tobytes() and gz.tobytes() == wz.tobytes()
+
+
+@pytest.mark.parametrize("idx,w,h,nf", [(300, 240, 180, 300), (301, 752, 480, 1000), (302, 1241, 376, 500), (303, 400, 960, 700),
+                                        (304, 321, 245, 64), (305, 1000, 300, 3000)])
+def test_stereo_other_sizes_and_feature_counts(idx, w, h, nf):
+    (exl, exr, kl, dl, kr, dr), (rl, rr) = _pair(idx, w, h, nf)
+    for mb, mbf in ((MB, MBF), (0.12, 40.0)):
+        want_u, want_z = oracle.stereo_matches(rl, rr, kl, dl, kr, dr, mb, mbf)
+        got_u, got_z = capi.stereo_match(exl, exr, kl, dl, kr, dr, mb, mbf)
+        assert got_u.tobytes() == want_u.tobytes() and got_z.tobytes() == want_z.tobytes()
+    # subsets with awkward counts (the right side scanned 64 at a time)
+    rng = np.random.default_rng(idx)
+    for nl, nr in ((1, 65), (64, 1), (65, 63), (len(kl), 64)):
+        sl = np.sort(rng.permutation(len(kl))[:min(nl, len(kl))])
+        sr = np.sort(rng.permutation(len(kr))[:min(nr, len(kr))])
+        a = (kl[sl].copy(), np.ascontiguousarray(dl[sl]), kr[sr].copy(), np.ascontiguousarray(dr[sr]))
+        want_u, want_z = oracle.stereo_matches(rl, rr, *a, MB, MBF)
+        got_u, got_z = capi.stereo_match(exl, exr, *a, MB, MBF)
+        assert got_u.tobytes() == want_u.tobytes() and got_z.tobytes() == want_z.tobytes(), (nl, nr)
