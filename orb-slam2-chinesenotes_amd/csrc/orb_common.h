@@ -45,10 +45,23 @@ struct OrbGeom {
     OrbLevelGeom L[ORB_MAX_LEVELS];
 };
 
-struct OrbCell {                // one FAST cell ROI (reference :826-861), 12 bytes
+struct OrbCell {                // one FAST cell ROI (reference :826-861) + everything k_fast_cells derives from it, 32 bytes
     short x0, y0, w, h;         // ROI inside the level image
-    unsigned char level, ci, cj, pad;
+    unsigned char level, ci, cj;
+    unsigned char xoff;         // x0 & 3: the tile is staged from the aligned column xa = x0 - xoff
+    // derived on the host once per geometry (the kernel is vector-issue bound and has no scalar integer division):
+    unsigned char ndw;          // dwords per staged row = (xoff + w + 3) / 4
+    unsigned char rowsPerPass;  // 64 / ndw
+    unsigned char nq, stepR;    // quads covering the zone columns; 64 / nq
+    unsigned char qLo, hLo, nh; // first zone quad; first quad / number of quads of the halo-inclusive range
+    unsigned char zh;           // zone rows = h - 6
+    unsigned char zLo, zHi;     // zone columns [zLo, zHi) in tile bytes (zLo = xoff + 3)
+    unsigned char pad[2];
+    unsigned int invDw;         // ceil(2^20 / ndw), ceil(2^20 / nq): lane -> (row, column) without division
+    unsigned int invQ;
 };
+static_assert(sizeof(OrbCell) == 32, "OrbCell is loaded as one 32-byte scalar record");
+
 
 // Candidate key layout (64 bit), sorted ascending by the quadtree kernel:
 //   [61:58] quadtree root   [57:34] 12 x 2-bit quadrant path (depth 0 in the top bits)

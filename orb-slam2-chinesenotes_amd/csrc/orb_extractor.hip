@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstddef>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -154,7 +155,8 @@ static int build_geometry(orb_extractor* h, int rows, int cols)
                     OrbCell c;
                     c.x0 = (short)iniX; c.y0 = (short)iniY;
                     c.w = (short)((int)maxX - (int)iniX); c.h = (short)((int)maxY - (int)iniY);
-                    c.level = (unsigned char)l; c.ci = (unsigned char)i; c.cj = (unsigned char)j; c.pad = 0;
+                    std::memset(&c.level, 0, sizeof(c) - offsetof(OrbCell, level));
+                    c.level = (unsigned char)l; c.ci = (unsigned char)i; c.cj = (unsigned char)j;
                     if (c.w < 7 || c.h < 7) continue;                    // cv::FAST finds nothing in such a ROI
                     {   // k_fast_cells works on quads of 4 aligned columns: items = quads per row x zone rows
                         const int xoff = c.x0 & 3, zLo = xoff + 3, zHi = zLo + c.w - 6;
@@ -164,6 +166,18 @@ static int build_geometry(orb_extractor* h, int rows, int cols)
                             return ORB_ERR_UNSUPPORTED;
                         }
                         maxItems = std::max(maxItems, items);
+                        const int ndw = (xoff + c.w + 3) >> 2, qLo = zLo >> 2, nq = ((zHi - 1) >> 2) + 1 - qLo;
+                        const int hLo = (zLo - 1) >> 2, nh = (zHi >> 2) + 1 - hLo;
+                        c.xoff = (unsigned char)xoff;
+                        c.ndw = (unsigned char)ndw;
+                        c.rowsPerPass = (unsigned char)(64 / ndw);
+                        c.nq = (unsigned char)nq;
+                        c.stepR = (unsigned char)(64 / nq);
+                        c.qLo = (unsigned char)qLo; c.hLo = (unsigned char)hLo; c.nh = (unsigned char)nh;
+                        c.zh = (unsigned char)(c.h - 6);
+                        c.zLo = (unsigned char)zLo; c.zHi = (unsigned char)zHi;
+                        c.invDw = ((1u << 20) + ndw - 1) / ndw;
+                        c.invQ = ((1u << 20) + nq - 1) / nq;
                         maxPdw = std::max(maxPdw, (xoff + c.w + 3) / 4 + 1);       // staged dwords + one of right slack
                         maxRows = std::max(maxRows, (int)c.h);
                         maxZone = std::max(maxZone, (c.w - 6) * (c.h - 6));

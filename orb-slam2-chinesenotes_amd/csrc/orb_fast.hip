@@ -144,12 +144,11 @@ __global__ __launch_bounds__(WAVE) void k_fast_cells(const OrbGeom G, const uint
     const uint8_t* img = pyr + (size_t)f * pyrSlab + L.pyrOff;
 
     // ---- stage the ROI rows [y0, y0+h) as aligned dwords; lane -> (row in pass, dword column)
-    const int xa = cell.x0 & ~3, xoff = cell.x0 - xa;
-    const int ndw = (xoff + cell.w + 3) >> 2;                      // <= 18
+    const int xoff = cell.xoff, xa = cell.x0 - xoff;
+    const int ndw = cell.ndw;                                      // <= 18
     {
-        const unsigned inv = ((1u << 20) + ndw - 1) / ndw;
-        const int rp = (int)(((unsigned)lane * inv) >> 20), c = lane - rp * ndw;
-        const int rowsPerPass = WAVE / ndw;
+        const int rp = (int)(((unsigned)lane * cell.invDw) >> 20), c = lane - rp * ndw;
+        const int rowsPerPass = cell.rowsPerPass;
         if (rp < rowsPerPass) {
             const uint8_t* src = img + (size_t)(cell.y0 + rp) * L.pitch + xa + 4 * c;
             const size_t step = (size_t)rowsPerPass * L.pitch;
@@ -160,14 +159,13 @@ __global__ __launch_bounds__(WAVE) void k_fast_cells(const OrbGeom G, const uint
                 *dstp = *reinterpret_cast<const uint32_t*>(src);
         }
     }
-    const int zw = cell.w - 6, zh = cell.h - 6;                    // detection zone: tile rows [3,3+zh), cols [zLo,zHi)
-    const int zLo = xoff + 3, zHi = zLo + zw;
+    const int zh = cell.zh;                                        // detection zone: tile rows [3,3+zh), cols [zLo,zHi)
+    const int zLo = cell.zLo, zHi = cell.zHi;
     // Quads [qLo, qHi) cover the zone columns [zLo, zHi); the halo columns zLo-1 and zHi (and the rows above and
     // below the zone) only ever read as score 0 by the NMS -- cv::FAST scores nothing outside the ROI interior -- so
     // they are zeroed here instead of being run through the detector (one quad per row less for 3 alignments in 4).
-    const int qLo = zLo >> 2, qHi = ((zHi - 1) >> 2) + 1;
-    const int nq = qHi - qLo;
-    const int hLo = (zLo - 1) >> 2, hHi = (zHi >> 2) + 1, nh = hHi - hLo;        // halo-inclusive quad range
+    const int qLo = cell.qLo, nq = cell.nq, qHi = qLo + nq;
+    const int hLo = cell.hLo, nh = cell.nh, hHi = hLo + nh;        // halo-inclusive quad range
     for (int i = lane; i < 2 * nh; i += WAVE) {
         const int row = (i < nh) ? 2 : 3 + zh, q = hLo + (i < nh ? i : i - nh);
         smapDw[row * FT_PDW + q] = 0;
@@ -186,12 +184,12 @@ __global__ __launch_bounds__(WAVE) void k_fast_cells(const OrbGeom G, const uint
     const int lowTh = min(iniTh, minTh);
     const unsigned thK = (unsigned)(0x7fff - lowTh) * 0x10001u;
     const int nItems = nq * zh;
-    const unsigned invq = ((1u << 20) + nq - 1) / nq;
+    const unsigned invq = cell.invQ;
     int nA = 0, nB = 0;                                            // wave-uniform queue lengths
     // item -> (zone row ry, quad qi) is advanced incrementally (64 items per step): no per-item division
     int ry = (int)(((unsigned)lane * invq) >> 20);
     int qi = lane - ry * nq;
-    const int stepR = WAVE / nq, stepQ = WAVE - stepR * nq;
+    const int stepR = cell.stepR, stepQ = WAVE - stepR * nq;
     for (int base = 0; base < nItems; base += WAVE) {
         const int item = base + lane;
         bool pa = false, pb = false;
