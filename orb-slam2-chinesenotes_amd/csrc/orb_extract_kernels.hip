@@ -1,8 +1,9 @@
-// orb_extract_kernels.hip -- gfx950 kernels of the ORB extractor (wave64, LDS-tiled, no MFMA:
-// this is integer/bitwise stencil + gather work bounded by HBM/LDS, not a dense contraction).
+// orb_extract_kernels.hip -- the pyramid kernels of the ORB extractor on gfx950 (wave64; no MFMA: fixed-point
+// bilinear resampling, bound by the memory system).
 //
 // Stage map (reference src/ORBextractor.cc):
-//   k_copy_level0 / k_resize_level   ComputePyramid            :1153-1180  (cv::resize INTER_LINEAR)
+//   k_copy_level0 / k_resize_level4p (fallbacks k_resize_level4, k_resize_level)   ComputePyramid :1153-1180
+//                                                                                   (cv::resize INTER_LINEAR)
 //   (k_fast_cells lives in orb_fast.hip)
 //   (k_quadtree lives in orb_quadtree.hip)
 //   (k_orient_desc lives in orb_desc.hip)

@@ -2,20 +2,23 @@
 // Reference: the cell loop of ORBextractor::ComputeKeyPointsOctTree, src/ORBextractor.cc:795-875
 // (cv::FAST(cell ROI, iniThFAST, nonmax=true), fallback to minThFAST when it returns nothing).
 //
-// One wave64 per FAST cell (<= 66x66 px ROI).  What bounds this kernel is VALU issue (rocprofv3:
-// half of the wave-cycles are issue stalls on integer min/max), so the arithmetic is arranged for
-// the cheapest instruction mix CDNA4 offers:
-//   * the ROI is staged in LDS with aligned dword loads and read back as dwords: one lane computes
-//     FOUR horizontally adjacent pixels from a 7-row x 12-byte window (21 ds_read_b32);
-//   * V(p) = max(I_p - min_arcs max_arc ring, max_arcs min_arc ring - I_p) is evaluated on PAIRS of
-//     pixels with v_pk_maximum3_f16 / v_pk_minimum3_f16: a u8 stored in a 16-bit half is a positive
-//     f16 subnormal whose order is the integer order, so the packed 3-input float min/max is exact
-//     and moves 2 pixels x 3 operands per instruction (measured 2.1x the per-pixel rate of
-//     v_max3_i32; tools/ubench).  One v_perm_b32 builds each packed ring operand from the window;
+// One wave64 per FAST cell (<= 66x66 px ROI).  What bounds this kernel is VALU issue (rocprofv3: 95 % VALU-busy,
+// ~1090 vector instructions per cell), so the arithmetic is arranged for the cheapest instruction mix CDNA4 offers:
+//   * the ROI is staged in LDS with aligned dword loads; a lane works on a QUAD of 4 horizontally adjacent pixels
+//     as two packed pairs;
+//   * phase A is an exact cheap rejection on every pair: a 9-arc contains ring pixel k or k+8 for every k, so
+//     V <= U = max(I - max_k min(r_k, r_k+8), min_k max(r_k, r_k+8) - I); with the four even k (11 dword reads)
+//     about 3 pairs in 4 have U <= min(iniTh, minTh) in both pixels and are finished;
+//   * phase B computes the exact V(p) = max(I_p - min_arcs max_arc ring, max_arcs min_arc ring - I_p) only for the
+//     queued pairs (7 rows x 12 bytes: 21 dword reads), on dense lanes again;
+//   * both phases use v_pk_maximum3_f16 / v_pk_minimum3_f16: a u8 stored in a 16-bit half is a positive f16
+//     subnormal whose order is the integer order, so the packed 3-input float min/max is exact and moves 2 pixels x
+//     3 operands per instruction (tools/ubench).  One v_perm_b32 builds each packed ring operand from the window;
 //   * V is threshold-free: both thresholds and the NMS read the same u8 score map;
-//   * only pixels with V > min(iniTh, minTh) can ever be keypoints: they are queued (the queue
-//     re-uses the image tile's LDS) and NMS + emission run over the queue, not over the zone;
-//   * the quadtree path of a candidate is two table look-ups (x and y bisect independently).
+//   * only pixels with V > min(iniTh, minTh) can ever be keypoints: they are queued (the queue re-uses the image
+//     tile's LDS) and NMS + emission run over the queue, not over the zone;
+//   * the quadtree path of a candidate is two table look-ups (x and y bisect independently);
+//   * everything derived from the cell rectangle alone comes precomputed in the 32-byte OrbCell record.
 #include <algorithm>
 
 #include "orb_kernels.h"
@@ -25,7 +28,7 @@
 #define FT_PAD 4                       // dwords of slack around the tile (edge quads read one dword outside)
 // LDS is sized per image geometry (dynamic): tile and score map use a row pitch of `pdw` dwords that covers the
 // widest ROI of the frame (13 dwords at 640x480 instead of the 18 a 66-px ROI would need), which roughly doubles
-// the number of resident waves -- the kernel is latency/occupancy-bound once the arithmetic is this lean.
+// the number of resident waves.
 
 __device__ __forceinline__ unsigned pk_max3(unsigned a, unsigned b, unsigned c)
 {
