@@ -185,6 +185,88 @@ __global__ __launch_bounds__(256) void k_resize_level4p(uint8_t* __restrict__ py
 }
 
 // ------------------------------------------------------------------------------------------------
+// Two levels per launch.  The resize kernels are bound by the memory system (their time does not change when the
+// arithmetic is removed), and every level is written once and read back once; here a workgroup produces a BAND of
+// PAIR_ROWS rows of level D = M+1 together with the rows of level M those need: the M rows are computed from level
+// S = M-1 (global windows, as above), written to HBM (level M is an output of its own) AND kept in LDS, and the D
+// band is resampled from the LDS copy.  Level M is never read back from HBM (-23 % of the pyramid's traffic over the
+// pairs (1,2) (3,4) (5,6)).  Adjacent bands overlap by 1-2 rows of M, which both workgroups compute and write with
+// identical bytes.  Valid for scale <= 2 (consecutive D rows then draw on adjacent or overlapping M rows, so the
+// bands cover every row of M).  Measured at 640x480 x 512 frames: bands of 8 / 12 / 16 / 20 / 32 / 48 / 64 rows take
+// 0.380 / 0.362 / 0.346 / 0.358 / 0.362 / 0.378 / 0.42 ms for the whole pyramid, the unfused kernels 0.375 ms.
+#define PAIR_ROWS 16
+
+__global__ __launch_bounds__(256) void k_resize_pair(uint8_t* __restrict__ pyr, size_t pyrSlab, int srcOff, int srcPitch,
+                                                     int midOff, int midPitch, int midH, int dstOff, int dstPitch, int dstH,
+                                                     const uint4* __restrict__ xqM, const int2* __restrict__ ytabM, int x4M,
+                                                     unsigned invM, const uint4* __restrict__ xqD,
+                                                     const int2* __restrict__ ytabD, int x4D, unsigned invD, int ldsPitchDw)
+{
+    extern __shared__ uint32_t band[];                 // [rows of M][ldsPitchDw]
+    const int f = blockIdx.y;
+    const int R0 = blockIdx.x * PAIR_ROWS, R1 = min(R0 + PAIR_ROWS, dstH);
+    const uint8_t* src = pyr + (size_t)f * pyrSlab + srcOff;
+    uint8_t* mid = pyr + (size_t)f * pyrSlab + midOff;
+    uint8_t* dst = pyr + (size_t)f * pyrSlab + dstOff;
+    const int m0 = ytabD[R0].x & 0xffff, m1 = min((int)((unsigned)ytabD[R1 - 1].x >> 16), midH - 1);
+    const int nM = m1 - m0 + 1, gM = (nM + RESIZE_ROWS - 1) / RESIZE_ROWS;
+
+    // ---- rows m0..m1 of level M from level S: one item = 4 pixels x 4 rows, all loads before the first use
+    for (unsigned idx = threadIdx.x; idx < (unsigned)(gM * x4M); idx += blockDim.x) {
+        const unsigned g = __umulhi(idx, invM), x4 = idx - g * (unsigned)x4M;
+        const uint4 q0 = xqM[3 * x4], q1 = xqM[3 * x4 + 1];
+        const uint2 q2 = *reinterpret_cast<const uint2*>(xqM + 3 * x4 + 2);
+        int2 ty[RESIZE_ROWS];
+#pragma unroll
+        for (int r = 0; r < RESIZE_ROWS; r++) ty[r] = ytabM[min(m0 + (int)g * RESIZE_ROWS + r, m1)];
+        uint2 wA0[RESIZE_ROWS], wA1[RESIZE_ROWS], wB0[RESIZE_ROWS], wB1[RESIZE_ROWS];
+#pragma unroll
+        for (int r = 0; r < RESIZE_ROWS; r++) {
+            const unsigned rowA = __umul24((unsigned)ty[r].x & 0xffffu, (unsigned)srcPitch);
+            const unsigned rowB = __umul24((unsigned)ty[r].x >> 16, (unsigned)srcPitch);
+            wA0[r] = *reinterpret_cast<const uint2*>(src + (rowA + q0.x));
+            wA1[r] = *reinterpret_cast<const uint2*>(src + (rowA + q0.y));
+            wB0[r] = *reinterpret_cast<const uint2*>(src + (rowB + q0.x));
+            wB1[r] = *reinterpret_cast<const uint2*>(src + (rowB + q0.y));
+        }
+#pragma unroll
+        for (int r = 0; r < RESIZE_ROWS; r++) {
+            const unsigned lr = g * RESIZE_ROWS + r;
+            const unsigned b0 = (unsigned)ty[r].y & 0xffffu, b1 = (unsigned)ty[r].y >> 16;
+            const unsigned out = resize_px(wA0[r], wB0[r], q0.z, q1.z, b0, b1) | (resize_px(wA0[r], wB0[r], q0.w, q1.w, b0, b1) << 8) |
+                                 (resize_px(wA1[r], wB1[r], q1.x, q2.x, b0, b1) << 16) | (resize_px(wA1[r], wB1[r], q1.y, q2.y, b0, b1) << 24);
+            if ((int)lr < nM) {
+                band[lr * (unsigned)ldsPitchDw + x4] = out;
+                *reinterpret_cast<uint32_t*>(mid + (__umul24((unsigned)m0 + lr, (unsigned)midPitch) + x4 * 4)) = out;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- rows R0..R1-1 of level D from the LDS band, again 4 pixels x 4 rows per item
+    const int nD = R1 - R0, gD = (nD + RESIZE_ROWS - 1) / RESIZE_ROWS;
+    for (unsigned idx = threadIdx.x; idx < (unsigned)(gD * x4D); idx += blockDim.x) {
+        const unsigned g = __umulhi(idx, invD), x4 = idx - g * (unsigned)x4D;
+        const uint4 q0 = xqD[3 * x4], q1 = xqD[3 * x4 + 1];
+        const uint2 q2 = *reinterpret_cast<const uint2*>(xqD + 3 * x4 + 2);
+        const unsigned ia = q0.x >> 2, ib = q0.y >> 2;
+#pragma unroll
+        for (int r = 0; r < RESIZE_ROWS; r++) {
+            const int lr = (int)g * RESIZE_ROWS + r;
+            const int2 ty = ytabD[min(R0 + lr, R1 - 1)];
+            const unsigned b0 = (unsigned)ty.y & 0xffffu, b1 = (unsigned)ty.y >> 16;
+            const uint32_t* rowA = band + (unsigned)(((int)((unsigned)ty.x & 0xffffu) - m0) * ldsPitchDw);
+            const uint32_t* rowB = band + (unsigned)((min((int)((unsigned)ty.x >> 16), m1) - m0) * ldsPitchDw);
+            const uint2 wA0 = make_uint2(rowA[ia], rowA[ia + 1]), wA1 = make_uint2(rowA[ib], rowA[ib + 1]);
+            const uint2 wB0 = make_uint2(rowB[ia], rowB[ia + 1]), wB1 = make_uint2(rowB[ib], rowB[ib + 1]);
+            const unsigned out = resize_px(wA0, wB0, q0.z, q1.z, b0, b1) | (resize_px(wA0, wB0, q0.w, q1.w, b0, b1) << 8) |
+                                 (resize_px(wA1, wB1, q1.x, q2.x, b0, b1) << 16) | (resize_px(wA1, wB1, q1.y, q2.y, b0, b1) << 24);
+            if (lr < nD) *reinterpret_cast<uint32_t*>(dst + (__umul24((unsigned)(R0 + lr), (unsigned)dstPitch) + x4 * 4)) = out;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // launch wrappers (keep <<<>>> syntax inside this translation unit)
 // exact division of idx < 2^31 by d via multiply-high: q = (idx * ceil(2^32/d)) >> 32 is exact while idx*d < 2^32
 // d == 1 has no 32-bit inverse: 0 tells the kernels that a row holds a single item (index == row)
@@ -224,4 +306,27 @@ void orb_launch_resize(hipStream_t st, uint8_t* pyr, size_t pyrSlab, const OrbLe
     else
         hipLaunchKernelGGL(k_resize_level, grid, dim3(64, 4), 0, st, pyr, pyrSlab, src.pyrOff, src.pitch,
                            dst.pyrOff, dst.pitch, dst.w, dst.h, xtab, ytab);
+}
+
+// Levels M and M+1 in one launch (k_resize_pair); returns false when the pair is not eligible (the caller then
+// uses orb_launch_resize for each level).
+bool orb_launch_resize_pair(hipStream_t st, uint8_t* pyr, size_t pyrSlab, const OrbLevelGeom& S, const OrbLevelGeom& M,
+                            const OrbLevelGeom& D, const uint4* xqM, const int2* ytabM, const uint4* xqD, const int2* ytabD,
+                            int nFrames)
+{
+    if (!xqM || !xqD) return false;
+    const int x4M = (M.w + 3) / 4, x4D = (D.w + 3) / 4;
+    const double scaleD = (double)M.h / D.h;
+    if (x4M < 2 || x4D < 2 || scaleD > 2.0 || (double)M.w / D.w > 2.0) return false;
+    // rows of M one band needs: PAIR_ROWS * scale + 2, + 1 for rounding
+    const int maxRows = (int)(PAIR_ROWS * scaleD) + 4;
+    const int ldsPitchDw = x4M + 2;                             // 8-byte windows overrun a row by up to one dword
+    const size_t lds = (size_t)maxRows * ldsPitchDw * 4;
+    if (lds > 48 * 1024) return false;
+    if ((long long)maxRows * x4M * x4M >= (1ll << 32) || (long long)PAIR_ROWS * x4D * x4D >= (1ll << 32)) return false;
+    if ((long long)S.h * S.pitch >= (1ll << 31) || S.pitch >= (1 << 24) || M.pitch >= (1 << 24) || D.pitch >= (1 << 24)) return false;
+    const int bands = (D.h + PAIR_ROWS - 1) / PAIR_ROWS;
+    hipLaunchKernelGGL(k_resize_pair, dim3(bands, nFrames), dim3(256), lds, st, pyr, pyrSlab, S.pyrOff, S.pitch, M.pyrOff,
+                       M.pitch, M.h, D.pyrOff, D.pitch, D.h, xqM, ytabM, x4M, inv32(x4M), xqD, ytabD, x4D, inv32(x4D), ldsPitchDw);
+    return true;
 }

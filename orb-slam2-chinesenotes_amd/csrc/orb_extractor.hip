@@ -542,10 +542,21 @@ extern "C" int orb_extract_batch_device(orb_extractor* h, const uint8_t* d_imgs,
     ORB_HIP_TRY(hipMemsetAsync(h->dStat.p, 0, orb_extractor::statInts(n) * 4, st));
     if (prof) ORB_HIP_TRY(hipEventRecord(pe[0], st));
     orb_launch_copy_level0(st, d_imgs, rowStride, frameStride, pyr, h->pyrSlab, G.L[0].w, G.L[0].h, G.L[0].pitch, n);
-    for (int l = 1; l < G.nlevels; l++)
-        orb_launch_resize(st, pyr, h->pyrSlab, G.L[l - 1], G.L[l], (const int2*)h->dXtab.p + h->xtabOff[l],
-                          (const int2*)h->dYtab.p + h->ytabOff[l],
-                          h->xqOff[l] >= 0 ? (const uint4*)h->dXq.p + h->xqOff[l] : nullptr, n);
+    {
+        auto xq_of = [&](int l) { return h->xqOff[l] >= 0 ? (const uint4*)h->dXq.p + h->xqOff[l] : (const uint4*)nullptr; };
+        auto ytab_of = [&](int l) { return (const int2*)h->dYtab.p + h->ytabOff[l]; };
+        for (int l = 1; l < G.nlevels;) {
+            if (l + 1 < G.nlevels &&
+                orb_launch_resize_pair(st, pyr, h->pyrSlab, G.L[l - 1], G.L[l], G.L[l + 1], xq_of(l), ytab_of(l), xq_of(l + 1),
+                                       ytab_of(l + 1), n)) {
+                l += 2;
+                continue;
+            }
+            orb_launch_resize(st, pyr, h->pyrSlab, G.L[l - 1], G.L[l], (const int2*)h->dXtab.p + h->xtabOff[l], ytab_of(l),
+                              xq_of(l), n);
+            l++;
+        }
+    }
     if (prof) ORB_HIP_TRY(hipEventRecord(pe[1], st));
     orb_launch_fast_cells(st, G, pyr, h->pyrSlab, (const OrbCell*)h->dCells.p, (int)h->cells.size(),
                           (const uint32_t*)h->dPath.p, scand, h->candSlab, scc, serr, h->prm.ini_th_fast,
