@@ -175,7 +175,7 @@ def main():
 
     total_frames = frames_done
     fps = total_frames / elapsed
-    names = ["pyramid(k_copy_level0+7x k_resize_level)", "k_fast_cells", "k_quadtree", "k_orient_desc"]
+    names = ["pyramid(k_copy_level0 + resize kernels)", "k_fast_cells", "k_quadtree", "k_orient_desc"]
     dom = int(np.argmax(stage_ms[:4]))
     bytes_frame = algorithmic_bytes_per_frame(W, H, pyr_px, mean_kp)
     achieved = bytes_frame * launch_frames / (float(stage_ms[dom]) * 1e-3) / 1e9

@@ -62,7 +62,7 @@ def main():
     fetch, write = pmc(fetch_dir, "FETCH_SIZE"), pmc(write_dir, "WRITE_SIZE")
     res = {"frames_per_launch": frames, "unit": "bytes per launch (avg over launches)",
            "note": "FETCH_SIZE/WRITE_SIZE in KiB x1024; FETCH doubled only for 16-B/lane kernels (gfx950 correction); "
-                   "dword-load kernels uncorrected (uncalibrated width); k_resize_level4 is the average over the 7 levels",
+                   "dword-load kernels uncorrected (uncalibrated width); resize kernels are averages over their launches (k_resize_pair: levels 1+2, 3+4, 5+6; k_resize_level4p: level 7)",
            "bytes_per_launch": {}, "fetch_bytes": {}, "write_bytes": {}}
     for k in sorted(set(fetch) | set(write)):
         if not k.startswith("k_"):
