@@ -39,6 +39,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--input-sets", type=int, default=2,
+                    help="distinct input batches that consecutive steps alternate between: one 157 MB batch re-read every "
+                         "step would sit in the 256 MB Infinity Cache and flatter the pyramid's first kernel")
     ap.add_argument("--pipeline", type=int, default=1,
                     help="number of independent (extractor, matcher, output buffers) lanes that consecutive steps alternate "
                          "between; lanes run on their own streams, so step k+1 overlaps step k")
@@ -89,8 +92,9 @@ def main():
 
     # ---- synthetic inputs, resident in HBM before the timed region
     first, _ = shard.weak_range(B, rank)            # weak scaling: every rank owns B frames of its own
-    frames_np = synth.synth_batch(first, B, W, H)
-    d_imgs = torch.from_numpy(frames_np).to(dev)
+    n_sets = max(1, args.input_sets)
+    frames_sets = [synth.synth_batch(first + k * world * B, B, W, H) for k in range(n_sets)]
+    d_img_sets = [torch.from_numpy(fr).to(dev) for fr in frames_sets]
     d_kps = torch.zeros(B * cap * 28, dtype=torch.uint8, device=dev)
     d_desc = torch.zeros(B * cap * 32, dtype=torch.uint8, device=dev)
     d_counts = torch.zeros(B, dtype=torch.int32, device=dev)
@@ -124,6 +128,8 @@ def main():
 
     def step():
         ln = lanes[step_no[0] % len(lanes)]
+        ln["set"] = step_no[0] % n_sets                # which input batch this lane's buffers will hold results of
+        d_imgs = d_img_sets[ln["set"]]
         step_no[0] += 1
         lx, lm = ln["ex"], ln["mt"]
         lx.wait_for(lm.stream)                     # this lane's outputs of its previous step are still being matched
@@ -187,7 +193,7 @@ def main():
         "config": {"workload": "batch of %d synthetic %dx%d frames per GPU, nFeatures=%d, 8 levels, scale 1.2, "
                                "FAST 20/7; extract + SearchByBoW(frame i as keyframe, frame i+1), ratio 0.7"
                                % (B, W, H, args.nfeatures),
-                   "frames_per_gpu": B, "match": not args.no_match, "mean_keypoints": round(mean_kp, 1),
+                   "frames_per_gpu": B, "input_sets": n_sets, "match": not args.no_match, "mean_keypoints": round(mean_kp, 1),
                    "mean_bow_matches": round(float(nm.mean()), 1),
                    "frames_per_launch": launch_frames,
                    "stage_ms_per_launch": {n: round(float(v), 4) for n, v in zip(names + ["extract_total"], stage_ms)}},
@@ -207,7 +213,7 @@ def main():
             pass
 
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args, frames_np, d_kps, d_desc, counts, cap, nm, d_match)
+        out["cpu_baseline"] = cpu_baseline(args, frames_sets[lanes[0]["set"]], d_kps, d_desc, counts, cap, nm, d_match)
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
