@@ -258,8 +258,6 @@ static int build_geometry(orb_extractor* h, int rows, int cols)
     // It starts small (more resident workgroups: the kernel is latency-bound) and orb_extractor_sync() grows it to
     // the largest candidate count actually seen, so steady-state batches sort in LDS.
     h->sortCap = 1024;
-    h->sortCapFixed = false;
-    if (const char* e = getenv("ORB_SORT_CAP")) { h->sortCap = std::max(256, atoi(e)); h->sortCapFixed = true; }
     while (h->sortCap > 256 && orb_quadtree_lds_bytes(h->sortCap, nodeCap) > 60 * 1024) h->sortCap >>= 1;
     if (orb_quadtree_lds_bytes(h->sortCap, nodeCap) > 64 * 1024) {
         orb_set_error("nfeatures too large for the quadtree kernel's LDS budget");
@@ -581,7 +579,7 @@ static int check_status(orb_extractor* h)
     const int n = h->lastFrames;
     const int* err = h->hStat.data();
     const int* cand = err + n;
-    if (!h->sortCapFixed) {                            // adapt the quadtree's LDS sort capacity to the data
+    {                                                  // adapt the quadtree's LDS sort capacity to the data
         int mx = 0;
         for (size_t i = 0; i < (size_t)ORB_MAX_LEVELS * n; i++) mx = std::max(mx, cand[i]);
         int want = 1024;

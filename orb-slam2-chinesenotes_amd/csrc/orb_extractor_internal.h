@@ -45,7 +45,6 @@ struct orb_extractor {
     std::vector<OrbCell> cells;
     size_t pyrSlab = 0, candSlab = 0;
     int sortCap = 4096, nodeCap = 0, maxKp = 0;
-    bool sortCapFixed = false;
     int fastMaxItems = 64, fastPdw = 18, fastRows = 66, fastMaxZone = 3600;   // LDS sizing of k_fast_cells
 
     // device memory
