@@ -82,3 +82,23 @@ def test_extract_transform_match_chain_on_device():
         assert nm[p] == wn_ and np.array_equal(match[p, :len(kb)], wm), (a, b)
         total += wn_
     assert total > 50 * len(pairs)
+
+
+def test_vocab_transform_randomized_trees_and_sizes():
+    """Tree descent on seeded random trees (branching 2..10, depth 2..6, pruned and unpruned) with descriptor counts of
+    0, 1, around the wave width and thousands, every levelsup the tree allows."""
+    rng = np.random.default_rng(321)
+    m = capi.Matcher()
+    for t in range(14):
+        k, L = int(rng.integers(2, 11)), int(rng.integers(2, 7))
+        if k ** L > 200000:
+            L = 4
+        tree = synth.synth_vocab_tree(k, L, seed=1000 + t, prune=float(rng.choice([0.0, 0.1, 0.3])))
+        v = capi.Vocabulary(tree)
+        for n in (0, 1, 63, 64, 65, int(rng.integers(200, 3000))):
+            desc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+            for levelsup in sorted({0, 1, L - 1, L, int(rng.integers(0, L + 1))}):
+                ww, wn = oracle.vocab_transform(tree, desc, levelsup)
+                gw, gn = v.transform(m, desc, levelsup)
+                assert np.array_equal(gw, ww) and np.array_equal(gn, wn), (t, k, L, n, levelsup)
+        v.close()
