@@ -251,8 +251,70 @@ __global__ __launch_bounds__(1024) void k_match_bow(const BowSide* __restrict__ 
         const int na = cntA[node], nb = cntB[node];
         if (na == 0 || nb == 0) continue;
         const int a0 = startA[node], b0 = startB[node];
-        if (nb <= WAVE) {
-            // ---- fast path: the node's B features fit the wave; everything stays in registers
+        if (nb <= 16) {
+            // ---- small node (the usual case: ~10 features per node and frame): the wave works as 4 rows of 16
+            // lanes, every row holding the node's B features, and takes 4 A features at a time -- their distances
+            // are computed side by side, then the rows are resolved in order because the greedy "already taken"
+            // rule couples them.  Row minima are 4-step DPP reductions (row_shr), broadcast with v_readlane.
+            const int rowI = lane >> 4, col = lane & 15;
+            uint32_t dB[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            int jB = -1;
+            bool taken = true;                                     // columns >= nb count as taken (distance 256)
+            if (col < nb) {
+                jB = (int)(keysB[b0 + col] & 0xFFFFu);
+                load_desc(B.desc + (size_t)jB * 32, dB);
+                taken = takenB[jB] != 0;
+            }
+            for (int abase = 0; abase < na; abase += 4) {
+                const int p = abase + rowI;
+                uint32_t dA[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                int iA = -1;
+                bool okA = false;
+                if (p < na) {
+                    iA = (int)(keysA[a0 + p] & 0xFFFFu);
+                    okA = !(A.valid && !A.valid[iA]);              // :590-595
+                    if (okA) load_desc(A.desc + (size_t)iA * 32, dA);
+                }
+                unsigned d = 0;
+#pragma unroll
+                for (int w = 0; w < 8; w++) d += __popc(dB[w] ^ dA[w]);
+                const unsigned long long okMask = __ballot(okA);
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    if (abase + r >= na) break;
+                    if (!((okMask >> (16 * r)) & 1)) continue;
+                    const unsigned mine = ((taken ? 256u : d) << 16) | (unsigned)col;
+                    unsigned v1 = mine;
+                    ORB_DPP_STEP_UMIN(v1, 0x111, 0xf);
+                    ORB_DPP_STEP_UMIN(v1, 0x112, 0xf);
+                    ORB_DPP_STEP_UMIN(v1, 0x114, 0xf);
+                    ORB_DPP_STEP_UMIN(v1, 0x118, 0xf);
+                    const unsigned m1 = (unsigned)__builtin_amdgcn_readlane((int)v1, 16 * r + 15);
+                    unsigned v2 = mine == m1 ? 0xFFFFFFFFu : mine;
+                    ORB_DPP_STEP_UMIN(v2, 0x111, 0xf);
+                    ORB_DPP_STEP_UMIN(v2, 0x112, 0xf);
+                    ORB_DPP_STEP_UMIN(v2, 0x114, 0xf);
+                    ORB_DPP_STEP_UMIN(v2, 0x118, 0xf);
+                    const unsigned m2 = (unsigned)__builtin_amdgcn_readlane((int)v2, 16 * r + 15);
+                    const int best1 = (int)(m1 >> 16), best2 = (int)(m2 >> 16);      // 256 when nothing is left
+                    const bool pass = KK ? (best1 < TH_LOW) : (best1 <= TH_LOW);      // :772 vs :625
+                    if (pass && (float)best1 < __fmul_rn(ratio, (float)best2)) {
+                        const int win = (int)(m1 & 0xFFFFu);
+                        if (col == win) {
+                            taken = true;                          // in every row: the column is gone
+                            if (rowI == r) {
+                                takenB[jB] = 1;
+                                const int rIdx = KK ? iA : jB;
+                                res[rIdx] = (int16_t)(KK ? jB : iA);
+                                if (checkOri)
+                                    bin[rIdx] = (uint8_t)rot_bin(A.angle[(size_t)iA * A.angleStride], B.angle[(size_t)jB * B.angleStride]);
+                            }
+                        }
+                    }
+                }
+            }
+        } else if (nb <= WAVE) {
+            // ---- medium node: the node's B features fit the wave; everything stays in registers
             uint32_t dB[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             int jB = -1;
             bool taken = true;
