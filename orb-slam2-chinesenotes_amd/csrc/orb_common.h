@@ -45,22 +45,30 @@ struct OrbGeom {
     OrbLevelGeom L[ORB_MAX_LEVELS];
 };
 
-struct OrbCell {                // one FAST cell ROI (reference :826-861) + everything k_fast_cells derives from it, 32 bytes
-    short x0, y0, w, h;         // ROI inside the level image
-    unsigned char level, ci, cj;
-    unsigned char xoff;         // x0 & 3: the tile is staged from the aligned column xa = x0 - xoff
-    // derived on the host once per geometry (the kernel is vector-issue bound and has no scalar integer division):
-    unsigned char ndw;          // dwords per staged row = (xoff + w + 3) / 4
-    unsigned char rowsPerPass;  // 64 / ndw
-    unsigned char nq, stepR;    // quads covering the zone columns; 64 / nq
+// One work item of k_fast_strips: a run of `nc` horizontally adjacent FAST cells of one cell row (reference
+// :826-861: cell (ci, cj) has the ROI [16 + cj*wCell, +wCell+6) x [16 + ci*hCell, +hCell+6), clipped).  The detection
+// zones of adjacent cells (ROI minus cv::FAST's 3-px rim) tile the plane without overlap, so the strip is ONE tile
+// whose zone columns [zLo, zHi) are cut into cells every wCell columns; only the NMS and the threshold fallback
+// look at cell boundaries.  Everything the kernel would derive from the rectangle comes precomputed (the kernel is
+// vector-issue bound and has no integer division).
+struct OrbStrip {
+    short x0, y0, w, h;         // ROI of the strip inside the level image (first cell's ROI start, last cell's ROI end)
+    unsigned char level, ci, cj0, nc;
+    unsigned char xoff;         // x0 & 7: the tile is staged from the 8-byte aligned column x0 - xoff
+    unsigned char nx8;          // 8-byte groups per staged row = (xoff + w + 7) / 8
+    unsigned char stepG;        // 64 / nx8
+    unsigned char nq, stepR;    // quads (4 aligned columns) covering the zone columns; 64 / nq
     unsigned char qLo, hLo, nh; // first zone quad; first quad / number of quads of the halo-inclusive range
-    unsigned char zh;           // zone rows = h - 6
+    unsigned char zh;           // zone rows = h - 6 (tile rows [3, 3 + zh))
     unsigned char zLo, zHi;     // zone columns [zLo, zHi) in tile bytes (zLo = xoff + 3)
-    unsigned char pad[2];
-    unsigned int invDw;         // ceil(2^20 / ndw), ceil(2^20 / nq): lane -> (row, column) without division
-    unsigned int invQ;
+    unsigned char wCell;        // zone width of every cell of the strip but the (possibly clipped) last
+    short cxBase;               // cj0 * wCell - xoff: tile column -> x relative to the level's minBorderX (:868)
+    unsigned short zonePx;      // (zHi - zLo) * zh
+    unsigned int invX8, invQ;   // ceil(2^20 / nx8), ceil(2^20 / nq): lane -> (row, column) without division
+    unsigned int invW;          // ceil(2^16 / wCell): zone column -> cell of the strip
+    unsigned int pad[2];
 };
-static_assert(sizeof(OrbCell) == 32, "OrbCell is loaded as one 32-byte scalar record");
+static_assert(sizeof(OrbStrip) == 48, "OrbStrip is loaded as one scalar record");
 
 
 // Candidate key layout (64 bit), sorted ascending by the quadtree kernel:

@@ -99,20 +99,88 @@ static void axis_table(int srcLen, int dstLen, bool isX, std::vector<int2>& out)
     }
 }
 
-// level sizes, FAST cell list, quadtree boxes, slab layout for a rows x cols input
+// One row of FAST cells (reference :826-861) cut into strips of about `target` cells (k_fast_strips works on a strip)
+struct FastCellRow {
+    int level, ci, y0, h;
+    std::vector<int> x0, w;     // ROI start / width of the cells that the reference runs cv::FAST on (cj = index)
+};
+
+static int make_strips(const FastCellRow& row, int wCell, int target, std::vector<OrbStrip>& out, int& maxPdw, int& maxRows,
+                       int& maxSdw)
+{
+    const int J = (int)row.x0.size();
+    if (J == 0) return ORB_OK;
+    // columns are addressed with 8 bits inside the tile: xoff (<= 7) + strip ROI width <= 255
+    int kMax = std::max(1, std::min(8, (248 - 6) / wCell));
+    const int K = std::max(1, std::min(target, kMax));
+    const int nStrips = (J + K - 1) / K;
+    for (int s = 0, j0 = 0; s < nStrips; s++) {
+        const int nc = J / nStrips + (s < J % nStrips ? 1 : 0), j1 = j0 + nc - 1;
+        OrbStrip S;
+        std::memset(&S, 0, sizeof(S));
+        S.x0 = (short)row.x0[j0];
+        S.y0 = (short)row.y0;
+        S.w = (short)(row.x0[j1] + row.w[j1] - row.x0[j0]);
+        S.h = (short)row.h;
+        S.level = (unsigned char)row.level; S.ci = (unsigned char)row.ci; S.cj0 = (unsigned char)j0; S.nc = (unsigned char)nc;
+        const int xoff = S.x0 & 7, zLo = xoff + 3, zHi = zLo + S.w - 6;
+        if (xoff + S.w > 255 || S.h > 66 || wCell > 255) {
+            orb_set_error("FAST strip %dx%d too large for the kernel", (int)S.w, (int)S.h);
+            return ORB_ERR_UNSUPPORTED;
+        }
+        const int nx8 = (xoff + S.w + 7) / 8, qLo = zLo >> 2, nq = ((zHi - 1) >> 2) + 1 - qLo;
+        const int hLo = (zLo - 1) >> 2, nh = (zHi >> 2) + 1 - hLo;
+        S.xoff = (unsigned char)xoff;
+        S.nx8 = (unsigned char)nx8;
+        S.stepG = (unsigned char)(64 / nx8);
+        S.nq = (unsigned char)nq;
+        S.stepR = (unsigned char)(64 / nq);
+        S.qLo = (unsigned char)qLo; S.hLo = (unsigned char)hLo; S.nh = (unsigned char)nh;
+        S.zh = (unsigned char)(S.h - 6);
+        S.zLo = (unsigned char)zLo; S.zHi = (unsigned char)zHi;
+        S.wCell = (unsigned char)wCell;
+        S.cxBase = (short)(j0 * wCell - xoff);
+        S.zonePx = (unsigned short)((zHi - zLo) * (S.h - 6));
+        S.invX8 = ((1u << 20) + nx8 - 1) / nx8;
+        S.invQ = ((1u << 20) + nq - 1) / nq;
+        S.invW = ((1u << 16) + wCell - 1) / wCell;
+        for (int n = 0; n < zHi - zLo; n++)                              // the kernel's division-free cell index
+            if ((int)(((unsigned)n * S.invW) >> 16) != n / wCell) { orb_set_error("FAST cell index reciprocal inexact"); return ORB_ERR_INTERNAL; }
+        for (int l = 0; l < 64; l++)
+            if ((int)(((unsigned)l * S.invX8) >> 20) != l / nx8 || (int)(((unsigned)l * S.invQ) >> 20) != l / nq) {
+                orb_set_error("FAST lane decode reciprocal inexact");
+                return ORB_ERR_INTERNAL;
+            }
+        maxPdw = std::max(maxPdw, 2 * nx8);
+        maxRows = std::max(maxRows, (int)S.h);
+        maxSdw = std::max(maxSdw, nh);
+        out.push_back(S);
+        j0 += nc;
+    }
+    return ORB_OK;
+}
+
+// level sizes, FAST strips, quadtree boxes, slab layout for a rows x cols input.  Everything is built into locals
+// and committed to the handle only on success: a failed call leaves the handle without a geometry (rows = cols = 0),
+// never with a half-built one.
 static int build_geometry(orb_extractor* h, int rows, int cols)
 {
     const int nl = h->prm.nlevels;
-    OrbGeom& G = h->G;
+    h->rows = h->cols = 0;
+    OrbGeom G;
     std::memset(&G, 0, sizeof(G));
     G.nlevels = nl;
     for (int i = 0; i < 16; i++) G.umaxPacked |= (unsigned long long)(h->umax[i] & 15) << (4 * i);
-    h->cells.clear();
+    std::vector<OrbStrip> strips;
+    int nCells = 0;
     size_t pyrOff = 0;
     size_t candOff = 0;
     int kpOff = 0, nodeCap = 0;
     std::vector<uint32_t> pathTab;
-    int maxItems = 1, maxPdw = 4, maxRows = 7, maxZone = 1;
+    int maxPdw = 4, maxRows = 7, maxSdw = 1;
+    int stripTarget = h->fastStripCells;
+    if (const char* e = std::getenv("ORB_FAST_STRIP")) stripTarget = std::atoi(e);
+    stripTarget = std::max(1, std::min(8, stripTarget));
     for (int l = 0; l < nl; l++) {
         OrbLevelGeom& L = G.L[l];
         L.w = cv_round_f((float)cols * h->invScale[l]);                 // :1158
@@ -135,6 +203,8 @@ static int build_geometry(orb_extractor* h, int rows, int cols)
         const float width = (float)(maxBX - minB), height = (float)(maxBY - minB);
         const int nCols = (int)(width / 30.f), nRows = (int)(height / 30.f);
         int candCap = 0;
+        const size_t firstStrip = strips.size();
+        const int firstCell = nCells;
         if (nCols > 0 && nRows > 0) {
             const int wCell = (int)std::ceil(width / nCols), hCell = (int)std::ceil(height / nRows);
             if (wCell > 60 || hCell > 60 || nCols > 128 || nRows > 128) {
@@ -147,44 +217,24 @@ static int build_geometry(orb_extractor* h, int rows, int cols)
                 float maxY = iniY + hCell + 6;
                 if (iniY >= maxBY - 3) continue;
                 if (maxY > maxBY) maxY = (float)maxBY;
+                FastCellRow row;
+                row.level = l; row.ci = i; row.y0 = (int)iniY; row.h = (int)maxY - (int)iniY;
                 for (int j = 0; j < nCols; j++) {
                     const float iniX = (float)(minB + j * wCell);
                     float maxX = iniX + wCell + 6;
                     if (iniX >= maxBX - 6) continue;
                     if (maxX > maxBX) maxX = (float)maxBX;
-                    OrbCell c;
-                    c.x0 = (short)iniX; c.y0 = (short)iniY;
-                    c.w = (short)((int)maxX - (int)iniX); c.h = (short)((int)maxY - (int)iniY);
-                    std::memset(&c.level, 0, sizeof(c) - offsetof(OrbCell, level));
-                    c.level = (unsigned char)l; c.ci = (unsigned char)i; c.cj = (unsigned char)j;
-                    if (c.w < 7 || c.h < 7) continue;                    // cv::FAST finds nothing in such a ROI
-                    {   // k_fast_cells works on quads of 4 aligned columns: items = quads per row x zone rows
-                        const int xoff = c.x0 & 3, zLo = xoff + 3, zHi = zLo + c.w - 6;
-                        const int items = (((zHi - 1) >> 2) + 1 - (zLo >> 2)) * (c.h - 6);    // quads covering [zLo, zHi)
-                        if (items > 1024) {                              // <= 16 quad steps per lane
-                            orb_set_error("FAST cell %dx%d too large for the kernel", c.w, c.h);
-                            return ORB_ERR_UNSUPPORTED;
-                        }
-                        maxItems = std::max(maxItems, items);
-                        const int ndw = (xoff + c.w + 3) >> 2, qLo = zLo >> 2, nq = ((zHi - 1) >> 2) + 1 - qLo;
-                        const int hLo = (zLo - 1) >> 2, nh = (zHi >> 2) + 1 - hLo;
-                        c.xoff = (unsigned char)xoff;
-                        c.ndw = (unsigned char)ndw;
-                        c.rowsPerPass = (unsigned char)(64 / ndw);
-                        c.nq = (unsigned char)nq;
-                        c.stepR = (unsigned char)(64 / nq);
-                        c.qLo = (unsigned char)qLo; c.hLo = (unsigned char)hLo; c.nh = (unsigned char)nh;
-                        c.zh = (unsigned char)(c.h - 6);
-                        c.zLo = (unsigned char)zLo; c.zHi = (unsigned char)zHi;
-                        c.invDw = ((1u << 20) + ndw - 1) / ndw;
-                        c.invQ = ((1u << 20) + nq - 1) / nq;
-                        maxPdw = std::max(maxPdw, (xoff + c.w + 3) / 4 + 1);       // staged dwords + one of right slack
-                        maxRows = std::max(maxRows, (int)c.h);
-                        maxZone = std::max(maxZone, (c.w - 6) * (c.h - 6));
-                    }
-                    h->cells.push_back(c);
-                    candCap += ((c.w - 6 + 1) / 2) * ((c.h - 6 + 1) / 2);   // 3x3 strict NMS bound
+                    const int cw = (int)maxX - (int)iniX;
+                    if (cw < 7 || row.h < 7) continue;                   // cv::FAST finds nothing in such a ROI
+                    // the skip rules are monotone in j, so the cells of a row are cj = 0 .. J-1 without gaps
+                    if ((int)row.x0.size() != j) { orb_set_error("FAST cell row with a gap"); return ORB_ERR_INTERNAL; }
+                    row.x0.push_back((int)iniX);
+                    row.w.push_back(cw);
+                    candCap += ((cw - 6 + 1) / 2) * ((row.h - 6 + 1) / 2);   // 3x3 strict NMS bound
+                    nCells++;
                 }
+                const int rc = make_strips(row, wCell, stripTarget, strips, maxPdw, maxRows, maxSdw);
+                if (rc != ORB_OK) return rc;
             }
         }
         L.candBase = (int)candOff;
@@ -204,7 +254,8 @@ static int build_geometry(orb_extractor* h, int rows, int cols)
         if (nIni <= 0) {
             // reference divides by zero here (portrait images): defined as "no keypoints"
             L.nIni = 0; L.hX = 1.f; L.candCap = 0;
-            while (!h->cells.empty() && h->cells.back().level == l) h->cells.pop_back();
+            strips.resize(firstStrip);
+            nCells = firstCell;
         } else {
             L.nIni = nIni;
             L.hX = (float)L.boxW / nIni;
@@ -246,32 +297,26 @@ static int build_geometry(orb_extractor* h, int rows, int cols)
         nodeCap = std::max(nodeCap, L.kpCap);
     }
     G.kpSlab = kpOff;
-    h->pyrSlab = (size_t)align_up((int)pyrOff, 256);
-    h->candSlab = candOff;
-    h->nodeCap = nodeCap;
-    h->maxKp = kpOff;
-    h->fastMaxItems = (maxItems + 63) / 64 * 64;
-    h->fastPdw = maxPdw;
-    h->fastRows = maxRows;
-    h->fastMaxZone = maxZone;
     // LDS sort capacity per (frame, level) instance; larger candidate sets are sorted in global memory.
     // It starts small (more resident workgroups: the kernel is latency-bound) and orb_extractor_sync() grows it to
     // the largest candidate count actually seen, so steady-state batches sort in LDS.
-    h->sortCap = 1024;
-    while (h->sortCap > 256 && orb_quadtree_lds_bytes(h->sortCap, nodeCap) > 60 * 1024) h->sortCap >>= 1;
-    if (orb_quadtree_lds_bytes(h->sortCap, nodeCap) > 64 * 1024) {
+    int sortCap = 1024;
+    while (sortCap > 256 && orb_quadtree_lds_bytes(sortCap, nodeCap) > 60 * 1024) sortCap >>= 1;
+    if (orb_quadtree_lds_bytes(sortCap, nodeCap) > 64 * 1024) {
         orb_set_error("nfeatures too large for the quadtree kernel's LDS budget");
         return ORB_ERR_UNSUPPORTED;
     }
-    h->rows = rows;
-    h->cols = cols;
+    if (orb_fast_lds_bytes(maxPdw, maxRows, 4096) > 64 * 1024 || orb_fast_dense_lds_bytes(maxPdw, maxRows, maxSdw) > 64 * 1024) {
+        orb_set_error("FAST strip tile needs more than 64 KB of LDS");
+        return ORB_ERR_UNSUPPORTED;
+    }
 
     // upload constants for this geometry
     int rc;
-    if (!h->cells.empty()) {
-        if ((rc = h->dCells.ensure(h->cells.size() * sizeof(OrbCell))) != ORB_OK) return rc;
-        ORB_HIP_TRY(hipMemcpyAsync(h->dCells.p, h->cells.data(), h->cells.size() * sizeof(OrbCell),
-                                   hipMemcpyHostToDevice, h->stream));
+    if (!strips.empty()) {
+        if ((rc = h->dCells.ensure(strips.size() * sizeof(OrbStrip))) != ORB_OK) return rc;
+        ORB_HIP_TRY(hipMemcpyAsync(h->dCells.p, strips.data(), strips.size() * sizeof(OrbStrip), hipMemcpyHostToDevice,
+                                   h->stream));
     }
     if (!pathTab.empty()) {
         if ((rc = h->dPath.ensure(pathTab.size() * 4)) != ORB_OK) return rc;
@@ -323,7 +368,25 @@ static int build_geometry(orb_extractor* h, int rows, int cols)
         }
     }
     ORB_HIP_TRY(hipStreamSynchronize(h->stream));     // host vectors go out of scope
+    // commit
+    h->G = G;
+    h->strips.swap(strips);
+    h->nCells = nCells;
+    h->pyrSlab = (size_t)align_up((int)pyrOff, 256);
+    h->candSlab = candOff;
+    h->nodeCap = nodeCap;
+    h->maxKp = kpOff;
+    h->fastPdw = maxPdw;
+    h->fastRows = maxRows;
+    h->fastSdw = maxSdw;
+    // candidate queue of a strip (pixels whose score exceeds the lower threshold); a strip with more switches to
+    // the dense scan.  At most 64 queue steps (one bit per step in the kernel).
+    h->fastCandCap = 640;
+    if (const char* e = std::getenv("ORB_FAST_CANDCAP")) h->fastCandCap = std::max(64, std::min(4096, std::atoi(e)));
+    h->sortCap = sortCap;
     h->framesCap = 0;                                  // slabs changed size: re-allocate lazily
+    h->rows = rows;
+    h->cols = cols;
     return ORB_OK;
 }
 
@@ -334,6 +397,7 @@ static int ensure_scratch(orb_extractor* h, int nFrames)
     if ((rc = h->dPyr.ensure(h->pyrSlab * nFrames + 256)) != ORB_OK) return rc;   // + slack: window loads overrun a row by <= 11 B
     if ((rc = h->dCand.ensure(h->candSlab * 8 * nFrames)) != ORB_OK) return rc;
     if ((rc = h->dKpl.ensure((size_t)h->G.kpSlab * 4 * nFrames)) != ORB_OK) return rc;
+    if ((rc = h->dOvf.ensure((size_t)4 * std::max<size_t>(1, h->strips.size()) * nFrames)) != ORB_OK) return rc;
     if ((rc = h->dStat.ensure(orb_extractor::statInts(nFrames) * 4)) != ORB_OK) return rc;
     h->framesCap = nFrames;
     return ORB_OK;
@@ -403,7 +467,7 @@ extern "C" void orb_extractor_destroy(orb_extractor* h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    DevBuf* bufs[] = {&h->dPattern, &h->dAngTab, &h->dCells, &h->dXtab, &h->dYtab, &h->dXq, &h->dPath, &h->dPyr, &h->dCand, &h->dKpl,
+    DevBuf* bufs[] = {&h->dPattern, &h->dAngTab, &h->dCells, &h->dXtab, &h->dYtab, &h->dXq, &h->dPath, &h->dPyr, &h->dCand, &h->dKpl, &h->dOvf,
                       &h->dStat, &h->dImgs, &h->dKps, &h->dDesc, &h->dCounts,
                       &h->dStereo, &h->dStereoIn};
     for (DevBuf* b : bufs) b->release();
@@ -556,9 +620,9 @@ extern "C" int orb_extract_batch_device(orb_extractor* h, const uint8_t* d_imgs,
         }
     }
     if (prof) ORB_HIP_TRY(hipEventRecord(pe[1], st));
-    orb_launch_fast_cells(st, G, pyr, h->pyrSlab, (const OrbCell*)h->dCells.p, (int)h->cells.size(),
-                          (const uint32_t*)h->dPath.p, scand, h->candSlab, scc, serr, h->prm.ini_th_fast,
-                          h->prm.min_th_fast, h->fastMaxItems, h->fastPdw, h->fastRows, h->fastMaxZone, n);
+    orb_launch_fast_strips(st, G, pyr, h->pyrSlab, (const OrbStrip*)h->dCells.p, (int)h->strips.size(),
+                           (const uint32_t*)h->dPath.p, scand, h->candSlab, scc, serr, h->ovfCountP(), (int*)h->dOvf.p,
+                           h->prm.ini_th_fast, h->prm.min_th_fast, h->fastPdw, h->fastRows, h->fastSdw, h->fastCandCap, n);
     if (prof) ORB_HIP_TRY(hipEventRecord(pe[2], st));
     orb_launch_quadtree(st, G, scand, h->candSlab, scc, skpl, skc, serr, h->sortCap, h->nodeCap, n);
     if (prof) ORB_HIP_TRY(hipEventRecord(pe[3], st));

@@ -42,23 +42,27 @@ struct orb_extractor {
     // geometry for the current image size
     int rows = 0, cols = 0;
     OrbGeom G;
-    std::vector<OrbCell> cells;
+    std::vector<OrbStrip> strips;               // FAST work items (runs of cells of one cell row)
+    int nCells = 0;
     size_t pyrSlab = 0, candSlab = 0;
     int sortCap = 4096, nodeCap = 0, maxKp = 0;
-    int fastMaxItems = 64, fastPdw = 18, fastRows = 66, fastMaxZone = 3600;   // LDS sizing of k_fast_cells
+    int fastPdw = 20, fastRows = 66, fastSdw = 18, fastCandCap = 640;   // LDS sizing of k_fast_strips
+    int fastStripCells = 4;                 // cells per strip aimed at (ORB_FAST_STRIP overrides, 1..8)
 
     // device memory
     DevBuf dPattern, dAngTab, dCells, dXtab, dYtab, dXq, dPath;   // constants
     std::vector<size_t> xtabOff, ytabOff;       // per level offsets (in int2 units)
     std::vector<long long> xqOff;               // per level offset into dXq (uint4 units), -1 = level not eligible
-    DevBuf dPyr, dCand, dKpl;                   // per-batch scratch
+    DevBuf dPyr, dCand, dKpl, dOvf;             // per-batch scratch (dOvf: FAST strips to redo densely)
     // per-batch status words, ONE allocation so that one memset clears it and one copy fetches it:
-    // [err: n][FAST candidates per level: 8n][keypoints per level: 8n] for the n frames of the current batch
+    // [err: n][FAST candidates per level: 8n][keypoints per level: 8n][FAST overflow-list length: 1 (+3 pad)]
+    // for the n frames of the current batch
     DevBuf dStat;
     int* errP() const { return (int*)dStat.p; }
     int* candCountP() const { return (int*)dStat.p + lastFrames; }
     int* kpCountP() const { return (int*)dStat.p + (size_t)(1 + ORB_MAX_LEVELS) * lastFrames; }
-    static size_t statInts(int n) { return (size_t)(1 + 2 * ORB_MAX_LEVELS) * n; }
+    int* ovfCountP() const { return (int*)dStat.p + (size_t)(1 + 2 * ORB_MAX_LEVELS) * lastFrames; }
+    static size_t statInts(int n) { return (size_t)(1 + 2 * ORB_MAX_LEVELS) * n + 4; }
     DevBuf dImgs, dKps, dDesc, dCounts;         // staging for the host-buffer API
     DevBuf dStereo, dStereoIn;                  // stereo search: (SAD, index) pairs; host-API staging
     const int8_t* patternPtr = nullptr;         // device pointer in use (own copy or caller's)

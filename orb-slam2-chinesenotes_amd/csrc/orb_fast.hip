@@ -1,24 +1,33 @@
-// orb_fast.hip -- per-cell FAST-9/16 detection on gfx950.
+// orb_fast.hip -- FAST-9/16 detection over strips of cells on gfx950.
 // Reference: the cell loop of ORBextractor::ComputeKeyPointsOctTree, src/ORBextractor.cc:795-875
 // (cv::FAST(cell ROI, iniThFAST, nonmax=true), fallback to minThFAST when it returns nothing).
 //
-// One wave64 per FAST cell (<= 66x66 px ROI).  What bounds this kernel is VALU issue (rocprofv3: 95 % VALU-busy,
-// ~1090 vector instructions per cell), so the arithmetic is arranged for the cheapest instruction mix CDNA4 offers:
-//   * the ROI is staged in LDS with aligned dword loads; a lane works on a QUAD of 4 horizontally adjacent pixels
+// One wave64 per STRIP = a run of horizontally adjacent cells of one cell row (OrbStrip, orb_common.h).  The detection
+// zones of adjacent cells tile the plane without overlap, so the score V of a pixel does not depend on its cell; only
+// the 3x3 NMS (cell-local: it must not see the neighbouring cell) and the iniTh -> minTh fallback (per cell) do.
+// The kernel is bound by VALU issue and, below ~20 waves per CU, by latency (rocprofv3, profiles/r02_*_valu.json:
+// time follows 1/occupancy), so it is arranged for few instructions, DENSE lanes and a small LDS footprint:
+//   * the strip ROI is staged in LDS with 8-byte loads; a lane works on a QUAD of 4 horizontally adjacent pixels
 //     as two packed pairs;
 //   * phase A is an exact cheap rejection on every pair: a 9-arc contains ring pixel k or k+8 for every k, so
 //     V <= U = max(I - max_k min(r_k, r_k+8), min_k max(r_k, r_k+8) - I); with the four even k (11 dword reads)
-//     about 3 pairs in 4 have U <= min(iniTh, minTh) in both pixels and are finished;
-//   * phase B computes the exact V(p) = max(I_p - min_arcs max_arc ring, max_arcs min_arc ring - I_p) only for the
-//     queued pairs (7 rows x 12 bytes: 21 dword reads), on dense lanes again;
+//     about 5 pairs in 6 have U <= min(iniTh, minTh) in both pixels and are finished;
+//   * surviving pairs go to two small ring queues (left / right pair of a quad) that are drained 64 at a time as
+//     soon as 64 are waiting: phase B, the exact V(p) = max(I_p - min_arcs max_arc ring, max_arcs min_arc ring - I_p)
+//     (7 rows x 12 bytes: 17 dword reads), always runs on full waves except for one last partial step per queue and
+//     strip (one wave per CELL left phase B at 2.6 steps for 1.5 waves of work);
 //   * both phases use v_pk_maximum3_f16 / v_pk_minimum3_f16: a u8 stored in a 16-bit half is a positive f16
 //     subnormal whose order is the integer order, so the packed 3-input float min/max is exact and moves 2 pixels x
 //     3 operands per instruction (tools/ubench).  One v_perm_b32 builds each packed ring operand from the window;
-//   * V is threshold-free: both thresholds and the NMS read the same u8 score map;
-//   * only pixels with V > min(iniTh, minTh) can ever be keypoints: they are queued (the queue re-uses the image
-//     tile's LDS) and NMS + emission run over the queue, not over the zone;
+//   * V is threshold-free, and only pixels with V > min(iniTh, minTh) can ever be keypoints OR suppress one (a
+//     neighbour at or below the threshold in force is below the pixel it would suppress): phase B appends exactly
+//     those, (row, col, score), to a candidate queue.  There is NO score map next to the tile: when all scores are
+//     known the tile is dead, it is zeroed, the candidates' scores are scattered into it and the NMS reads it as the
+//     score map -- LDS per wave is one tile, not two (23 instead of 13 waves per CU at 3 cells per strip);
+//   * NMS + emission run over the queue, not over the zone.  A strip whose candidates overflow the queue (noise
+//     images) is put on a list and redone by k_fast_strips_dense (tile + full score map, dense scan): same results;
 //   * the quadtree path of a candidate is two table look-ups (x and y bisect independently);
-//   * everything derived from the cell rectangle alone comes precomputed in the 32-byte OrbCell record.
+//   * everything derived from the strip rectangle alone comes precomputed in the 48-byte OrbStrip record.
 #include <algorithm>
 
 #include "orb_kernels.h"
@@ -26,9 +35,9 @@
 
 #define WAVE 64
 #define FT_PAD 4                       // dwords of slack around the tile (edge quads read one dword outside)
-// LDS is sized per image geometry (dynamic): tile and score map use a row pitch of `pdw` dwords that covers the
-// widest ROI of the frame (13 dwords at 640x480 instead of the 18 a 66-px ROI would need), which roughly doubles
-// the number of resident waves.
+#define FT_QRING 128                   // entries of one pair ring: < 64 left over + <= 64 appended per phase-A step
+// LDS is sized per image geometry (dynamic): the tile uses a row pitch of `pdw` dwords (even: rows are staged with
+// 8-byte stores) that covers the widest strip of the frame.
 
 __device__ __forceinline__ unsigned pk_max3(unsigned a, unsigned b, unsigned c)
 {
@@ -120,258 +129,437 @@ __device__ __forceinline__ unsigned fast_pair(const unsigned (&W)[7][3])
     return pk_max_i16(v, 0u);
 }
 
-__global__ __launch_bounds__(WAVE) void k_fast_cells(const OrbGeom G, const uint8_t* __restrict__ pyr,
-                                                     size_t pyrSlab, const OrbCell* __restrict__ cells,
-                                                     const uint32_t* __restrict__ pathTab,
-                                                     unsigned long long* __restrict__ cand, size_t candSlab,
-                                                     int* __restrict__ candCount, int* __restrict__ errFlags,
-                                                     int iniTh, int minTh, int maxItems, int pdw, int rowsMax, int tileDwords,
-                                                     int nCells, int nFrames, unsigned invPerFrame)
+
+__device__ __forceinline__ int mbcnt64(unsigned long long m)
 {
-    // dynamic LDS: [pad | tile (>= 2 bytes per zone pixel: it later holds the candidate queue) | pad | score map | pair queues]
-    extern __shared__ uint32_t fsm[];
-    uint32_t* tileDw = fsm + FT_PAD;
-    uint32_t* smapDw = tileDw + tileDwords + FT_PAD;
-    uint16_t* pairQ = reinterpret_cast<uint16_t*>(smapDw + rowsMax * pdw);   // [2][maxItems]
-    const int FT_PDW = pdw, FT_PITCH = 4 * pdw;
-    const int lane = threadIdx.x;
-    int f, ci;
-    if (invPerFrame) {                                             // 1-D XCD-aware grid: a frame's cells share one L2
-        if (!orb_xcd_decode(blockIdx.x, (unsigned)nCells, invPerFrame, nFrames, f, ci)) return;
-    } else {
-        f = blockIdx.y;
-        ci = blockIdx.x;
-    }
-    const OrbCell cell = cells[ci];
-    const OrbLevelGeom& L = G.L[cell.level];
-    const uint8_t* img = pyr + (size_t)f * pyrSlab + L.pyrOff;
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
 
-    // ---- stage the ROI rows [y0, y0+h) as aligned dwords; lane -> (row in pass, dword column)
-    const int xoff = cell.xoff, xa = cell.x0 - xoff;
-    const int ndw = cell.ndw;                                      // <= 18
-    {
-        const int rp = (int)(((unsigned)lane * cell.invDw) >> 20), c = lane - rp * ndw;
-        const int rowsPerPass = cell.rowsPerPass;
-        if (rp < rowsPerPass) {
-            const uint8_t* src = img + (size_t)(cell.y0 + rp) * L.pitch + xa + 4 * c;
-            const size_t step = (size_t)rowsPerPass * L.pitch;
-            uint32_t* dstp = tileDw + rp * FT_PDW + c;
-            const int dstep = rowsPerPass * FT_PDW;
-#pragma unroll 4
-            for (int r = rp; r < cell.h; r += rowsPerPass, src += step, dstp += dstep)
-                *dstp = *reinterpret_cast<const uint32_t*>(src);
+// 3x3 strict NMS test of the score at (row, col), cell-local: columns outside [cs, ce) belong to the neighbouring
+// cell, which cv::FAST on this cell's ROI never scores.  sc = S-1 must exceed max(0, scores of the neighbours above
+// th); a neighbour at or below th is below S anyway, so this is S > max(1, raw neighbour values).
+__device__ __forceinline__ bool fast_nms_ok(const uint8_t* s, int pitch, bool first, bool last, int S)
+{
+    int m = max(max((int)s[-pitch], (int)s[pitch]), 1);
+    const int l = max(max((int)s[-pitch - 1], (int)s[-1]), (int)s[pitch - 1]);
+    const int r = max(max((int)s[-pitch + 1], (int)s[1]), (int)s[pitch + 1]);
+    if (!first) m = max(m, l);
+    if (!last) m = max(m, r);
+    return S > m;
+}
+
+// where the scores of phase B go: DENSE = score map (smapZ[row * spitch + col]); otherwise the candidate queue
+struct FastSink {
+    uint8_t* smapZ;             // DENSE
+    int spitch;
+    uint16_t* candPos;          // queue: row << 8 | col
+    uint8_t* candScore;
+    int candCap;
+    int nCand;                  // may exceed candCap: overflow, nothing beyond candCap was stored
+};
+
+// one phase-B step: exact scores of up to 64 queued pairs (H = 0: pixels 4q, 4q+1; H = 1: 4q+2, 4q+3)
+template <int H, bool DENSE>
+__device__ __forceinline__ void fast_bstep(const uint32_t* tileDw, const uint16_t* Q, int head, int n, int lane, int pdw,
+                                           int zLo, int zHi, int lowTh, FastSink& K)
+{
+    const bool act = lane < n;
+    int sLo = 0, sHi = 0, row = 0, cx = 0;
+    if (act) {
+        const int ent = Q[(head + lane) & (FT_QRING - 1)];
+        row = ent >> 8;
+        const int q = ent & 0xff;
+        unsigned W[7][3];
+#pragma unroll
+        for (int r = 0; r < 7; r++) {
+            const uint32_t* p = tileDw + (row - 3 + r) * pdw + q - 1;
+            W[r][0] = p[0]; W[r][1] = p[1]; W[r][2] = p[2];
         }
+        const unsigned s2 = H ? fast_pair<6>(W) : fast_pair<4>(W);      // two scores, one per 16-bit half
+        cx = 4 * q + 2 * H;
+        sLo = (int)(s2 & 0xff);
+        sHi = (int)((s2 >> 16) & 0xff);
+        if (!(cx >= zLo && cx < zHi)) sLo = 0;                           // pixel of the neighbouring strip
+        if (!(cx + 1 >= zLo && cx + 1 < zHi)) sHi = 0;
+        if (DENSE) *reinterpret_cast<uint16_t*>(K.smapZ + row * K.spitch + cx) = (uint16_t)(sLo | (sHi << 8));
     }
-    const int zh = cell.zh;                                        // detection zone: tile rows [3,3+zh), cols [zLo,zHi)
-    const int zLo = cell.zLo, zHi = cell.zHi;
-    // Quads [qLo, qHi) cover the zone columns [zLo, zHi); the halo columns zLo-1 and zHi (and the rows above and
-    // below the zone) only ever read as score 0 by the NMS -- cv::FAST scores nothing outside the ROI interior -- so
-    // they are zeroed here instead of being run through the detector (one quad per row less for 3 alignments in 4).
-    const int qLo = cell.qLo, nq = cell.nq, qHi = qLo + nq;
-    const int hLo = cell.hLo, nh = cell.nh, hHi = hLo + nh;        // halo-inclusive quad range
-    for (int i = lane; i < 2 * nh; i += WAVE) {
-        const int row = (i < nh) ? 2 : 3 + zh, q = hLo + (i < nh ? i : i - nh);
-        smapDw[row * FT_PDW + q] = 0;
+    if (!DENSE) {
+        const bool pLo = sLo > lowTh, pHi = sHi > lowTh;
+        const unsigned long long bLo = __ballot(pLo), bHi = __ballot(pHi);
+        const int nLo = __popcll(bLo), nHi = __popcll(bHi);
+        if (K.nCand + nLo + nHi <= K.candCap) {
+            const int e = (row << 8) | cx;
+            if (pLo) {
+                const int w = K.nCand + mbcnt64(bLo);
+                K.candPos[w] = (uint16_t)e;
+                K.candScore[w] = (uint8_t)sLo;
+            }
+            if (pHi) {
+                const int w = K.nCand + nLo + mbcnt64(bHi);
+                K.candPos[w] = (uint16_t)(e + 1);
+                K.candScore[w] = (uint8_t)sHi;
+            }
+        }
+        K.nCand += nLo + nHi;
     }
-    for (int i = lane; i < 2 * zh; i += WAVE) {                                   // left / right halo quads of the zone rows
-        const int row = 3 + (i >> 1), q = (i & 1) ? hHi - 1 : hLo;
-        if (q < qLo || q >= qHi) smapDw[row * FT_PDW + q] = 0;
-    }
-    __syncthreads();
+}
 
-    // ---- phase A: cheap exact rejection on every pixel pair (what cv::FAST's threshold tests amount to).
+// ---- stage the ROI rows [y0, y0+h) as aligned 8-byte groups; item -> (row, group) advanced incrementally
+__device__ __forceinline__ void fast_stage(const OrbStrip& S, const uint8_t* img, int pitch, uint32_t* tileDw, int pdw,
+                                           int lane)
+{
+    const int nx = S.nx8, total = nx * S.h;
+    int r = (int)(((unsigned)lane * S.invX8) >> 20), g = lane - r * nx;
+    const int stR = S.stepG, stG = WAVE - stR * nx;
+    const uint8_t* base = img + (size_t)S.y0 * pitch + (S.x0 - S.xoff);
+#pragma unroll 4
+    for (int i = lane; i < total; i += WAVE) {
+        const uint2 v = *reinterpret_cast<const uint2*>(base + r * pitch + 8 * g);
+        *reinterpret_cast<uint2*>(tileDw + r * pdw + 2 * g) = v;
+        g += stG;
+        r += stR;
+        if (g >= nx) { g -= nx; r++; }
+    }
+}
+
+// ---- phases A and B over the zone of a staged strip
+template <bool DENSE>
+__device__ __forceinline__ void fast_detect(const OrbStrip& S, const uint32_t* tileDw, int FT_PDW, uint16_t* pairQ,
+                                            uint32_t* smapQ, int sdw, int lowTh, int lane, FastSink& K)
+{
+    // phase A: cheap exact rejection on every pixel pair (what cv::FAST's threshold tests amount to).
     // A 9-arc of the 16-ring contains ring pixel k or k+8 for every k, so with lo_k = min(r_k, r_k+8),
     // hi_k = max(r_k, r_k+8):   V <= U := max(I - max_k lo_k, min_k hi_k - I).
     // Only the 4 even k are used here (rows y, y+-2, y+-3: 11 dword reads instead of 21); pairs with
     // U <= lowTh in both pixels score 0 (never a corner at either threshold) and skip the exact V (about 5 in 6 pairs).
-    const int lowTh = min(iniTh, minTh);
+    const int zh = S.zh, zLo = S.zLo, zHi = S.zHi, qLo = S.qLo, nq = S.nq;
     const unsigned thK = (unsigned)(0x7fff - lowTh) * 0x10001u;
     const int nItems = nq * zh;
-    const unsigned invq = cell.invQ;
-    int nA = 0, nB = 0;                                            // wave-uniform queue lengths
+    int cntA = 0, cntB = 0, headA = 0, headB = 0;                  // wave-uniform ring state
     // item -> (zone row ry, quad qi) is advanced incrementally (64 items per step): no per-item division
-    int ry = (int)(((unsigned)lane * invq) >> 20);
+    int ry = (int)(((unsigned)lane * S.invQ) >> 20);
     int qi = lane - ry * nq;
-    const int stepR = cell.stepR, stepQ = WAVE - stepR * nq;
-    for (int base = 0; base < nItems; base += WAVE) {
-        const int item = base + lane;
-        bool pa = false, pb = false;
-        const int q = qLo + qi;
-        const int row = 3 + ry;
-        if (item < nItems) {
-            const uint32_t* p = tileDw + row * FT_PDW + q - 1;
-            const unsigned c0 = p[0], c1 = p[1], c2 = p[2];                                   // row y
-            const unsigned u1 = p[-3 * FT_PDW + 1], d1 = p[3 * FT_PDW + 1];                   // rows y-3, y+3: x .. x+3
-            const unsigned a0 = p[-2 * FT_PDW], a1 = p[-2 * FT_PDW + 1], a2 = p[-2 * FT_PDW + 2];   // row y-2
-            const unsigned b0 = p[2 * FT_PDW], b1 = p[2 * FT_PDW + 1], b2 = p[2 * FT_PDW + 2];      // row y+2
-            smapDw[row * FT_PDW + q] = 0;
-            unsigned u[2];
+    const int stepR = S.stepR, stepQ = WAVE - stepR * nq;
+    for (int base = 0;; base += WAVE) {
+        const bool more = base < nItems;
+        if (more) {
+            const int item = base + lane;
+            bool pa = false, pb = false;
+            const int q = qLo + qi;
+            const int row = 3 + ry;
+            if (item < nItems) {
+                const uint32_t* p = tileDw + row * FT_PDW + q - 1;
+                const unsigned c0 = p[0], c1 = p[1], c2 = p[2];                                   // row y
+                const unsigned u1 = p[-3 * FT_PDW + 1], d1 = p[3 * FT_PDW + 1];                   // rows y-3, y+3: x .. x+3
+                const unsigned a0 = p[-2 * FT_PDW], a1 = p[-2 * FT_PDW + 1], a2 = p[-2 * FT_PDW + 2];   // row y-2
+                const unsigned b0 = p[2 * FT_PDW], b1 = p[2 * FT_PDW + 1], b2 = p[2 * FT_PDW + 2];      // row y+2
+                if (DENSE) smapQ[row * sdw + q] = 0;
+                unsigned u[2];
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                // window byte index of the pair's first pixel: 4 (pixels 4q,4q+1) or 6 (4q+2,4q+3)
-                const unsigned cc = h ? pick2<6>(c0, c1, c2) : pick2<4>(c0, c1, c2);
-                const unsigned r0 = h ? pick2<6>(0, d1, 0) : pick2<4>(0, d1, 0);              // k=0  (0,+3)
-                const unsigned r8 = h ? pick2<6>(0, u1, 0) : pick2<4>(0, u1, 0);              // k=8  (0,-3)
-                const unsigned r4 = h ? pick2<9>(c0, c1, c2) : pick2<7>(c0, c1, c2);          // k=4  (+3,0)
-                const unsigned r12 = h ? pick2<3>(c0, c1, c2) : pick2<1>(c0, c1, c2);         // k=12 (-3,0)
-                const unsigned r2 = h ? pick2<8>(b0, b1, b2) : pick2<6>(b0, b1, b2);          // k=2  (+2,+2)
-                const unsigned r10 = h ? pick2<4>(a0, a1, a2) : pick2<2>(a0, a1, a2);         // k=10 (-2,-2)
-                const unsigned r6 = h ? pick2<8>(a0, a1, a2) : pick2<6>(a0, a1, a2);          // k=6  (+2,-2)
-                const unsigned r14 = h ? pick2<4>(b0, b1, b2) : pick2<2>(b0, b1, b2);         // k=14 (-2,+2)
-                const unsigned mlo = pk_max3(pk_min2(r0, r8), pk_min2(r4, r12), pk_max2(pk_min2(r2, r10), pk_min2(r6, r14)));
-                const unsigned mhi = pk_min3(pk_max2(r0, r8), pk_max2(r4, r12), pk_min2(pk_max2(r2, r10), pk_max2(r6, r14)));
-                u[h] = pk_max_i16(pk_sub_i16(cc, mlo), pk_sub_i16(mhi, cc));                  // U per 16-bit half (signed)
+                for (int h = 0; h < 2; h++) {
+                    // window byte index of the pair's first pixel: 4 (pixels 4q,4q+1) or 6 (4q+2,4q+3)
+                    const unsigned cc = h ? pick2<6>(c0, c1, c2) : pick2<4>(c0, c1, c2);
+                    const unsigned r0 = h ? pick2<6>(0, d1, 0) : pick2<4>(0, d1, 0);              // k=0  (0,+3)
+                    const unsigned r8 = h ? pick2<6>(0, u1, 0) : pick2<4>(0, u1, 0);              // k=8  (0,-3)
+                    const unsigned r4 = h ? pick2<9>(c0, c1, c2) : pick2<7>(c0, c1, c2);          // k=4  (+3,0)
+                    const unsigned r12 = h ? pick2<3>(c0, c1, c2) : pick2<1>(c0, c1, c2);         // k=12 (-3,0)
+                    const unsigned r2 = h ? pick2<8>(b0, b1, b2) : pick2<6>(b0, b1, b2);          // k=2  (+2,+2)
+                    const unsigned r10 = h ? pick2<4>(a0, a1, a2) : pick2<2>(a0, a1, a2);         // k=10 (-2,-2)
+                    const unsigned r6 = h ? pick2<8>(a0, a1, a2) : pick2<6>(a0, a1, a2);          // k=6  (+2,-2)
+                    const unsigned r14 = h ? pick2<4>(b0, b1, b2) : pick2<2>(b0, b1, b2);         // k=14 (-2,+2)
+                    const unsigned mlo = pk_max3(pk_min2(r0, r8), pk_min2(r4, r12), pk_max2(pk_min2(r2, r10), pk_min2(r6, r14)));
+                    const unsigned mhi = pk_min3(pk_max2(r0, r8), pk_max2(r4, r12), pk_min2(pk_max2(r2, r10), pk_max2(r6, r14)));
+                    u[h] = pk_max_i16(pk_sub_i16(cc, mlo), pk_sub_i16(mhi, cc));                  // U per 16-bit half (signed)
+                }
+                // a pair is queued if one of its pixels has U > lowTh: adding 0x7fff - lowTh to a signed half in
+                // [-255, 255] sets bit 15 exactly then.  Pixels of a neighbouring strip inside an edge quad may queue
+                // a pair needlessly; phase B zeroes their scores, so zone membership is not tested here.
+                pa = (pk_add_u16(u[0], thK) & 0x80008000u) != 0;
+                pb = (pk_add_u16(u[1], thK) & 0x80008000u) != 0;
             }
-            // a pair is queued if one of its pixels has U > lowTh: adding 0x7fff - lowTh to a signed half in
-            // [-255, 255] sets bit 15 exactly then.  Pixels of a neighbouring cell inside an edge quad may queue
-            // a pair needlessly; phase B zeroes their scores, so zone membership is not tested here.
-            pa = (pk_add_u16(u[0], thK) & 0x80008000u) != 0;
-            pb = (pk_add_u16(u[1], thK) & 0x80008000u) != 0;
+            const unsigned long long ba = __ballot(pa), bb = __ballot(pb);
+            const uint16_t ent = (uint16_t)((row << 8) | q);          // queue entries carry (row, quad) directly
+            if (pa) pairQ[(headA + cntA + mbcnt64(ba)) & (FT_QRING - 1)] = ent;
+            if (pb) pairQ[FT_QRING + ((headB + cntB + mbcnt64(bb)) & (FT_QRING - 1))] = ent;
+            cntA += __popcll(ba);
+            cntB += __popcll(bb);
+            qi += stepQ;
+            ry += stepR;
+            if (qi >= nq) { qi -= nq; ry++; }
         }
-        const unsigned long long ba = __ballot(pa), bb = __ballot(pb);
-        const unsigned long long lt = (1ull << lane) - 1;
-        const uint16_t ent = (uint16_t)((row << 8) | q);          // queue entries carry (row, quad) directly
-        if (pa) pairQ[nA + __popcll(ba & lt)] = ent;
-        if (pb) pairQ[maxItems + nB + __popcll(bb & lt)] = ent;
-        nA += __popcll(ba);
-        nB += __popcll(bb);
-        qi += stepQ;
-        ry += stepR;
-        if (qi >= nq) { qi -= nq; ry++; }
+        // phase B: exact V for queued pairs, a full wave at a time (the last pass flushes the remainders).  LDS
+        // operations of one wave execute in order; the barrier only keeps the compiler from reordering them.
+        __syncthreads();
+        while (cntA >= WAVE || (!more && cntA > 0)) {
+            const int n = min(cntA, WAVE);
+            fast_bstep<0, DENSE>(tileDw, pairQ, headA, n, lane, FT_PDW, zLo, zHi, lowTh, K);
+            headA = (headA + n) & (FT_QRING - 1);
+            cntA -= n;
+        }
+        while (cntB >= WAVE || (!more && cntB > 0)) {
+            const int n = min(cntB, WAVE);
+            fast_bstep<1, DENSE>(tileDw, pairQ + FT_QRING, headB, n, lane, FT_PDW, zLo, zHi, lowTh, K);
+            headB = (headB + n) & (FT_QRING - 1);
+            cntB -= n;
+        }
+        if (!more) break;
     }
     __syncthreads();
+}
 
-    // ---- phase B: exact V for the queued pairs (dense lanes again); remember pixels above the lower threshold
-    unsigned long long cmask = 0;                                  // bit 2*step+j, steps over queue A then queue B
-    int step = 0;
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-        const int nQ = h ? nB : nA;
-        const uint16_t* Q = pairQ + (h ? maxItems : 0);
-        for (int base = 0; base < nQ; base += WAVE, step++) {
-            const int e = base + lane;
-            if (e < nQ) {
-                const int ent = Q[e];
-                const int row = ent >> 8, q = ent & 0xff;
-                unsigned W[7][3];
-#pragma unroll
-                for (int r = 0; r < 7; r++) {
-                    const uint32_t* p = tileDw + (row - 3 + r) * FT_PDW + q - 1;
-                    W[r][0] = p[0]; W[r][1] = p[1]; W[r][2] = p[2];
-                }
-                const unsigned s2 = h ? fast_pair<6>(W) : fast_pair<4>(W);      // two scores, one per 16-bit half
-                const int cx = 4 * q + 2 * h;
-                int sLo = (int)(s2 & 0xff), sHi = (int)((s2 >> 16) & 0xff);
-                if (!(cx >= zLo && cx < zHi)) sLo = 0;             // pixel of the neighbouring cell
-                if (!(cx + 1 >= zLo && cx + 1 < zHi)) sHi = 0;
-                reinterpret_cast<uint16_t*>(smapDw)[(row * FT_PITCH + cx) >> 1] = (uint16_t)(sLo | (sHi << 8));
-                unsigned fl = 0;
-                if (sLo > lowTh) fl |= 1;
-                if (sHi > lowTh) fl |= 2;
-                cmask |= (unsigned long long)fl << (2 * step);
-            }
-        }
+// key of the candidate at tile (row, col) in cell c of the strip; S1 = score + 1
+#define FAST_KEY(row, col, c, S1)                                                                                         \
+    (((unsigned long long)(xtab[(col) + S.cxBase] | ytab[(row) + cy0]) << ORB_KEY_PATH_SHIFT) |                           \
+     ((unsigned long long)S.ci << 27) | ((unsigned long long)(S.cj0 + (c)) << 20) | ((unsigned long long)(row) << 14) |   \
+     ((unsigned long long)((col) - S.xoff - (c) * wCell) << 8) | (unsigned long long)((S1) - 1))
+
+__global__ __launch_bounds__(WAVE) void k_fast_strips(const OrbGeom G, const uint8_t* __restrict__ pyr,
+                                                      size_t pyrSlab, const OrbStrip* __restrict__ strips,
+                                                      const uint32_t* __restrict__ pathTab,
+                                                      unsigned long long* __restrict__ cand, size_t candSlab,
+                                                      int* __restrict__ candCount, int* __restrict__ errFlags,
+                                                      int* __restrict__ ovfCount, int* __restrict__ ovfList, int iniTh, int minTh, int pdw,
+                                                      int rowsMax, int candCap, int nStrips, int nFrames, unsigned invPerFrame)
+{
+    // dynamic LDS: [pad | tile | pad | pair rings | candidate positions | candidate scores]
+    extern __shared__ uint32_t fsm[];
+    const int tileDwords = rowsMax * pdw;
+    uint32_t* tileDw = fsm + FT_PAD;
+    uint16_t* pairQ = reinterpret_cast<uint16_t*>(tileDw + tileDwords + FT_PAD);   // [2][FT_QRING]
+    const int FT_PDW = pdw, FT_PITCH = 4 * pdw;
+    const int lane = threadIdx.x;
+    int f, si;
+    if (invPerFrame) {                                             // 1-D XCD-aware grid: a frame's strips share one L2
+        if (!orb_xcd_decode(blockIdx.x, (unsigned)nStrips, invPerFrame, nFrames, f, si)) return;
+    } else {
+        f = blockIdx.y;
+        si = blockIdx.x;
     }
-    const int stepsA = (nA + WAVE - 1) / WAVE;                     // steps [0, stepsA) belong to queue A
-    __syncthreads();                                               // tile is dead from here on: it becomes the queue
+    const OrbStrip S = strips[si];
+    const OrbLevelGeom& L = G.L[S.level];
+    fast_stage(S, pyr + (size_t)f * pyrSlab + L.pyrOff, L.pitch, tileDw, FT_PDW, lane);
+    __syncthreads();
 
-    // ---- queue of candidate pixels, entry = row << 8 | col (tile coordinates); order is irrelevant
-    uint16_t* queue = reinterpret_cast<uint16_t*>(tileDw);
-    const uint8_t* smap = reinterpret_cast<const uint8_t*>(smapDw);
-    const int mine = __popcll(cmask);
-    const int incl = orb_wave_scan_incl(mine);
-    const int nCand = __builtin_amdgcn_readlane(incl, WAVE - 1);
+    FastSink K;
+    K.smapZ = nullptr; K.spitch = 0;
+    K.candPos = pairQ + 2 * FT_QRING;
+    K.candScore = reinterpret_cast<uint8_t*>(K.candPos + candCap);
+    K.candCap = candCap;
+    K.nCand = 0;
+    const int lowTh = min(iniTh, minTh);
+    fast_detect<false>(S, tileDw, FT_PDW, pairQ, nullptr, 0, lowTh, lane, K);
+    const int nCand = K.nCand;
     if (nCand == 0) return;
-    if (nCand > 2 * tileDwords) {                                  // cannot happen: the tile region holds 2 B per zone pixel
-        if (lane == 0) atomicOr(&errFlags[f], 16);
+    if (nCand > candCap) {                                         // redone by k_fast_strips_dense
+        if (lane == 0) ovfList[atomicAdd(ovfCount, 1)] = (f << 16) | si;
         return;
     }
+
+    // ---- the tile is dead: it becomes the score map (0 everywhere but at the candidates)
     {
-        int w = incl - mine;
-        unsigned long long mm = cmask;
-        while (mm) {
-            const int bit = __ffsll((long long)mm) - 1;
-            mm &= mm - 1;
-            const int st = bit >> 1;
-            const int h = st >= stepsA;
-            const int e = (h ? st - stepsA : st) * WAVE + lane;
-            const int ent = pairQ[(h ? maxItems : 0) + e];
-            queue[w++] = (uint16_t)((ent & 0xff00) | (4 * (ent & 0xff) + 2 * h + (bit & 1)));
-        }
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        uint4* t4 = reinterpret_cast<uint4*>(fsm);                  // pad + tile + pad: 16-byte aligned, a multiple of 16 bytes
+        const int n4 = (FT_PAD + S.h * FT_PDW + FT_PAD + 3) >> 2;
+        for (int i = lane; i < n4; i += WAVE) t4[i] = z;
+    }
+    __syncthreads();
+    uint8_t* smap = reinterpret_cast<uint8_t*>(tileDw);
+    for (int e = lane; e < nCand; e += WAVE) {
+        const unsigned ent = K.candPos[e];
+        smap[(ent >> 8) * FT_PITCH + (ent & 0xff)] = K.candScore[e];
     }
     __syncthreads();
 
-    // ---- cell-local 3x3 strict NMS on score = (V > th) ? V-1 : 0.  The reference re-runs cv::FAST with
-    // minThFAST when the iniThFAST call returns NO KEYPOINT (:857-861) -- i.e. after NMS, so a plateau of
-    // equal scores that suppresses itself also triggers the fallback.
-    unsigned long long keep = 0;
-    int total = 0;
-    for (int attempt = 0; attempt < 2 && total == 0; attempt++) {
-        const int th = attempt ? minTh : iniTh;
-        keep = 0;
+    const int zLo = S.zLo, zHi = S.zHi, wCell = S.wCell;
+    // ---- cell-local 3x3 strict NMS over the candidate queue (any order), both thresholds at once; which one counts
+    // is decided per cell afterwards: minTh only where iniTh leaves NO KEYPOINT after NMS (:857-861, so a plateau of
+    // equal scores that suppresses itself also triggers the fallback).
+    unsigned long long keep0 = 0, keep1 = 0;                       // one bit per queue step (<= 64 steps)
+    unsigned has = 0;
+    {
         int it = 0;
         for (int base = 0; base < nCand; base += WAVE, it++) {
             const int e = base + lane;
-            bool k = false;
             if (e < nCand) {
-                const unsigned ent = queue[e];
-                const uint8_t* s = smap + (ent >> 8) * FT_PITCH + (ent & 0xff);
-                const int S = s[0];
-                if (S > th) {
-                    // sc = S-1 must exceed max(0, scores of the neighbours above th); a neighbour at or below th
-                    // is below S anyway, so this is S > max(1, raw neighbour values)
-                    const int m0 = max(max((int)s[-FT_PITCH - 1], (int)s[-FT_PITCH]), (int)s[-FT_PITCH + 1]);
-                    const int m1 = max(max((int)s[-1], (int)s[1]), 1);
-                    const int m2 = max(max((int)s[FT_PITCH - 1], (int)s[FT_PITCH]), (int)s[FT_PITCH + 1]);
-                    k = S > max(max(m0, m1), m2);
-                }
+                const unsigned ent = K.candPos[e];
+                const int row = ent >> 8, col = ent & 0xff;
+                const int c = (int)(((unsigned)(col - zLo) * S.invW) >> 16);
+                const int cs = zLo + c * wCell, ce = min(cs + wCell, zHi);
+                const int Sv = K.candScore[e];
+                const bool ok = fast_nms_ok(smap + row * FT_PITCH + col, FT_PITCH, col == cs, col == ce - 1, Sv);
+                const unsigned k0 = ok && Sv > iniTh, k1 = ok && Sv > minTh;
+                keep0 |= (unsigned long long)k0 << it;
+                keep1 |= (unsigned long long)k1 << it;
+                has |= k0 << c;
             }
-            if (k) keep |= 1ull << it;
-            total += __popcll(__ballot(k));
         }
     }
+    const unsigned fb = ~orb_wave_or(has);                         // cells without a keypoint at iniTh
+    unsigned long long keepF = 0;
+    int mine = 0;
+    for (unsigned long long mm = keep0 | keep1; mm;) {             // the few entries of this lane that passed the NMS
+        const int it = __ffsll((long long)mm) - 1;
+        mm &= mm - 1;
+        const int col = K.candPos[it * WAVE + lane] & 0xff;
+        const unsigned c = ((unsigned)(col - zLo) * S.invW) >> 16;
+        const unsigned long long k = ((((fb >> c) & 1u) ? keep1 : keep0) >> it) & 1ull;
+        keepF |= k << it;
+        mine += (int)k;
+    }
+    const int incl = orb_wave_scan_incl(mine);
+    const int total = __builtin_amdgcn_readlane(incl, WAVE - 1);
     if (total == 0) return;
-
     int base0 = 0;
-    if (lane == 0) base0 = atomicAdd(&candCount[f * ORB_MAX_LEVELS + cell.level], total);
+    if (lane == 0) base0 = atomicAdd(&candCount[f * ORB_MAX_LEVELS + S.level], total);
     base0 = __builtin_amdgcn_readfirstlane(base0);
     if (base0 + total > L.candCap) {                               // cannot happen: candCap is the NMS bound
         if (lane == 0) atomicOr(&errFlags[f], 1);
         return;
     }
-    unsigned long long* out = cand + (size_t)f * candSlab + L.candBase + base0;
     const uint32_t* xtab = pathTab + L.pathXOff;
     const uint32_t* ytab = pathTab + L.pathYOff;
-    int run = 0, it = 0;
-    for (int base = 0; base < nCand; base += WAVE, it++) {
-        const bool k = (keep >> it) & 1;
-        const unsigned long long b = __ballot(k);
-        if (k) {
-            const unsigned ent = queue[base + lane];
-            const int row = ent >> 8, col = ent & 0xff;
-            const int xin = col - xoff, yin = row;                 // cv::FAST keypoint coords inside the ROI
-            const int S = smap[row * FT_PITCH + col];
-            const int cx = xin + cell.cj * L.wCell, cy = yin + cell.ci * L.hCell;   // :868-869
-            unsigned long long key = (unsigned long long)(xtab[cx] | ytab[cy]) << ORB_KEY_PATH_SHIFT;
-            key |= ((unsigned long long)cell.ci << 27) | ((unsigned long long)cell.cj << 20) |
-                   ((unsigned long long)yin << 14) | ((unsigned long long)xin << 8) | (unsigned long long)(S - 1);
-            out[run + __popcll(b & ((1ull << lane) - 1))] = key;
-        }
-        run += __popcll(b);
+    unsigned long long* out = cand + (size_t)f * candSlab + L.candBase;
+    const int cy0 = S.ci * L.hCell;
+    int w = base0 + incl - mine;
+    while (keepF) {
+        const int it = __ffsll((long long)keepF) - 1;
+        keepF &= keepF - 1;
+        const unsigned ent = K.candPos[it * WAVE + lane];
+        const int row = ent >> 8, col = ent & 0xff;
+        const int c = (int)(((unsigned)(col - zLo) * S.invW) >> 16);
+        const int Sv = K.candScore[it * WAVE + lane];
+        out[w++] = FAST_KEY(row, col, c, Sv);
     }
 }
 
-void orb_launch_fast_cells(hipStream_t st, const OrbGeom& G, const uint8_t* pyr, size_t pyrSlab,
-                           const OrbCell* cells, int nCells, const uint32_t* pathTab, unsigned long long* cand,
-                           size_t candSlab, int* candCount, int* errFlags, int iniTh, int minTh, int maxItems,
-                           int pdw, int rowsMax, int maxZonePx, int nFrames)
+// The strips of ovfList ((frame << 16 | strip) entries) again, with a full score map next to the tile and
+// a dense scan of it, one cell at a time: any number of candidates.  One wave per workgroup, grid-stride over the list.
+__global__ __launch_bounds__(WAVE) void k_fast_strips_dense(const OrbGeom G, const uint8_t* __restrict__ pyr,
+                                                            size_t pyrSlab, const OrbStrip* __restrict__ strips,
+                                                            const uint32_t* __restrict__ pathTab,
+                                                            unsigned long long* __restrict__ cand, size_t candSlab,
+                                                            int* __restrict__ candCount, int* __restrict__ errFlags,
+                                                            const int* __restrict__ ovfCount, const int* __restrict__ ovfList, int iniTh,
+                                                            int minTh, int pdw, int rowsMax, int sdw)
 {
-    if (nCells == 0) return;
-    const int tileDwords = std::max(rowsMax * pdw, (maxZonePx + 1) / 2);
-    const size_t lds = (size_t)4 * (FT_PAD + tileDwords + FT_PAD + rowsMax * pdw) + (size_t)4 * maxItems;
+    // dynamic LDS: [pad | tile | pad | score map | pair rings].  The score map only covers the zone and its 1-px
+    // halo: tile rows [2, 4 + zh) and the quads [hLo, hLo + nh), at its own pitch of sdw dwords.
+    extern __shared__ uint32_t fsm[];
+    const int tileDwords = rowsMax * pdw;
+    uint32_t* tileDw = fsm + FT_PAD;
+    uint32_t* smapDw = tileDw + tileDwords + FT_PAD;
+    uint16_t* pairQ = reinterpret_cast<uint16_t*>(smapDw + (rowsMax - 4) * sdw);   // [2][FT_QRING]
+    const int FT_PDW = pdw, SPITCH = 4 * sdw;
+    const int lane = threadIdx.x;
+    const int nList = *ovfCount;
+    const int lowTh = min(iniTh, minTh);
+    for (int li = blockIdx.x; li < nList; li += gridDim.x) {
+        const int ent = ovfList[li];
+        const int f = ent >> 16, si = ent & 0xffff;
+        const OrbStrip S = strips[si];
+        const OrbLevelGeom& L = G.L[S.level];
+        __syncthreads();                                           // previous strip's LDS reads are done
+        fast_stage(S, pyr + (size_t)f * pyrSlab + L.pyrOff, L.pitch, tileDw, FT_PDW, lane);
+        const int zh = S.zh, zLo = S.zLo, zHi = S.zHi;
+        // Quads [qLo, qHi) cover the zone columns [zLo, zHi); the halo columns zLo-1 and zHi (and the rows above and
+        // below the zone) only ever read as score 0 by the NMS -- cv::FAST scores nothing outside the ROI interior.
+        const int qLo = S.qLo, nq = S.nq, qHi = qLo + nq;
+        const int hLo = S.hLo, nh = S.nh, hHi = hLo + nh;          // halo-inclusive quad range
+        uint8_t* smapZ = reinterpret_cast<uint8_t*>(smapDw) - 2 * SPITCH - 4 * hLo;    // score of tile (row, byte col)
+        uint32_t* smapQ = smapDw - 2 * sdw - hLo;                  // the same, addressed by (row, quad)
+        for (int i = lane; i < 2 * nh; i += WAVE) {
+            const int row = (i < nh) ? 2 : 3 + zh, q = hLo + (i < nh ? i : i - nh);
+            smapQ[row * sdw + q] = 0;
+        }
+        for (int i = lane; i < 2 * zh; i += WAVE) {                // left / right halo quads of the zone rows
+            const int row = 3 + (i >> 1), q = (i & 1) ? hHi - 1 : hLo;
+            if (q < qLo || q >= qHi) smapQ[row * sdw + q] = 0;
+        }
+        __syncthreads();
+        FastSink K;
+        K.smapZ = smapZ; K.spitch = SPITCH;
+        K.candPos = nullptr; K.candScore = nullptr; K.candCap = 0; K.nCand = 0;
+        fast_detect<true>(S, tileDw, FT_PDW, pairQ, smapQ, sdw, lowTh, lane, K);
+
+        const uint8_t* smap = smapZ;
+        const int nc = S.nc, wCell = S.wCell;
+        const uint32_t* xtab = pathTab + L.pathXOff;
+        const uint32_t* ytab = pathTab + L.pathYOff;
+        unsigned long long* out = cand + (size_t)f * candSlab + L.candBase;
+        int* cnt = &candCount[f * ORB_MAX_LEVELS + S.level];
+        const int cy0 = S.ci * L.hCell;
+        // The reference re-runs cv::FAST with minThFAST when the iniThFAST call returns NO KEYPOINT (:857-861), i.e. after NMS
+        for (int c = 0; c < nc; c++) {
+            const int cs = zLo + c * wCell, ce = min(cs + wCell, zHi), wz = ce - cs, npx = wz * zh;
+            int t0 = 0, t1 = 0;
+            for (int base = 0; base < npx; base += WAVE) {
+                const int i = base + lane;
+                bool k0 = false, k1 = false;
+                if (i < npx) {
+                    const int r = i / wz, col = cs + i - r * wz;
+                    const uint8_t* s = smap + (3 + r) * SPITCH + col;
+                    const int Sv = s[0];
+                    const bool ok = fast_nms_ok(s, SPITCH, col == cs, col == ce - 1, Sv);
+                    k0 = ok && Sv > iniTh;
+                    k1 = ok && Sv > minTh;
+                }
+                t0 += __popcll(__ballot(k0));
+                t1 += __popcll(__ballot(k1));
+            }
+            const int th = t0 ? iniTh : minTh, tot = t0 ? t0 : t1;
+            if (tot == 0) continue;
+            int base0 = 0;
+            if (lane == 0) base0 = atomicAdd(cnt, tot);
+            base0 = __builtin_amdgcn_readfirstlane(base0);
+            if (base0 + tot > L.candCap) {                         // cannot happen: candCap is the NMS bound
+                if (lane == 0) atomicOr(&errFlags[f], 1);
+                break;
+            }
+            int run = base0;
+            for (int base = 0; base < npx; base += WAVE) {
+                const int i = base + lane;
+                bool k = false;
+                int row = 0, col = 0, Sv = 0;
+                if (i < npx) {
+                    const int r = i / wz;
+                    row = 3 + r;
+                    col = cs + i - r * wz;
+                    const uint8_t* s = smap + row * SPITCH + col;
+                    Sv = s[0];
+                    k = fast_nms_ok(s, SPITCH, col == cs, col == ce - 1, Sv) && Sv > th;
+                }
+                const unsigned long long b = __ballot(k);
+                if (k) out[run + mbcnt64(b)] = FAST_KEY(row, col, c, Sv);
+                run += __popcll(b);
+            }
+        }
+    }
+}
+#undef FAST_KEY
+
+size_t orb_fast_lds_bytes(int pdw, int rowsMax, int candCap)
+{
+    return (size_t)4 * (FT_PAD + rowsMax * pdw + FT_PAD) + (size_t)2 * 2 * FT_QRING + (size_t)3 * candCap;
+}
+size_t orb_fast_dense_lds_bytes(int pdw, int rowsMax, int sdw)
+{
+    return (size_t)4 * (FT_PAD + rowsMax * pdw + FT_PAD + (rowsMax - 4) * sdw) + (size_t)2 * 2 * FT_QRING;
+}
+
+// ovfList: nStrips * nFrames ints; *ovfCount zeroed by the caller before the launch
+void orb_launch_fast_strips(hipStream_t st, const OrbGeom& G, const uint8_t* pyr, size_t pyrSlab,
+                            const OrbStrip* strips, int nStrips, const uint32_t* pathTab, unsigned long long* cand,
+                            size_t candSlab, int* candCount, int* errFlags, int* ovfCount, int* ovfList, int iniTh, int minTh,
+                            int pdw, int rowsMax, int sdw, int candCap, int nFrames)
+{
+    if (nStrips == 0) return;
     unsigned inv = 0;
-    const unsigned wgs = orb_xcd_grid((unsigned)nCells, nFrames, &inv);
-    hipLaunchKernelGGL(k_fast_cells, wgs ? dim3(wgs) : dim3(nCells, nFrames), dim3(WAVE), lds, st, G, pyr, pyrSlab, cells,
-                       pathTab, cand, candSlab, candCount, errFlags, iniTh, minTh, maxItems, pdw, rowsMax, tileDwords, nCells,
-                       nFrames, inv);
+    const unsigned wgs = orb_xcd_grid((unsigned)nStrips, nFrames, &inv);
+    hipLaunchKernelGGL(k_fast_strips, wgs ? dim3(wgs) : dim3(nStrips, nFrames), dim3(WAVE),
+                       orb_fast_lds_bytes(pdw, rowsMax, candCap), st, G, pyr, pyrSlab, strips, pathTab, cand, candSlab,
+                       candCount, errFlags, ovfCount, ovfList, iniTh, minTh, pdw, rowsMax, candCap, nStrips, nFrames, inv);
+    const long long all = (long long)nStrips * nFrames;
+    hipLaunchKernelGGL(k_fast_strips_dense, dim3((unsigned)std::min<long long>(all, 2048)), dim3(WAVE),
+                       orb_fast_dense_lds_bytes(pdw, rowsMax, sdw), st, G, pyr, pyrSlab, strips, pathTab, cand, candSlab,
+                       candCount, errFlags, ovfCount, ovfList, iniTh, minTh, pdw, rowsMax, sdw);
 }

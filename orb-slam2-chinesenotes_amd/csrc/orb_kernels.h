@@ -9,10 +9,12 @@ bool orb_launch_resize_pair(hipStream_t st, uint8_t* pyr, size_t pyrSlab, const 
                             int nFrames);
 void orb_launch_resize(hipStream_t st, uint8_t* pyr, size_t pyrSlab, const OrbLevelGeom& src,
                        const OrbLevelGeom& dst, const int2* xtab, const int2* ytab, const uint4* xq, int nFrames);
-void orb_launch_fast_cells(hipStream_t st, const OrbGeom& G, const uint8_t* pyr, size_t pyrSlab,
-                           const OrbCell* cells, int nCells, const uint32_t* pathTab, unsigned long long* cand,
-                           size_t candSlab, int* candCount, int* errFlags, int iniTh, int minTh, int maxItems,
-                           int pdw, int rowsMax, int maxZonePx, int nFrames);
+size_t orb_fast_lds_bytes(int pdw, int rowsMax, int candCap);
+size_t orb_fast_dense_lds_bytes(int pdw, int rowsMax, int sdw);
+void orb_launch_fast_strips(hipStream_t st, const OrbGeom& G, const uint8_t* pyr, size_t pyrSlab,
+                            const OrbStrip* strips, int nStrips, const uint32_t* pathTab, unsigned long long* cand,
+                            size_t candSlab, int* candCount, int* errFlags, int* ovfCount, int* ovfList, int iniTh, int minTh,
+                            int pdw, int rowsMax, int sdw, int candCap, int nFrames);
 size_t orb_quadtree_lds_bytes(int sortCap, int nodeCap);
 void orb_launch_quadtree(hipStream_t st, const OrbGeom& G, unsigned long long* cand, size_t candSlab,
                          const int* candCount, uint32_t* kpl, int* kpCount, int* errFlags, int sortCap,

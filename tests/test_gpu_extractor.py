@@ -196,6 +196,34 @@ def test_unsupported_geometry_is_reported_not_crashed():
     ex.close()
 
 
+def test_good_size_after_unsupported_size_is_rebuilt():
+    """a failed geometry build must not leave a half-built geometry behind a matching (rows, cols):
+    good size, unsupported size, the SAME good size again -- bit-exact against the oracle."""
+    ex = capi.Extractor()
+    ref = oracle.Extractor()
+    img = synth.synth_frame(4)
+    k0, d0 = ex.extract(img)
+    with pytest.raises(capi.OrbError):
+        ex.extract(np.zeros((100, 4200), np.uint8))
+    k1, d1 = ex.extract(img)
+    rk, rd = ref.extract(img)
+    assert k1.tobytes() == rk.tobytes() and np.array_equal(d1, rd)
+    assert k0.tobytes() == k1.tobytes() and np.array_equal(d0, d1)
+    ex.close()
+
+
+@pytest.mark.parametrize("strip,cap", [(1, 640), (2, 64), (5, 200), (8, 4096)])
+def test_fast_strip_sizes_and_queue_overflow(monkeypatch, strip, cap):
+    """k_fast_strips tuning knobs (cells per strip, candidate-queue capacity) never change results: small queues send
+    strips to the dense kernel (k_fast_strips_dense), large strips exercise the cell-local NMS at cell seams."""
+    monkeypatch.setenv("ORB_FAST_STRIP", str(strip))
+    monkeypatch.setenv("ORB_FAST_CANDCAP", str(cap))
+    _cmp(synth.synth_frame(11))
+    _cmp(synth.synth_frame(12, 752, 480))
+    rng = np.random.default_rng(7)
+    _cmp((128 + rng.integers(-9, 10, (240, 320))).astype(np.uint8), nfeatures=500)
+
+
 def test_randomized_geometry_and_parameter_sweep():
     """40 seeded random (size, nfeatures, levels, scale factor, thresholds) combinations, each bit-exact against the
     oracle stage by stage: exercises odd widths/heights, degenerate upper levels, every resize path, cell grids with
