@@ -1,21 +1,31 @@
 #!/usr/bin/env python3
 """bench.py -- frames/s of the MI355X-native ORB front-end (extract + match), one JSON line.
 
-A "step" is one pass of the hot path over one batch of synthetic frames already resident in HBM:
-    ORBextractor::operator() on B frames  (pyramid -> FAST cells -> quadtree -> orientation+rBRIEF)
-  + vocabulary-node assignment (synthetic stand-in for DBoW2 transform)
-  + ORBmatcher::SearchByBoW for B (keyframe, frame) pairs (frame i as keyframe vs frame i+1).
-Workload at N=1 = BASELINE.json configs[1]/[3]: 640x480, 8 levels, 1000 features, batched
-(configs[3] is the same frame shape sharded over GPUs; per-GPU batch is fixed -> weak scaling).
+Default workload (BASELINE.json configs[1]/[3], `--config c4`): a "step" is one pass of the hot path over one batch of
+synthetic frames already resident in HBM:
+    ORBextractor::operator() on B frames  (pyramid -> FAST strips -> quadtree -> orientation+rBRIEF)
+  + DBoW2-shaped vocabulary descent (seeded k=10, L=6 tree, transform(..., levelsup=4): 60 Hamming per feature, the
+    amount of work Frame::ComputeBoW does, reference src/Frame.cc:425-433)
+  + ORBmatcher::SearchByBoW for B (keyframe, frame) pairs (frame i as keyframe vs frame i+1 of a moving-camera
+    sequence, so consecutive frames share most corners), ratio 0.7 as src/Tracking.cc:815.
+`value` is measured with TWO lanes (extractor, matcher, output buffers each) that consecutive steps alternate
+between, so the latency-bound stages of one step overlap the issue-bound stages of the next; the per-kernel durations
+behind `roofline` come from a separate single-lane (non-overlapped) pass of the same run, outside the timed region.
+Other configurations: `--config c3` (KITTI-sized stereo pairs: extract both + stereo search) and `--config c5`
+(752x480 stream against a 1000-keyframe descriptor DB) print the same contract line for their workloads.
 
-Multi-GPU: one process per GPU (torchrun), frames sharded by rank, NO data-path collective; the
-only collective is the RCCL broadcast of the BRIEF pattern from rank 0 at start-up.
+Multi-GPU: one process per GPU (torchrun, or `--gpus N` alone, which starts the ranks itself), frames sharded by rank,
+NO data-path collective; the only collective is the RCCL broadcast of the BRIEF pattern from rank 0 at start-up.
+`--scaling weak` (default) gives every rank B frames; `--scaling strong` splits ONE batch of B frames over the ranks
+(BASELINE.json configs[3] as written).
 
 The CPU oracle is used ONLY in the cpu_baseline leg (rank 0, N=1), on a bounded sample.
 """
 import argparse
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
@@ -23,11 +33,38 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "orb-slam2-chinesenotes_amd", "pyhost"))
 
 import numpy as np
+
+
+# ------------------------------------------------------------------ CPU-only worker (all-cores leg of cpu_baseline)
+def cpu_worker(first, count, width, height, nfeatures):
+    """Runs in a child process WITHOUT torch / GPU: oracle extraction of `count` sequence frames, wall time printed."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle
+    from orbhip import synth
+    frames = synth.synth_sequence(first, count, width, height)
+    ref = oracle.Extractor(nfeatures, 1.2, 8, 20, 7)
+    ref.extract(frames[0])
+    t0 = time.perf_counter()
+    for f in frames:
+        ref.extract(f)
+    print(json.dumps({"frames": count, "seconds": time.perf_counter() - t0}))
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
+    cpu_worker(*[int(v) for v in sys.argv[2:7]])
+    sys.exit(0)
+
 import torch
 
 from orbhip import capi, shard, synth
 
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
+N_SIMD, MAX_CLOCK_GHZ = 1024, 2.4
+VALU_ISSUE_PEAK = N_SIMD * MAX_CLOCK_GHZ / 2.0      # G wave-instructions/s: a wave64 VALU instruction issues over 2 cycles
+MBF = 386.1448
+MB = MBF / 718.856
+METRIC = "frames/sec ORB extract+match, 640x480 8-level 1000-feat; HBM GB/s vs peak"
+STAGES = ["pyramid(k_copy_level0 + resize kernels)", "k_fast_strips", "k_quadtree", "k_orient_desc"]
 
 
 def algorithmic_bytes_per_frame(cols, rows, pyr_px, n_kp):
@@ -35,31 +72,551 @@ def algorithmic_bytes_per_frame(cols, rows, pyr_px, n_kp):
     return cols * rows + pyr_px + n_kp * (28 + 32)
 
 
-def main():
+def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="c4", choices=["c4", "c3", "c5"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--input-sets", type=int, default=2,
                     help="distinct input batches that consecutive steps alternate between: one 157 MB batch re-read every "
                          "step would sit in the 256 MB Infinity Cache and flatter the pyramid's first kernel")
-    ap.add_argument("--pipeline", type=int, default=1,
+    ap.add_argument("--pipeline", type=int, default=2,
                     help="number of independent (extractor, matcher, output buffers) lanes that consecutive steps alternate "
                          "between; lanes run on their own streams, so step k+1 overlaps step k")
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames-per-gpu", type=int, default=512)
+    ap.add_argument("--frames-per-gpu", type=int, default=512, help="batch size B (weak: per GPU; strong: in total)")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--nfeatures", type=int, default=1000)
     ap.add_argument("--no-match", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-frames", type=int, default=200, help="timed frames of the single-thread cpu_baseline (+10 warm-up)")
+    ap.add_argument("--no-cpu-all-cores", action="store_true")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) or gloo (CPU rehearsal of the N>1 path)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses GPU 0")
-    args = ap.parse_args()
+    ap.add_argument("--master-port", type=int, default=29511)
+    return ap.parse_args()
 
+
+def load_profile(name):
+    p = os.path.join(ROOT, "profiles", name)
+    try:
+        return json.load(open(p))
+    except Exception:
+        return None
+
+
+def roofline_blocks(stage_ms, launch_frames, bytes_frame, extract_total_ms):
+    """The contract `roofline` block (HBM, as SURVEY 8(d) defines `achieved`) for the dominant extractor kernel, plus
+    `roofline_valu`: what actually binds FAST and the descriptor kernel is vector-instruction issue."""
+    dom = int(np.argmax(stage_ms[:4]))
+    kern_s = float(stage_ms[dom]) * 1e-3
+    achieved = bytes_frame * launch_frames / kern_s / 1e9
+    rf = {"bound": "hbm", "kernel": STAGES[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "algorithmic_bytes_per_frame": int(bytes_frame),
+          "frames_per_launch": launch_frames, "kernel_ms_per_launch": round(float(stage_ms[dom]), 4),
+          "pipeline_achieved_GBs": round(bytes_frame * launch_frames / (extract_total_ms * 1e-3) / 1e9, 2),
+          "binding": "valu_issue (see roofline_valu): the kernel moves ~1 MB/frame from L2, HBM is not what limits it"}
+    key = STAGES[dom].split("(")[0]
+    tr = load_profile("pmc_traffic.json")
+    if tr and key in tr.get("bytes_per_launch", {}):
+        rf["traffic"] = int(tr["bytes_per_launch"][key] * launch_frames / tr["frames_per_launch"])
+        rf["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2 per " \
+                               "profiles/r02_fetch_calibration.json), scaled to this launch size"
+    rv = None
+    vj = load_profile("r02_valu.json")
+    if vj and key in vj.get("kernels", {}):
+        k = vj["kernels"][key]
+        insts = k["valu_insts"] * launch_frames / vj["frames_per_launch"]
+        ach = insts / kern_s / 1e9
+        rv = {"bound": "valu_issue", "kernel": key, "achieved": round(ach, 2), "peak": VALU_ISSUE_PEAK, "unit": "G wave-inst/s",
+              "frac": round(ach / VALU_ISSUE_PEAK, 4), "valu_insts_per_launch": int(insts),
+              "valu_busy_profiled": k.get("valu_busy"), "cycles_per_valu_inst_profiled": k.get("cycles_per_valu_inst"),
+              "active_lane_frac_profiled": k.get("active_lane_frac"),
+              "note": "peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction; this kernel's mix (v_perm_b32, "
+                      "v_pk_*3_f16) averages cycles_per_valu_inst_profiled cycles, so frac x that / 2 is the share of "
+                      "issue cycles used; instruction counts from profiles/r02_valu.json (rocprofv3 --pmc SQ_INSTS_VALU)"}
+    return rf, rv
+
+
+# ================================================================== config c4 (default)
+def run_c4(args, rank, local_rank, world, dev, comm_dev, dist):
+    W, H = args.width, args.height
+    if args.scaling == "strong":
+        total = args.frames_per_gpu
+        first, B = shard.frame_range(total, world, rank)
+    else:
+        first, B = shard.weak_range(args.frames_per_gpu, rank)
+    if B <= 0:
+        raise SystemExit("rank %d has no frames" % rank)
+    ex = capi.Extractor(args.nfeatures, 1.2, 8, 20, 7, device=local_rank)
+    mt = capi.Matcher(0.7, True, device=local_rank)           # Tracking.cc:815 parameters
+    cap = ex.max_keypoints
+
+    # ---- the one collective: rank 0 broadcasts the BRIEF pattern (RCCL over xGMI)
+    pat = torch.zeros(1024, dtype=torch.int8, device=comm_dev)
+    if rank == 0:
+        pat.copy_(torch.from_numpy(capi.builtin_pattern()))
+    shard.broadcast_pattern(dist, pat, 0)
+    pat = pat.to(dev)
+    torch.cuda.synchronize()
+    ex.set_pattern_device(pat.data_ptr())
+
+    # ---- vocabulary: seeded complete k=10, L=6 tree (ORBvoc is absent), on the device
+    tree = synth.synth_vocab_tree_balanced(10, 6)
+    voc = capi.Vocabulary(tree, device=local_rank)
+    n_nodes = voc.level_nodes(4)
+
+    # ---- synthetic inputs, resident in HBM before the timed region
+    n_sets = max(1, args.input_sets)
+    set_stride = (args.frames_per_gpu * world + 7) // 8 * 8      # whole scenes between the input sets
+    frames_sets = [synth.synth_sequence(first + k * set_stride, B, W, H) for k in range(n_sets)]
+    d_img_sets = [torch.from_numpy(fr).to(dev) for fr in frames_sets]
+    valid_np = np.stack([synth.synth_valid_flags(cap, first + i) for i in range(B)])
+    d_valid = torch.from_numpy(valid_np).to(dev)
+    kf_idx = torch.arange(B, dtype=torch.int32, device=dev)
+    f_idx = ((torch.arange(B, dtype=torch.int32, device=dev) + 1) % B).to(torch.int32)
+
+    def new_lane(lex, lmt):
+        ln = dict(ex=lex, mt=lmt, kps=torch.zeros(B * cap * 28, dtype=torch.uint8, device=dev),
+                  desc=torch.zeros(B * cap * 32, dtype=torch.uint8, device=dev), counts=torch.zeros(B, dtype=torch.int32, device=dev),
+                  nodeof=torch.zeros(B * cap, dtype=torch.int16, device=dev), match=torch.zeros(B * cap, dtype=torch.int32, device=dev),
+                  nm=torch.zeros(B, dtype=torch.int32, device=dev), set=0)
+        ln["store"] = dict(desc=ln["desc"].data_ptr(), kps=ln["kps"].data_ptr(), valid=d_valid.data_ptr(),
+                           counts=ln["counts"].data_ptr(), node_of=ln["nodeof"].data_ptr(), cap=cap, n_frames=B, n_nodes=n_nodes)
+        return ln
+
+    # lanes: consecutive steps alternate between lanes, each lane on its own streams, so the latency-bound stages of one
+    # step (pyramid, quadtree, matcher) overlap the issue-bound stages (FAST, descriptors) of the next.
+    lanes = [new_lane(ex, mt)]
+    for _ in range(1, max(1, args.pipeline)):
+        lex = capi.Extractor(args.nfeatures, 1.2, 8, 20, 7, device=local_rank)
+        lex.set_pattern_device(pat.data_ptr())
+        lanes.append(new_lane(lex, capi.Matcher(0.7, True, device=local_rank)))
+    torch.cuda.synchronize()
+    step_no = [0]
+
+    def step(only_lane=None):
+        ln = lanes[step_no[0] % len(lanes)] if only_lane is None else lanes[only_lane]
+        ln["set"] = step_no[0] % n_sets                # which input batch this lane's buffers will hold results of
+        d_imgs = d_img_sets[ln["set"]]
+        step_no[0] += 1
+        lx, lm = ln["ex"], ln["mt"]
+        lx.wait_for(lm.stream)                     # this lane's outputs of its previous step are still being matched
+        lx.extract_batch_device(d_imgs.data_ptr(), B, H, W, W, W * H, ln["kps"].data_ptr(), ln["desc"].data_ptr(), cap,
+                                ln["counts"].data_ptr())
+        if not args.no_match:
+            lm.wait_for(lx.stream)
+            voc.transform_device(lm, ln["desc"].data_ptr(), ln["counts"].data_ptr(), B, cap, 4, d_node_of=ln["nodeof"].data_ptr())
+            lm.match_bow_batch_device(ln["store"], kf_idx.data_ptr(), f_idx.data_ptr(), B, ln["match"].data_ptr(),
+                                      ln["nm"].data_ptr())
+
+    def full_sync():
+        for ln in lanes:
+            ln["ex"].sync()
+            ln["mt"].sync()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    full_sync()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    full_sync()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    elapsed = shard.max_over_ranks(dist, elapsed, comm_dev)
+    frames_done = shard.sum_over_ranks(dist, B * args.steps, comm_dev)
+
+    # ---- single-lane pass, outside the timed region: per-kernel durations that describe each kernel running alone
+    # (HIP events on the extractor's own stream)
+    n_prof = 6
+    step(0); full_sync()
+    ex.set_profiling(True)
+    t1 = time.perf_counter()
+    for _ in range(n_prof):
+        step(0)
+    full_sync()
+    single_ms = (time.perf_counter() - t1) / n_prof * 1e3
+    stage_ms = ex.stage_ms()
+    launch_frames = ex.profiled_frames()
+    ex.set_profiling(False)
+    ln0 = lanes[0]
+    counts = ln0["counts"].cpu().numpy()
+    nm = ln0["nm"].cpu().numpy()
+    mean_kp = float(counts.mean())
+    pyr_px = sum(int(ex.pyramid_level(0, l).size) for l in range(8))
+
+    if rank != 0:
+        return None
+    fps = frames_done / elapsed
+    bytes_frame = algorithmic_bytes_per_frame(W, H, pyr_px, mean_kp)
+    rf, rv = roofline_blocks(stage_ms, launch_frames, bytes_frame, float(stage_ms[4]))
+    out = {
+        "metric": METRIC, "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "batch of %d synthetic %dx%d frames %s, nFeatures=%d, 8 levels, scale 1.2, FAST 20/7; extract + "
+                               "vocabulary descent (k=10, L=6, levelsup 4) + SearchByBoW(frame i as keyframe, frame i+1), ratio 0.7"
+                               % (args.frames_per_gpu, W, H, "per GPU" if args.scaling == "weak" else "in total, split over the GPUs",
+                                  args.nfeatures),
+                   "frames_per_gpu": B, "input_sets": n_sets, "lanes": len(lanes), "match": not args.no_match,
+                   "mean_keypoints": round(mean_kp, 1), "mean_bow_matches": round(float(nm.mean()), 1),
+                   "vocabulary": "complete k=10 L=6 tree, %d nodes, %d level-(L-4) nodes" % (tree["node_desc"].shape[0], n_nodes),
+                   "frames_per_launch": launch_frames,
+                   "single_lane_ms_per_step": round(single_ms, 4),
+                   "single_lane_frames_per_s": round(B / single_ms * 1e3, 1),
+                   "stage_ms_per_launch_single_lane": {n: round(float(v), 4) for n, v in zip(STAGES + ["extract_total"], stage_ms)},
+                   "transform_plus_match_ms_single_lane": round(single_ms - float(stage_ms[4]), 4)},
+        "roofline": rf,
+    }
+    if rv:
+        out["roofline_valu"] = rv
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_c4(args, frames_sets[ln0["set"]], first, ln0, counts, cap, nm, tree, valid_np)
+    return out
+
+
+def pin_one_core():
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+        os.sched_setaffinity(0, {cores[len(cores) // 2]})
+        return cores
+    except Exception:
+        return None
+
+
+def cpu_baseline_c4(args, frames_np, first, ln0, counts, cap, nm_gpu, tree, valid_np):
+    """The CPU oracle (kind 'port': the reference itself needs OpenCV/DBoW2 and cannot be built), as BASELINE.md plans it:
+    ONE pinned thread, 10 warm-up frames then >= 200 timed frames, median per-frame time (extract and match timed
+    separately); plus an all-cores figure (one frame stream per core, cores stated).  Every sampled frame is also the
+    parity check of the GPU results of the timed run."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle
+    ref = oracle.Extractor(args.nfeatures, 1.2, 8, 20, 7)
+    B = frames_np.shape[0]
+    kps_gpu = ln0["kps"].cpu().numpy().view(capi.KP_DTYPE).reshape(B, cap)
+    desc_gpu = ln0["desc"].cpu().numpy().reshape(B, cap, 32)
+    match_gpu = ln0["match"].cpu().numpy().reshape(B, cap)
+    all_cores = pin_one_core()
+    n_warm = min(10, max(B - 2, 0))
+    n_timed = max(1, min(args.cpu_frames, B - n_warm))
+    t_ext, t_mat, parity, feats = [], [], True, {}
+    for i in range(n_warm + n_timed):
+        t0 = time.perf_counter()
+        k, d = ref.extract(frames_np[i])
+        te = time.perf_counter() - t0
+        n = int(counts[i])
+        parity &= (n == len(k)) and kps_gpu[i, :n].tobytes() == k.tobytes() and np.array_equal(desc_gpu[i, :n], d)
+        tm = 0.0
+        fv = None
+        if not args.no_match:
+            t0 = time.perf_counter()
+            _, nid = oracle.vocab_transform(tree, d, 4)
+            fv = oracle.featvec_from_nodes(nid)
+            tm += time.perf_counter() - t0
+        feats[i] = (k, d, fv)
+        if not args.no_match and i >= 1:
+            (ka, da, fva), (kb, db, fvb) = feats[i - 1], feats[i]
+            t0 = time.perf_counter()
+            nmr, mr = oracle.search_by_bow(da, ka["angle"], valid_np[i - 1][:len(ka)], fva, db, kb["angle"], fvb, 0.7, True)
+            tm += time.perf_counter() - t0
+            parity &= (nmr == int(nm_gpu[i - 1])) and np.array_equal(mr, match_gpu[i - 1, :len(kb)])
+            feats.pop(i - 1)
+        if i >= n_warm:
+            t_ext.append(te)
+            t_mat.append(tm)
+    if all_cores:
+        os.sched_setaffinity(0, set(all_cores))
+    med_e, med_m = statistics.median(t_ext), statistics.median(t_mat)
+    res = {"value": round(1.0 / (med_e + med_m), 3), "unit": "frames/s", "cores": 1, "kind": "port",
+           "sample": "frames %d..%d of the benchmark batch after %d warm-up frames: oracle extract%s, one pinned thread, median "
+                     "per-frame time" % (n_warm, n_warm + n_timed - 1, n_warm,
+                                         "" if args.no_match else " + vocabulary descent + SearchByBoW"),
+           "timed_frames": n_timed, "extract_ms_per_frame_median": round(med_e * 1e3, 3),
+           "match_ms_per_frame_median": round(med_m * 1e3, 3),
+           "extract_only_frames_per_s": round(1.0 / med_e, 3),
+           "gpu_matches_oracle_on_sample": bool(parity)}
+    if not args.no_cpu_all_cores and all_cores and len(all_cores) > 1:
+        nproc = len(all_cores)
+        per = 24
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(first + 8 * w), str(per),
+                                   str(args.width), str(args.height), str(args.nfeatures)], stdout=subprocess.PIPE, text=True)
+                 for w in range(nproc)]
+        rate = 0.0
+        for p in procs:
+            o, _ = p.communicate(timeout=600)
+            try:
+                r = json.loads(o.strip().splitlines()[-1])
+                rate += r["frames"] / r["seconds"]
+            except Exception:
+                pass
+        res["all_cores"] = {"value": round(rate, 2), "unit": "frames/s (extract only)", "cores": nproc,
+                            "sample": "%d concurrent single-thread oracle processes x %d frames each" % (nproc, per)}
+    return res
+
+
+# ================================================================== config c3: stereo pairs
+def run_c3(args, rank, local_rank, world, dev, comm_dev, dist):
+    """KITTI-sized stereo: a step = S pairs resident in HBM: extract S left + S right images (two handles on two
+    streams, as the reference's two threads, src/Frame.cc:82-85) + ComputeStereoMatches (src/Frame.cc:513-699) per pair
+    on the device-resident pyramids."""
+    W, H, nf, S = 1241, 376, 2000, 32
+    exl, exr = capi.Extractor(nf, device=local_rank), capi.Extractor(nf, device=local_rank)
+    cap = exl.max_keypoints
+    base = rank * S
+    lefts = np.stack([synth.synth_frame(100 + base + i, W, H) for i in range(S)])
+    rights = np.stack([synth.synth_stereo_right(100 + base + i, W, H) for i in range(S)])
+    d_l, d_r = torch.from_numpy(lefts).to(dev), torch.from_numpy(rights).to(dev)
+    buf = lambda n, dt: torch.zeros(n, dtype=dt, device=dev)
+    kl, kr = buf(S * cap * 28, torch.uint8), buf(S * cap * 28, torch.uint8)
+    dl, dr = buf(S * cap * 32, torch.uint8), buf(S * cap * 32, torch.uint8)
+    cl, cr = buf(S, torch.int32), buf(S, torch.int32)
+    ur, dp = buf(S * cap, torch.float32), buf(S * cap, torch.float32)
+    torch.cuda.synchronize()
+
+    def step():
+        exl.extract_batch_device(d_l.data_ptr(), S, H, W, W, W * H, kl.data_ptr(), dl.data_ptr(), cap, cl.data_ptr())
+        exr.extract_batch_device(d_r.data_ptr(), S, H, W, W, W * H, kr.data_ptr(), dr.data_ptr(), cap, cr.data_ptr())
+        exl.sync(); exr.sync()
+        nl, nr = cl.cpu().numpy(), cr.cpu().numpy()              # the search needs the counts on the host
+        for i in range(S):
+            capi.stereo_match_device(exl, exr, i, i, kl.data_ptr() + i * cap * 28, dl.data_ptr() + i * cap * 32, int(nl[i]),
+                                     kr.data_ptr() + i * cap * 28, dr.data_ptr() + i * cap * 32, int(nr[i]), MB, MBF,
+                                     ur.data_ptr() + i * cap * 4, dp.data_ptr() + i * cap * 4)
+        return nl, nr
+
+    for _ in range(args.warmup):
+        step()
+    exl.sync(); torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        nl, nr = step()
+    exl.sync(); exr.sync(); torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = shard.max_over_ranks(dist, time.perf_counter() - t0, comm_dev)
+    pairs = shard.sum_over_ranks(dist, S * args.steps, comm_dev)
+    exl.set_profiling(True)
+    for _ in range(4):
+        step()
+    exl.sync(); exr.sync()
+    stage_ms = exl.stage_ms()
+    exl.set_profiling(False)
+    if rank != 0:
+        return None
+    pyr_px = sum(int(exl.pyramid_level(0, l).size) for l in range(8))
+    u = ur.cpu().numpy().reshape(S, cap)
+    z = dp.cpu().numpy().reshape(S, cap)
+    mean_kp = float(nl.mean())
+    bytes_img = algorithmic_bytes_per_frame(W, H, pyr_px, mean_kp)
+    # per pair: both extractions + the stereo search's reads (both keypoint/descriptor sets, 11x(2L+11)-px SAD bands)
+    bytes_pair = 2 * bytes_img + int(nl.mean() + nr.mean()) * 60 + int(nl.mean()) * 2 * 11 * 21
+    rf, rv = roofline_blocks(stage_ms, S, bytes_img, float(stage_ms[4]))
+    rf["algorithmic_bytes_per_pair"] = int(bytes_pair)
+    out = {"metric": "frames/sec ORB extract + stereo search, 1241x376 stereo pairs, 8-level 2000-feat; HBM GB/s vs peak",
+           "value": round(2 * pairs / elapsed, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "u8", "data": "synthetic",
+           "config": {"workload": "BASELINE configs[2]: %d synthetic KITTI-sized stereo pairs (1241x376, disparity 12+8*floor(y/94), "
+                                  "nFeatures 2000) per step: extract left + right, ComputeStereoMatches per pair on the device "
+                                  "pyramids" % S, "pairs_per_step": S, "pairs_per_s": round(pairs / elapsed, 2),
+                      "ms_per_pair": round(elapsed / (pairs / world) * 1e3, 4), "mean_keypoints_left": round(mean_kp, 1),
+                      "mean_stereo_matches": round(float((u[:, :] >= 0).sum() / S), 1),
+                      "stage_ms_per_launch_left_handle": {n: round(float(v), 4) for n, v in zip(STAGES + ["extract_total"], stage_ms)}},
+           "roofline": rf}
+    if rv:
+        out["roofline_valu"] = rv
+    if world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle
+        all_cores = pin_one_core()
+        rl, rr = oracle.Extractor(nf), oracle.Extractor(nf)
+        kg_l = kl.cpu().numpy().view(capi.KP_DTYPE).reshape(S, cap)
+        dg_l = dl.cpu().numpy().reshape(S, cap, 32)
+        ts, parity = [], True
+        for i in range(min(S, 2 + max(1, args.cpu_frames // 10))):
+            t0 = time.perf_counter()
+            k1, d1 = rl.extract(lefts[i])
+            k2, d2 = rr.extract(rights[i])
+            uo, zo = oracle.stereo_matches(rl, rr, k1, d1, k2, d2, MB, MBF)
+            dt = time.perf_counter() - t0
+            if i >= 2:
+                ts.append(dt)
+            n = int(nl[i])
+            parity &= n == len(k1) and kg_l[i, :n].tobytes() == k1.tobytes() and np.array_equal(dg_l[i, :n], d1)
+            parity &= u[i, :n].tobytes() == uo.tobytes() and z[i, :n].tobytes() == zo.tobytes()
+        if all_cores:
+            os.sched_setaffinity(0, set(all_cores))
+        med = statistics.median(ts)
+        out["cpu_baseline"] = {"value": round(2.0 / med, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+                               "sample": "%d of the benchmark pairs after 2 warm-up pairs: oracle extract x2 + stereo search, one "
+                                         "pinned thread, median" % len(ts), "ms_per_pair_median": round(med * 1e3, 3),
+                               "gpu_matches_oracle_on_sample": bool(parity)}
+    return out
+
+
+# ================================================================== config c5: stream vs keyframe DB
+def run_c5(args, rank, local_rank, world, dev, comm_dev, dist):
+    """EuRoC-sized stream: a step = ONE 752x480 query frame: extract + vocabulary descent + SearchByBoW against every
+    keyframe of a 1000-keyframe descriptor DB resident in HBM (the Relocalization candidate loop, reference
+    src/Tracking.cc:1471-1492, is the batch axis); match(i) runs beside extract(i+1) over two query slots."""
+    W, H, n_kf = 752, 480, 1000
+    ex, mt = capi.Extractor(args.nfeatures, device=local_rank), capi.Matcher(0.7, True, device=local_rank)
+    cap = ex.max_keypoints
+    F = n_kf + 2                                                  # slots n_kf, n_kf+1 hold stream frames alternately
+    buf = lambda n, dt: torch.zeros(n, dtype=dt, device=dev)
+    d_kps, d_desc = buf(F * cap * 28, torch.uint8), buf(F * cap * 32, torch.uint8)
+    d_counts, d_node = buf(F, torch.int32), buf(F * cap, torch.int16)
+    valid_np = np.stack([synth.synth_valid_flags(cap, 7000 + i) for i in range(F)])
+    d_valid = torch.from_numpy(valid_np).to(dev)
+    tree = synth.synth_vocab_tree_balanced(10, 6)
+    voc = capi.Vocabulary(tree, device=local_rank)
+    n_nodes = voc.level_nodes(4)
+    # the keyframe DB: 1000 frames of a moving-camera sequence (125 scenes x 8 views); the stream revisits those scenes
+    for k0 in range(0, n_kf, 40):
+        n = min(40, n_kf - k0)
+        d_b = torch.from_numpy(synth.synth_sequence(k0, n, W, H)).to(dev)
+        ex.extract_batch_device(d_b.data_ptr(), n, H, W, W, W * H, d_kps.data_ptr() + k0 * cap * 28,
+                                d_desc.data_ptr() + k0 * cap * 32, cap, d_counts.data_ptr() + k0 * 4)
+        ex.sync()
+    voc.transform_device(mt, d_desc.data_ptr(), d_counts.data_ptr(), n_kf, cap, 4, d_node_of=d_node.data_ptr())
+    mt.sync()
+    n_q = 16
+    q_first = 3 + 8 * (rank % 100)
+    stream_np = np.stack([synth.synth_sequence(q_first + 61 * i, 1, W, H, noise=5)[0] for i in range(n_q)])
+    stream = torch.from_numpy(stream_np).to(dev)
+    kf_idx = torch.arange(n_kf, dtype=torch.int32, device=dev)
+    f_idx = [torch.full((n_kf,), n_kf + s, dtype=torch.int32, device=dev) for s in (0, 1)]
+    d_match = [buf(n_kf * cap, torch.int32) for _ in (0, 1)]
+    d_nm = [buf(n_kf, torch.int32) for _ in (0, 1)]
+    store = dict(desc=d_desc.data_ptr(), kps=d_kps.data_ptr(), valid=d_valid.data_ptr(), counts=d_counts.data_ptr(),
+                 node_of=d_node.data_ptr(), cap=cap, n_frames=F, n_nodes=n_nodes)
+    torch.cuda.synchronize()
+
+    def extract(i):                                # stream frame i -> query slot i % 2
+        s = i % 2
+        ex.extract_batch_device(stream.data_ptr() + (i % n_q) * W * H, 1, H, W, W, W * H, d_kps.data_ptr() + (n_kf + s) * cap * 28,
+                                d_desc.data_ptr() + (n_kf + s) * cap * 32, cap, d_counts.data_ptr() + (n_kf + s) * 4)
+
+    def match(i):
+        s = i % 2
+        voc.transform_device(mt, d_desc.data_ptr() + (n_kf + s) * cap * 32, d_counts.data_ptr() + (n_kf + s) * 4, 1, cap, 4,
+                             d_node_of=d_node.data_ptr() + (n_kf + s) * cap * 2)
+        mt.match_bow_batch_device(store, kf_idx.data_ptr(), f_idx[s].data_ptr(), n_kf, d_match[s].data_ptr(), d_nm[s].data_ptr())
+
+    def run(n, i0=0):
+        # software pipeline over two query slots: match(i) runs beside extract(i+1).  Both stream waits are taken
+        # BEFORE the two launches, so match(i) waits for extract(i) only and extract(i+1) for match(i-1) only (which
+        # used the slot extract(i+1) is about to overwrite).
+        ex.wait_for(mt.stream)
+        extract(i0)
+        for i in range(i0, i0 + n):
+            mt.wait_for(ex.stream)
+            ex.wait_for(mt.stream)
+            extract(i + 1)
+            match(i)
+
+    run(max(args.warmup, 2))
+    ex.sync(); mt.sync(); torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    run(args.steps)
+    ex.sync(); mt.sync(); torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = shard.max_over_ranks(dist, time.perf_counter() - t0, comm_dev)
+    done = shard.sum_over_ranks(dist, args.steps, comm_dev)
+    # non-overlapped match duration (the dominant kernel of this configuration is k_match_bow over 1000 pairs)
+    t_m = []
+    for i in range(4):
+        ex.wait_for(mt.stream); extract(i); ex.sync()
+        t1 = time.perf_counter(); match(i); mt.sync(); t_m.append(time.perf_counter() - t1)
+    match_ms = statistics.median(t_m) * 1e3
+    if rank != 0:
+        return None
+    last = (args.steps - 1) % 2                    # slot of the last matched stream frame (frame index steps-1)
+    nm = d_nm[last].cpu().numpy()
+    cnts = d_counts.cpu().numpy()
+    n1 = float(cnts[:n_kf].mean())
+    bytes_query = n_kf * (n1 * (32 + 4 + 1 + 4) + 8 * n_nodes + 4 * float(cnts[n_kf + last]))     # SURVEY 8(d): B_bow per pair
+    ach = bytes_query / (match_ms * 1e-3) / 1e9
+    out = {"metric": "frames/sec ORB extract + SearchByBoW vs 1000-keyframe DB, 752x480 8-level 1000-feat; HBM GB/s vs peak",
+           "value": round(done / elapsed, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "u8", "data": "synthetic",
+           "config": {"workload": "BASELINE configs[4]: 752x480 stream, per frame extract + vocabulary descent + SearchByBoW against "
+                                  "a %d-keyframe DB in HBM (moving-camera sequence of 125 scenes x 8 views; the stream revisits "
+                                  "them)" % n_kf, "pair_matchings_per_s": round(n_kf * done / elapsed, 0),
+                      "mean_matches_per_pair": round(float(nm.mean()), 2), "max_matches_per_pair": int(nm.max()),
+                      "transform_plus_match_ms_alone": round(match_ms, 4)},
+           "roofline": {"bound": "hbm", "kernel": "k_match_bow (+ k_vocab_transform of the query)", "achieved": round(ach, 2),
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                        "algorithmic_bytes_per_query": int(bytes_query), "kernel_ms_per_launch": round(match_ms, 4),
+                        "binding": "latency of the per-node descriptor loads (43 % VALU-busy), not HBM"}}
+    if world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle
+        all_cores = pin_one_core()
+        ref = oracle.Extractor(args.nfeatures)
+        # the DB side of the sample: GPU-extracted keyframes (their parity is the extractor tests' business), 60 keyframes
+        sample_kf = list(range(0, n_kf, max(1, n_kf // 60)))[:60]
+        kps_all = d_kps.cpu().numpy().view(capi.KP_DTYPE).reshape(F, cap)
+        desc_all = d_desc.cpu().numpy().reshape(F, cap, 32)
+        mg = d_match[last].cpu().numpy().reshape(n_kf, cap)
+        qi = (args.steps - 1) % n_q
+        t0 = time.perf_counter()
+        kq, dq = ref.extract(stream_np[qi])
+        t_ext = time.perf_counter() - t0
+        parity = len(kq) == int(cnts[n_kf + last]) and np.array_equal(desc_all[n_kf + last, :len(kq)], dq)
+        t0 = time.perf_counter()
+        fvq = oracle.featvec_from_nodes(oracle.vocab_transform(tree, dq, 4)[1])
+        t_tr = time.perf_counter() - t0
+        t_match = 0.0
+        for kf in sample_kf:
+            n = int(cnts[kf])
+            dk, kk = desc_all[kf, :n], kps_all[kf, :n]
+            fvk = oracle.featvec_from_nodes(oracle.vocab_transform(tree, dk, 4)[1])     # DB side is precomputed in the reference too
+            t0 = time.perf_counter()
+            nmr, mr = oracle.search_by_bow(dk, kk["angle"], valid_np[kf][:n], fvk, dq, kq["angle"], fvq, 0.7, True)
+            t_match += time.perf_counter() - t0
+            parity &= nmr == int(nm[kf]) and np.array_equal(mr, mg[kf, :len(kq)])
+        if all_cores:
+            os.sched_setaffinity(0, set(all_cores))
+        per_frame = t_ext + t_tr + t_match / len(sample_kf) * n_kf
+        out["cpu_baseline"] = {"value": round(1.0 / per_frame, 4), "unit": "frames/s", "cores": 1, "kind": "port",
+                               "sample": "one stream frame: oracle extract + vocabulary descent timed whole, SearchByBoW timed on %d of "
+                                         "the %d keyframes and scaled to %d; one pinned thread" % (len(sample_kf), n_kf, n_kf),
+                               "extract_ms": round(t_ext * 1e3, 3), "transform_ms": round(t_tr * 1e3, 3),
+                               "match_ms_per_pair": round(t_match / len(sample_kf) * 1e3, 4),
+                               "gpu_matches_oracle_on_sample": bool(parity)}
+    return out
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as plain `python bench.py --gpus N`: start the N ranks as fresh child processes BEFORE anything here
+        # touches the GPU (no exec from a process that initialised HIP), and leave with their exit code
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr",
+               "127.0.0.1", "--master-port", str(args.master_port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        sys.exit(subprocess.call(cmd, env=env))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: refusing to print a mislabelled number" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     if args.single_device:
@@ -75,188 +632,11 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
-
-    B, W, H = args.frames_per_gpu, args.width, args.height
-    ex = capi.Extractor(args.nfeatures, 1.2, 8, 20, 7, device=local_rank)
-    mt = capi.Matcher(0.7, True, device=local_rank)           # Tracking.cc:815 parameters
-    cap = ex.max_keypoints
-
-    # ---- the one collective: rank 0 broadcasts the BRIEF pattern (RCCL over xGMI)
-    pat = torch.zeros(1024, dtype=torch.int8, device=comm_dev)
-    if rank == 0:
-        pat.copy_(torch.from_numpy(capi.builtin_pattern()))
-    shard.broadcast_pattern(dist, pat, 0)
-    pat = pat.to(dev)
-    torch.cuda.synchronize()
-    ex.set_pattern_device(pat.data_ptr())
-
-    # ---- synthetic inputs, resident in HBM before the timed region
-    first, _ = shard.weak_range(B, rank)            # weak scaling: every rank owns B frames of its own
-    n_sets = max(1, args.input_sets)
-    frames_sets = [synth.synth_batch(first + k * world * B, B, W, H) for k in range(n_sets)]
-    d_img_sets = [torch.from_numpy(fr).to(dev) for fr in frames_sets]
-    d_kps = torch.zeros(B * cap * 28, dtype=torch.uint8, device=dev)
-    d_desc = torch.zeros(B * cap * 32, dtype=torch.uint8, device=dev)
-    d_counts = torch.zeros(B, dtype=torch.int32, device=dev)
-    d_nodeof = torch.zeros(B * cap, dtype=torch.int16, device=dev)
-    d_valid = torch.from_numpy(np.stack([synth.synth_valid_flags(cap, rank * B + i) for i in range(B)])).to(dev)
-    d_cent = torch.from_numpy(synth.synth_vocabulary()).to(dev)
-    kf_idx = torch.arange(B, dtype=torch.int32, device=dev)
-    f_idx = ((torch.arange(B, dtype=torch.int32, device=dev) + 1) % B).to(torch.int32)
-    d_match = torch.zeros(B * cap, dtype=torch.int32, device=dev)
-    d_nm = torch.zeros(B, dtype=torch.int32, device=dev)
-    store = dict(desc=d_desc.data_ptr(), kps=d_kps.data_ptr(), valid=d_valid.data_ptr(), counts=d_counts.data_ptr(),
-                 node_of=d_nodeof.data_ptr(), cap=cap, n_frames=B)
-    torch.cuda.synchronize()
-
-    # ---- lanes: lane 0 is (ex, mt, the buffers above); further lanes (--pipeline P) have their own extractor, matcher
-    # and output buffers and share the read-only inputs.  Consecutive steps alternate between lanes, each lane on its
-    # own streams, so the latency-bound stages of one step (pyramid, quadtree, matcher) overlap the issue-bound stages
-    # (FAST, descriptors) of the next.
-    lanes = [dict(ex=ex, mt=mt, kps=d_kps, desc=d_desc, counts=d_counts, nodeof=d_nodeof, match=d_match, nm=d_nm, store=store)]
-    for _ in range(1, max(1, args.pipeline)):
-        lex = capi.Extractor(args.nfeatures, 1.2, 8, 20, 7, device=local_rank)
-        lex.set_pattern_device(pat.data_ptr())
-        lmt = capi.Matcher(0.7, True, device=local_rank)
-        ln = dict(ex=lex, mt=lmt, kps=torch.zeros_like(d_kps), desc=torch.zeros_like(d_desc), counts=torch.zeros_like(d_counts),
-                  nodeof=torch.zeros_like(d_nodeof), match=torch.zeros_like(d_match), nm=torch.zeros_like(d_nm))
-        ln["store"] = dict(desc=ln["desc"].data_ptr(), kps=ln["kps"].data_ptr(), valid=d_valid.data_ptr(),
-                           counts=ln["counts"].data_ptr(), node_of=ln["nodeof"].data_ptr(), cap=cap, n_frames=B)
-        lanes.append(ln)
-    torch.cuda.synchronize()
-    step_no = [0]
-
-    def step():
-        ln = lanes[step_no[0] % len(lanes)]
-        ln["set"] = step_no[0] % n_sets                # which input batch this lane's buffers will hold results of
-        d_imgs = d_img_sets[ln["set"]]
-        step_no[0] += 1
-        lx, lm = ln["ex"], ln["mt"]
-        lx.wait_for(lm.stream)                     # this lane's outputs of its previous step are still being matched
-        lx.extract_batch_device(d_imgs.data_ptr(), B, H, W, W, W * H, ln["kps"].data_ptr(), ln["desc"].data_ptr(), cap,
-                                ln["counts"].data_ptr())
-        if not args.no_match:
-            lm.wait_for(lx.stream)
-            lm.bow_assign_device(ln["desc"].data_ptr(), ln["counts"].data_ptr(), B, cap, d_cent.data_ptr(),
-                                 ln["nodeof"].data_ptr())
-            lm.match_bow_batch_device(ln["store"], kf_idx.data_ptr(), f_idx.data_ptr(), B, ln["match"].data_ptr(),
-                                      ln["nm"].data_ptr())
-
-    def full_sync():
-        for ln in lanes:
-            ln["ex"].sync()
-            ln["mt"].sync()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    full_sync()
-    ex.set_profiling(True)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    full_sync()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    elapsed = shard.max_over_ranks(dist, elapsed, comm_dev)
-    frames_done = shard.sum_over_ranks(dist, B * args.steps, comm_dev)
-
-    stage_ms = ex.stage_ms()                       # HIP events on the stream the kernels were launched on
-    launch_frames = ex.profiled_frames()           # frames per timed launch (sub-batch 0)
-    ex.set_profiling(False)
-    counts = d_counts.cpu().numpy()
-    nm = d_nm.cpu().numpy()
-    mean_kp = float(counts.mean())
-    pyr_px = sum(int(ex.pyramid_level(0, l).size) for l in range(8))
-
-    if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
-        return
-
-    total_frames = frames_done
-    fps = total_frames / elapsed
-    names = ["pyramid(k_copy_level0 + resize kernels)", "k_fast_cells", "k_quadtree", "k_orient_desc"]
-    dom = int(np.argmax(stage_ms[:4]))
-    bytes_frame = algorithmic_bytes_per_frame(W, H, pyr_px, mean_kp)
-    achieved = bytes_frame * launch_frames / (float(stage_ms[dom]) * 1e-3) / 1e9
-    out = {
-        "metric": "frames/sec ORB extract+match, 640x480 8-level 1000-feat; HBM GB/s vs peak",
-        "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": "batch of %d synthetic %dx%d frames per GPU, nFeatures=%d, 8 levels, scale 1.2, "
-                               "FAST 20/7; extract + SearchByBoW(frame i as keyframe, frame i+1), ratio 0.7"
-                               % (B, W, H, args.nfeatures),
-                   "frames_per_gpu": B, "input_sets": n_sets, "match": not args.no_match, "mean_keypoints": round(mean_kp, 1),
-                   "mean_bow_matches": round(float(nm.mean()), 1),
-                   "frames_per_launch": launch_frames,
-                   "stage_ms_per_launch": {n: round(float(v), 4) for n, v in zip(names + ["extract_total"], stage_ms)}},
-        "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                     "algorithmic_bytes_per_frame": int(bytes_frame), "frames_per_launch": launch_frames,
-                     "kernel_ms_per_launch": round(float(stage_ms[dom]), 4)},
-    }
-    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")     # filled by tools/pmc_summary.py from rocprofv3 --pmc runs
-    if os.path.exists(pmc):
-        try:
-            tr = json.load(open(pmc))
-            key = names[dom].split("(")[0]
-            if tr.get("frames_per_launch") == launch_frames and key in tr.get("bytes_per_launch", {}):
-                out["roofline"]["traffic"] = tr["bytes_per_launch"][key]
-        except Exception:
-            pass
-
-    if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args, frames_sets[lanes[0]["set"]], d_kps, d_desc, counts, cap, nm, d_match)
-    print(json.dumps(out), flush=True)
+    out = {"c4": run_c4, "c3": run_c3, "c5": run_c5}[args.config](args, rank, local_rank, world, dev, comm_dev, dist)
+    if rank == 0 and out is not None:
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
-
-
-def cpu_baseline(args, frames_np, d_kps, d_desc, counts, cap, nm_gpu, d_match):
-    """The CPU oracle (kind 'port': the reference itself needs OpenCV/DBoW2 and cannot be built),
-    single thread, on a bounded sample of the same frames; also the parity check of that sample."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle
-    ref = oracle.Extractor(args.nfeatures, 1.2, 8, 20, 7)
-    cent = synth.synth_vocabulary()
-    B = frames_np.shape[0]
-    kps_gpu = d_kps.cpu().numpy().view(capi.KP_DTYPE).reshape(B, cap)
-    desc_gpu = d_desc.cpu().numpy().reshape(B, cap, 32)
-    match_gpu = d_match.cpu().numpy().reshape(B, cap)
-    t_start = time.perf_counter()
-    done, parity = 0, True
-    feats = []
-    t_extract = t_match = 0.0
-    while done < B and (time.perf_counter() - t_start) < args.cpu_seconds:
-        t0 = time.perf_counter()
-        k, d = ref.extract(frames_np[done])
-        t_extract += time.perf_counter() - t0
-        n = int(counts[done])
-        parity &= (n == len(k)) and kps_gpu[done, :n].tobytes() == k.tobytes() and np.array_equal(desc_gpu[done, :n], d)
-        feats.append((k, d))
-        if not args.no_match and done >= 1:
-            t0 = time.perf_counter()
-            (ka, da), (kb, db) = feats[done - 1], feats[done]
-            fva, fvb = oracle.bow_transform(da, cent), oracle.bow_transform(db, cent)
-            valid = synth.synth_valid_flags(cap, done - 1)[:len(ka)]
-            nmr, mr = oracle.search_by_bow(da, ka["angle"], valid, fva, db, kb["angle"], fvb, 0.7, True)
-            t_match += time.perf_counter() - t0
-            parity &= (nmr == int(nm_gpu[done - 1])) and np.array_equal(mr, match_gpu[done - 1, :len(kb)])
-        done += 1
-    total = t_extract + t_match
-    return {"value": round(done / total, 3), "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d of the %d benchmark frames, oracle extract%s, single thread" %
-                      (done, B, "" if args.no_match else " + bow_transform + SearchByBoW"),
-            "extract_ms_per_frame": round(t_extract / done * 1e3, 3),
-            "match_ms_per_frame": round(t_match / max(done - 1, 1) * 1e3, 3),
-            "gpu_matches_oracle_on_sample": bool(parity)}
 
 
 if __name__ == "__main__":

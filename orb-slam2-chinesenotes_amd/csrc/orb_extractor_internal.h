@@ -47,7 +47,7 @@ struct orb_extractor {
     size_t pyrSlab = 0, candSlab = 0;
     int sortCap = 4096, nodeCap = 0, maxKp = 0;
     int fastPdw = 20, fastRows = 66, fastSdw = 18, fastCandCap = 640;   // LDS sizing of k_fast_strips
-    int fastStripCells = 4;                 // cells per strip aimed at (ORB_FAST_STRIP overrides, 1..8)
+    int fastStripCells = 3;                 // cells per strip aimed at (ORB_FAST_STRIP overrides, 1..8)
 
     // device memory
     DevBuf dPattern, dAngTab, dCells, dXtab, dYtab, dXq, dPath;   // constants

@@ -5,6 +5,7 @@
 // reference tree; the algorithm is restated from its published source (first-minimum Hamming descent, children in
 // stored order).  Building the std::map containers (and the tf-idf BowVector, which uses doubles) stays on the host.
 #include <algorithm>
+#include <cstring>
 #include <map>
 #include <new>
 #include <vector>
@@ -13,14 +14,34 @@
 
 struct orb_vocab {
     int device = 0, nNodes = 0, L = 0;
-    MBuf desc, childBegin, children, wordId;
+    // The tree is re-laid out at creation: nodes are numbered in breadth-first SLOT order, so the children of a node
+    // are consecutive slots in their stored order (what "first minimum wins" iterates over) and one level of a descent
+    // reads ONE contiguous run of k x 32 bytes instead of k scattered 32-byte rows (ids come from file order in DBoW2).
+    MBuf slotDesc;          // [nNodes][32]
+    MBuf slotKids;          // int2 per slot: {first child slot, number of children}
+    MBuf slotNode;          // int32 per slot: the caller's node id
+    MBuf wordId;            // int32 per node id
     std::vector<int> depth;                         // host: depth of every node
     std::map<int, std::pair<MBuf, int>> compact;    // levelsup -> (device int32 compactOf[nNodes], K)
 };
 
-__global__ __launch_bounds__(256) void k_vocab_transform(const uint8_t* __restrict__ nodeDesc,
-                                                         const int32_t* __restrict__ childBegin,
-                                                         const int32_t* __restrict__ children,
+#include "orb_wave.h"
+
+// minimum over the 16 lanes of a DPP row, returned in every lane of the row (row_ror 8, 4, 2, 1)
+__device__ __forceinline__ unsigned row16_umin(unsigned v)
+{
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x128, 0xf, 0xf, false));
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x124, 0xf, 0xf, false));
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x122, 0xf, 0xf, false));
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x121, 0xf, 0xf, false));
+    return v;
+}
+
+// 16 lanes (one DPP row) per feature: lane r scores child r of the current node (its 32 bytes are one contiguous
+// read next to its siblings'), the row minimum of (distance << 16 | child index) is the first-minimum child.  The
+// descent is a chain of dependent loads, so what matters is many short chains in flight: 4 features per wave.
+__global__ __launch_bounds__(256) void k_vocab_transform(const uint4* __restrict__ slotDesc, const int2* __restrict__ slotKids,
+                                                         const int32_t* __restrict__ slotNode,
                                                          const int32_t* __restrict__ wordId, int nidLevel,
                                                          const int32_t* __restrict__ compactOf,
                                                          const uint8_t* __restrict__ desc,
@@ -28,33 +49,39 @@ __global__ __launch_bounds__(256) void k_vocab_transform(const uint8_t* __restri
                                                          int32_t* __restrict__ wordOf, int32_t* __restrict__ nodeId,
                                                          uint16_t* __restrict__ nodeOf)
 {
-    const int f = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = blockIdx.y, r = threadIdx.x & 15, i = blockIdx.x * 16 + (threadIdx.x >> 4);
     if (i >= cap) return;
     const size_t row = (size_t)f * cap + i;
     const int n = counts ? counts[f] : cap;
     if (i >= n) {
-        if (nodeOf) nodeOf[row] = 0xFFFF;
+        if (nodeOf && r == 0) nodeOf[row] = 0xFFFF;
         return;
     }
     const uint4 lo = reinterpret_cast<const uint4*>(desc + row * 32)[0], hi = reinterpret_cast<const uint4*>(desc + row * 32)[1];
-    int finalId = 0, level = 0, nid = (nidLevel <= 0) ? 0 : -1;
-    int b = childBegin[0], e = childBegin[1];
-    while (e > b) {                                               // do { ... } while (!isLeaf())
+    int slot = 0, level = 0, nidSlot = (nidLevel <= 0) ? 0 : -1;
+    int2 kids = slotKids[0];
+    while (kids.y > 0) {                                          // do { ... } while (!isLeaf())
         ++level;
-        int best = 257, bestId = -1;
-        for (int c = b; c < e; c++) {
-            const int id = children[c];
-            const uint4 nl = reinterpret_cast<const uint4*>(nodeDesc + (size_t)id * 32)[0], nh = reinterpret_cast<const uint4*>(nodeDesc + (size_t)id * 32)[1];
-            const int h = __popc(lo.x ^ nl.x) + __popc(lo.y ^ nl.y) + __popc(lo.z ^ nl.z) + __popc(lo.w ^ nl.w) +
-                          __popc(hi.x ^ nh.x) + __popc(hi.y ^ nh.y) + __popc(hi.z ^ nh.z) + __popc(hi.w ^ nh.w);
-            if (h < best) { best = h; bestId = id; }              // first minimum wins
+        unsigned best = 0xFFFFFFFFu;
+        for (int c0 = 0; c0 < kids.y; c0 += 16) {
+            const int c = c0 + r;
+            unsigned key = 0xFFFFFFFFu;
+            if (c < kids.y) {
+                const uint4* nd = slotDesc + (size_t)(kids.x + c) * 2;
+                const uint4 nl = nd[0], nh = nd[1];
+                const int h = __popc(lo.x ^ nl.x) + __popc(lo.y ^ nl.y) + __popc(lo.z ^ nl.z) + __popc(lo.w ^ nl.w) +
+                              __popc(hi.x ^ nh.x) + __popc(hi.y ^ nh.y) + __popc(hi.z ^ nh.z) + __popc(hi.w ^ nh.w);
+                key = ((unsigned)h << 16) | (unsigned)c;          // first minimum wins: smaller child index on ties
+            }
+            best = min(best, row16_umin(key));
         }
-        finalId = bestId;
-        if (level == nidLevel) nid = finalId;
-        b = childBegin[finalId];
-        e = childBegin[finalId + 1];
+        slot = kids.x + (int)(best & 0xffffu);
+        if (level == nidLevel) nidSlot = slot;
+        kids = slotKids[slot];
     }
-    if (wordOf) wordOf[row] = wordId[finalId];
+    if (r != 0) return;
+    if (wordOf) wordOf[row] = wordId[slotNode[slot]];
+    const int nid = nidSlot >= 0 ? slotNode[nidSlot] : -1;
     if (nodeId) nodeId[row] = nid;
     if (nodeOf) nodeOf[row] = (nid >= 0 && compactOf) ? (uint16_t)compactOf[nid] : (uint16_t)0xFFFF;
 }
@@ -84,18 +111,33 @@ extern "C" int orb_vocab_create(int device, const uint8_t* node_desc, const int3
             order.push_back(id);
         }
     }
+    for (int i = 0; i < n_nodes; i++)
+        if (child_begin[i + 1] - child_begin[i] > 65535) { orb_set_error("vocabulary: more than 65535 children"); return ORB_ERR_UNSUPPORTED; }
+    // slot layout: `order` is a breadth-first order in which the children of a node are consecutive, in stored order
+    // (nodes unreachable from the root get no slot: a descent never visits them)
+    const int nSlots = (int)order.size();
+    std::vector<int32_t> slotOf(n_nodes, -1), slotNode(nSlots);
+    for (int s2 = 0; s2 < nSlots; s2++) { slotOf[order[s2]] = s2; slotNode[s2] = order[s2]; }
+    std::vector<int32_t> kids(2 * (size_t)nSlots);
+    std::vector<uint8_t> sdesc((size_t)32 * nSlots);
+    for (int s2 = 0; s2 < nSlots; s2++) {
+        const int node = order[s2], nc = child_begin[node + 1] - child_begin[node];
+        kids[2 * (size_t)s2] = nc > 0 ? slotOf[children[child_begin[node]]] : 0;
+        kids[2 * (size_t)s2 + 1] = nc;
+        std::memcpy(&sdesc[(size_t)32 * s2], node_desc + (size_t)32 * node, 32);
+    }
     orb_vocab* v = new (std::nothrow) orb_vocab();
     if (!v) return ORB_ERR_INTERNAL;
     v->device = device; v->nNodes = n_nodes; v->L = L; v->depth = depth;
     int rc;
-    if ((rc = v->desc.ensure((size_t)32 * n_nodes)) != ORB_OK || (rc = v->childBegin.ensure((size_t)4 * (n_nodes + 1))) != ORB_OK ||
-        (rc = v->children.ensure((size_t)4 * nch)) != ORB_OK || (rc = v->wordId.ensure((size_t)4 * n_nodes)) != ORB_OK) {
-        delete v;
+    if ((rc = v->slotDesc.ensure((size_t)32 * nSlots)) != ORB_OK || (rc = v->slotKids.ensure((size_t)8 * nSlots)) != ORB_OK ||
+        (rc = v->slotNode.ensure((size_t)4 * nSlots)) != ORB_OK || (rc = v->wordId.ensure((size_t)4 * n_nodes)) != ORB_OK) {
+        orb_vocab_destroy(v);
         return rc;
     }
-    ORB_HIP_TRY(hipMemcpy(v->desc.p, node_desc, (size_t)32 * n_nodes, hipMemcpyHostToDevice));
-    ORB_HIP_TRY(hipMemcpy(v->childBegin.p, child_begin, (size_t)4 * (n_nodes + 1), hipMemcpyHostToDevice));
-    ORB_HIP_TRY(hipMemcpy(v->children.p, children, (size_t)4 * nch, hipMemcpyHostToDevice));
+    ORB_HIP_TRY(hipMemcpy(v->slotDesc.p, sdesc.data(), (size_t)32 * nSlots, hipMemcpyHostToDevice));
+    ORB_HIP_TRY(hipMemcpy(v->slotKids.p, kids.data(), (size_t)8 * nSlots, hipMemcpyHostToDevice));
+    ORB_HIP_TRY(hipMemcpy(v->slotNode.p, slotNode.data(), (size_t)4 * nSlots, hipMemcpyHostToDevice));
     ORB_HIP_TRY(hipMemcpy(v->wordId.p, word_id, (size_t)4 * n_nodes, hipMemcpyHostToDevice));
     *out = v;
     return ORB_OK;
@@ -105,7 +147,7 @@ extern "C" void orb_vocab_destroy(orb_vocab* v)
 {
     if (!v) return;
     (void)hipSetDevice(v->device);
-    v->desc.release(); v->childBegin.release(); v->children.release(); v->wordId.release();
+    v->slotDesc.release(); v->slotKids.release(); v->slotNode.release(); v->wordId.release();
     for (auto& kv : v->compact) kv.second.first.release();
     delete v;
 }
@@ -154,8 +196,8 @@ extern "C" int orb_bow_transform_device(orb_matcher* m, orb_vocab* v, const uint
         if ((rc = compact_table(v, levelsup, &tab, &K)) != ORB_OK) return rc;
         if (K > 65534) { orb_set_error("more than 65534 vocabulary nodes at that level"); return ORB_ERR_UNSUPPORTED; }
     }
-    hipLaunchKernelGGL(k_vocab_transform, dim3((cap + 255) / 256, n_frames), dim3(256), 0, m->stream,
-                       (const uint8_t*)v->desc.p, (const int32_t*)v->childBegin.p, (const int32_t*)v->children.p,
+    hipLaunchKernelGGL(k_vocab_transform, dim3((cap + 15) / 16, n_frames), dim3(256), 0, m->stream,
+                       (const uint4*)v->slotDesc.p, (const int2*)v->slotKids.p, (const int32_t*)v->slotNode.p,
                        (const int32_t*)v->wordId.p, v->L - levelsup, tab, d_desc, d_counts, cap, d_word_of, d_node_id, d_node_of);
     ORB_HIP_TRY(hipGetLastError());
     return ORB_OK;

@@ -424,6 +424,14 @@ def stereo_match(ex_left, ex_right, k_l, d_l, k_r, d_r, mb, mbf):
     return u[:n], z[:n]
 
 
+def stereo_match_device(ex_left, ex_right, frame_l, frame_r, d_kps_l, d_desc_l, n_l, d_kps_r, d_desc_r, n_r, mb, mbf,
+                        d_u_right, d_depth):
+    """Device-pointer form: frames frame_l / frame_r of the handles' last batches; asynchronous on the left handle's stream."""
+    _check(lib().orb_stereo_match_device(ex_left.h, ex_right.h, frame_l, frame_r, C.c_void_p(d_kps_l), C.c_void_p(d_desc_l), n_l,
+                                         C.c_void_p(d_kps_r), C.c_void_p(d_desc_r), n_r, C.c_float(mb), C.c_float(mbf),
+                                         C.c_void_p(d_u_right), C.c_void_p(d_depth)))
+
+
 class Vocabulary:
     """A flattened DBoW2 vocabulary tree on the device (see orbhip.synth.synth_vocab_tree for the array layout)."""
 

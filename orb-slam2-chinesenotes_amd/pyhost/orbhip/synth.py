@@ -117,3 +117,49 @@ def synth_vocab_tree(k: int = 10, L: int = 3, seed: int = 0xB0CAB, prune: float 
     word_id[leaves] = np.arange(len(leaves), dtype=np.int32)
     node_desc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
     return dict(node_desc=node_desc, child_begin=child_begin, children=children, word_id=word_id, L=L, k=k)
+
+
+def synth_sequence(first: int, count: int, width: int = 640, height: int = 480, views: int = 8, noise: int = 6) -> np.ndarray:
+    """Frames that look like a slowly moving camera: frame i is view v = i % views of scene g = i // views, i.e. the
+    noise-free synth_frame(views * g) rolled by (v, 2v) pixels (rows, columns) with fresh noise.  Consecutive frames of
+    a scene share almost all corners, so SearchByBoW between frame i and i+1 finds hundreds of matches (unrelated
+    scenes give about 7) -- the accept / greedy-taken / rotation-histogram path of the matcher is exercised."""
+    out = np.empty((count, height, width), np.uint8)
+    base, base_g = None, -1
+    for k in range(count):
+        i = first + k
+        g, v = divmod(i, views)
+        if g != base_g:
+            base, base_g = synth_frame(views * g, width, height, noise=0).astype(np.int16), g
+        img = np.roll(base, (v, 2 * v), axis=(0, 1))
+        if noise > 0:
+            nz = splitmix64(SEED0 + 0x20000 + i, 0, width * height) % np.uint64(2 * noise + 1)
+            img = img + (nz.astype(np.int16).reshape(height, width) - noise)
+        out[k] = np.clip(img, 0, 255).astype(np.uint8)
+    return out
+
+
+def synth_vocab_tree_balanced(k: int = 10, L: int = 6, seed: int = 0xB0CAB) -> dict:
+    """A complete k-ary tree of depth L in the layout of synth_vocab_tree (vectorised: 1.1 M nodes for the DBoW2 shape
+    k = 10, L = 6 of ORBvoc, the work Frame::ComputeBoW's transform(..., 4) does per feature: 6 levels x 10 Hamming).
+    Node ids are permuted (ids come from file order in DBoW2); leaves are the words."""
+    rng = np.random.default_rng(seed)
+    n_inner = (k ** L - 1) // (k - 1)
+    n = n_inner + k ** L
+    perm = np.arange(n, dtype=np.int64)
+    perm[1:] = 1 + rng.permutation(n - 1)                           # BFS index -> node id; root stays node 0
+    inv = np.empty(n, np.int64)
+    inv[perm] = np.arange(n)                                        # node id -> BFS index
+    nchild = np.where(inv < n_inner, k, 0)
+    child_begin = np.zeros(n + 1, np.int64)
+    np.cumsum(nchild, out=child_begin[1:])
+    children = np.empty(int(child_begin[-1]), np.int32)
+    inner_ids = np.nonzero(inv < n_inner)[0]                        # ascending node id
+    bfs = inv[inner_ids]
+    kid_bfs = (bfs[:, None] * k + 1 + np.arange(k)[None, :])        # BFS children of BFS node b: k*b+1 .. k*b+k
+    children[:] = perm[kid_bfs].reshape(-1).astype(np.int32)
+    word_id = np.full(n, -1, np.int32)
+    leaves = np.nonzero(inv >= n_inner)[0]
+    word_id[leaves] = np.arange(leaves.size, dtype=np.int32)
+    node_desc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    return dict(node_desc=node_desc, child_begin=child_begin.astype(np.int32), children=children, word_id=word_id, L=L, k=k)

@@ -243,6 +243,18 @@ def bow_transform(desc, centroids):
     return FeatVec(ids[:nn], offs[:nn + 1], idx[:n])
 
 
+def featvec_from_nodes(node_id):
+    """FeatureVector of DBoW2's transform: fv[nid].push_back(i) for i ascending (features whose descent ended above
+    the level, node_id < 0, are in no node) -> ascending node ids, ascending indices inside a node."""
+    node_id = np.asarray(node_id, np.int64)
+    idx = np.nonzero(node_id >= 0)[0]
+    order = idx[np.argsort(node_id[idx], kind="stable")]
+    ids, counts = np.unique(node_id[idx], return_counts=True)
+    offs = np.zeros(ids.size + 1, np.int32)
+    np.cumsum(counts, out=offs[1:])
+    return FeatVec(ids.astype(np.uint32), offs, order.astype(np.int32))
+
+
 def search_by_bow(desc_kf, angle_kf, valid_kf, fv_kf, desc_f, angle_f, fv_f, ratio=0.7, check_ori=True):
     desc_kf = np.ascontiguousarray(desc_kf, np.uint8); desc_f = np.ascontiguousarray(desc_f, np.uint8)
     angle_kf = np.ascontiguousarray(angle_kf, np.float32); angle_f = np.ascontiguousarray(angle_f, np.float32)
