@@ -182,9 +182,12 @@ def run_c4(args, rank, local_rank, world, dev, comm_dev, dist):
         ln = dict(ex=lex, mt=lmt, kps=torch.zeros(B * cap * 28, dtype=torch.uint8, device=dev),
                   desc=torch.zeros(B * cap * 32, dtype=torch.uint8, device=dev), counts=torch.zeros(B, dtype=torch.int32, device=dev),
                   nodeof=torch.zeros(B * cap, dtype=torch.int16, device=dev), match=torch.zeros(B * cap, dtype=torch.int32, device=dev),
-                  nm=torch.zeros(B, dtype=torch.int32, device=dev), set=0)
+                  nm=torch.zeros(B, dtype=torch.int32, device=dev), set=0,
+                  ckeys=torch.zeros(B * cap, dtype=torch.int32, device=dev), cstart=torch.zeros(B * n_nodes, dtype=torch.int16, device=dev),
+                  ccnt=torch.zeros(B * n_nodes, dtype=torch.int16, device=dev))
         ln["store"] = dict(desc=ln["desc"].data_ptr(), kps=ln["kps"].data_ptr(), valid=d_valid.data_ptr(),
-                           counts=ln["counts"].data_ptr(), node_of=ln["nodeof"].data_ptr(), cap=cap, n_frames=B, n_nodes=n_nodes)
+                           counts=ln["counts"].data_ptr(), node_of=ln["nodeof"].data_ptr(), cap=cap, n_frames=B, n_nodes=n_nodes,
+                           csr_keys=ln["ckeys"].data_ptr(), csr_start=ln["cstart"].data_ptr(), csr_cnt=ln["ccnt"].data_ptr())
         return ln
 
     # lanes: consecutive steps alternate between lanes, each lane on its own streams, so the latency-bound stages of one
@@ -209,6 +212,9 @@ def run_c4(args, rank, local_rank, world, dev, comm_dev, dist):
         if not args.no_match:
             lm.wait_for(lx.stream)
             voc.transform_device(lm, ln["desc"].data_ptr(), ln["counts"].data_ptr(), B, cap, 4, d_node_of=ln["nodeof"].data_ptr())
+            # the FeatureVector of every frame once (Frame::ComputeBoW), not once per pair inside the matcher
+            lm.build_csr_device(ln["nodeof"].data_ptr(), ln["counts"].data_ptr(), B, cap, n_nodes, ln["ckeys"].data_ptr(),
+                                ln["cstart"].data_ptr(), ln["ccnt"].data_ptr())
             lm.match_bow_batch_device(ln["store"], kf_idx.data_ptr(), f_idx.data_ptr(), B, ln["match"].data_ptr(),
                                       ln["nm"].data_ptr())
 
@@ -489,7 +495,10 @@ def run_c5(args, rank, local_rank, world, dev, comm_dev, dist):
         ex.extract_batch_device(d_b.data_ptr(), n, H, W, W, W * H, d_kps.data_ptr() + k0 * cap * 28,
                                 d_desc.data_ptr() + k0 * cap * 32, cap, d_counts.data_ptr() + k0 * 4)
         ex.sync()
+    d_ckeys, d_cstart, d_ccnt = buf(F * cap, torch.int32), buf(F * n_nodes, torch.int16), buf(F * n_nodes, torch.int16)
     voc.transform_device(mt, d_desc.data_ptr(), d_counts.data_ptr(), n_kf, cap, 4, d_node_of=d_node.data_ptr())
+    mt.build_csr_device(d_node.data_ptr(), d_counts.data_ptr(), n_kf, cap, n_nodes, d_ckeys.data_ptr(), d_cstart.data_ptr(),
+                        d_ccnt.data_ptr())
     mt.sync()
     n_q = 16
     q_first = 3 + 8 * (rank % 100)
@@ -500,7 +509,8 @@ def run_c5(args, rank, local_rank, world, dev, comm_dev, dist):
     d_match = [buf(n_kf * cap, torch.int32) for _ in (0, 1)]
     d_nm = [buf(n_kf, torch.int32) for _ in (0, 1)]
     store = dict(desc=d_desc.data_ptr(), kps=d_kps.data_ptr(), valid=d_valid.data_ptr(), counts=d_counts.data_ptr(),
-                 node_of=d_node.data_ptr(), cap=cap, n_frames=F, n_nodes=n_nodes)
+                 node_of=d_node.data_ptr(), cap=cap, n_frames=F, n_nodes=n_nodes, csr_keys=d_ckeys.data_ptr(),
+                 csr_start=d_cstart.data_ptr(), csr_cnt=d_ccnt.data_ptr())
     torch.cuda.synchronize()
 
     def extract(i):                                # stream frame i -> query slot i % 2
@@ -512,6 +522,9 @@ def run_c5(args, rank, local_rank, world, dev, comm_dev, dist):
         s = i % 2
         voc.transform_device(mt, d_desc.data_ptr() + (n_kf + s) * cap * 32, d_counts.data_ptr() + (n_kf + s) * 4, 1, cap, 4,
                              d_node_of=d_node.data_ptr() + (n_kf + s) * cap * 2)
+        mt.build_csr_device(d_node.data_ptr() + (n_kf + s) * cap * 2, d_counts.data_ptr() + (n_kf + s) * 4, 1, cap, n_nodes,
+                            d_ckeys.data_ptr() + (n_kf + s) * cap * 4, d_cstart.data_ptr() + (n_kf + s) * n_nodes * 2,
+                            d_ccnt.data_ptr() + (n_kf + s) * n_nodes * 2)
         mt.match_bow_batch_device(store, kf_idx.data_ptr(), f_idx[s].data_ptr(), n_kf, d_match[s].data_ptr(), d_nm[s].data_ptr())
 
     def run(n, i0=0):

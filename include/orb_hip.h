@@ -266,7 +266,18 @@ typedef struct orb_featstore {
     int32_t cap;
     int32_t n_frames;
     int32_t n_nodes;            /* size of the node-index space of node_of (0 = 128, the synthetic stand-in) */
+    /* optional (all three or none; NULL = the matcher builds the feature vector of both sides for every pair): the
+     * per-frame feature vectors as CSR, filled once per frame by orb_bow_build_csr_device -- the flattened
+     * DBoW2::FeatureVector that the reference computes once per Frame / KeyFrame (src/Frame.cc:425-433) */
+    const uint32_t* csr_keys;   /* [n_frames*cap]      node << 16 | feature index, grouped by node            */
+    const uint16_t* csr_start;  /* [n_frames*n_nodes]  first key of the node                                  */
+    const uint16_t* csr_cnt;    /* [n_frames*n_nodes]  features of the frame in the node                      */
 } orb_featstore;
+
+/* Builds the CSR arrays above for frames [0, n_frames) of node_of / counts (same layout as in the store; pass
+ * pointers offset to a frame to (re)build just that frame).  Asynchronous on the matcher's stream. */
+int orb_bow_build_csr_device(orb_matcher* m, const uint16_t* d_node_of, const int32_t* d_counts, int n_frames, int cap,
+                             int n_nodes, uint32_t* d_keys, uint16_t* d_start, uint16_t* d_cnt);
 
 /* Vocabulary stand-in (DBoW2 transform(...,4) of reference src/Frame.cc:431 is
  * OUT OF SCOPE this round): 2-level k=10 tree, centroids = 110 x 32 bytes (device pointer).
@@ -275,7 +286,8 @@ int orb_bow_assign_device(orb_matcher* m, const uint8_t* d_desc, const int32_t* 
                           int cap, const uint8_t* d_centroids_110x32, uint16_t* d_node_of);
 
 /* d_match: [n_pairs][cap] int32 (F-feature -> KF-feature or -1); d_nmatches: [n_pairs].
- * Asynchronous on the matcher's stream. */
+ * A pair whose kf_index / f_index is outside [0, n_frames) or whose count is outside [0, cap] is not run: its
+ * d_nmatches entry is -1 and its d_match row all -1.  Asynchronous on the matcher's stream. */
 int orb_match_bow_batch_device(orb_matcher* m, const orb_featstore* store,
                                const int32_t* d_kf_index, const int32_t* d_f_index, int n_pairs,
                                float ratio, int check_ori, int32_t* d_match, int32_t* d_nmatches);

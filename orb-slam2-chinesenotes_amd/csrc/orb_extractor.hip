@@ -178,9 +178,7 @@ static int build_geometry(orb_extractor* h, int rows, int cols)
     int kpOff = 0, nodeCap = 0;
     std::vector<uint32_t> pathTab;
     int maxPdw = 4, maxRows = 7, maxSdw = 1;
-    int stripTarget = h->fastStripCells;
-    if (const char* e = std::getenv("ORB_FAST_STRIP")) stripTarget = std::atoi(e);
-    stripTarget = std::max(1, std::min(8, stripTarget));
+    int stripsOfLevel[ORB_MAX_LEVELS] = {0};
     for (int l = 0; l < nl; l++) {
         OrbLevelGeom& L = G.L[l];
         L.w = cv_round_f((float)cols * h->invScale[l]);                 // :1158
@@ -233,7 +231,7 @@ static int build_geometry(orb_extractor* h, int rows, int cols)
                     candCap += ((cw - 6 + 1) / 2) * ((row.h - 6 + 1) / 2);   // 3x3 strict NMS bound
                     nCells++;
                 }
-                const int rc = make_strips(row, wCell, stripTarget, strips, maxPdw, maxRows, maxSdw);
+                const int rc = make_strips(row, wCell, h->fastStripK[l], strips, maxPdw, maxRows, maxSdw);
                 if (rc != ORB_OK) return rc;
             }
         }
@@ -256,7 +254,9 @@ static int build_geometry(orb_extractor* h, int rows, int cols)
             L.nIni = 0; L.hX = 1.f; L.candCap = 0;
             strips.resize(firstStrip);
             nCells = firstCell;
-        } else {
+        }
+        stripsOfLevel[l] = (int)(strips.size() - firstStrip);
+        if (nIni > 0) {
             L.nIni = nIni;
             L.hX = (float)L.boxW / nIni;
         }
@@ -372,6 +372,7 @@ static int build_geometry(orb_extractor* h, int rows, int cols)
     h->G = G;
     h->strips.swap(strips);
     h->nCells = nCells;
+    std::memcpy(h->fastStripsOfLevel, stripsOfLevel, sizeof(stripsOfLevel));
     h->pyrSlab = (size_t)align_up((int)pyrOff, 256);
     h->candSlab = candOff;
     h->nodeCap = nodeCap;
@@ -387,6 +388,7 @@ static int build_geometry(orb_extractor* h, int rows, int cols)
     h->framesCap = 0;                                  // slabs changed size: re-allocate lazily
     h->rows = rows;
     h->cols = cols;
+    h->geomDirty = false;
     return ORB_OK;
 }
 
@@ -432,6 +434,11 @@ extern "C" int orb_extractor_create(const orb_extractor_params* p, int device_id
     h->prm = *p;
     h->device = device_id;
     build_tables(h);
+    {
+        int k = 3;
+        if (const char* e = std::getenv("ORB_FAST_STRIP")) { k = std::max(1, std::min(8, std::atoi(e))); h->fastStripFixed = true; }
+        for (int l = 0; l < ORB_MAX_LEVELS; l++) h->fastStripK[l] = k;
+    }
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete h; orb_set_error("hipStreamCreate: %s", hipGetErrorString(e)); return ORB_ERR_HIP; }
     for (int k = 0; k < orb_extractor::kProfSlots; k++)
@@ -582,7 +589,7 @@ extern "C" int orb_extract_batch_device(orb_extractor* h, const uint8_t* d_imgs,
     }
     if (!d_kps || !d_desc || rowStride < (size_t)cols) return ORB_ERR_INVALID;
     int rc;
-    if (rows != h->rows || cols != h->cols)
+    if (rows != h->rows || cols != h->cols || h->geomDirty)
         if ((rc = build_geometry(h, rows, cols)) != ORB_OK) return rc;
     if ((rc = ensure_scratch(h, nFrames)) != ORB_OK) return rc;
     const OrbGeom& G = h->G;
@@ -650,6 +657,16 @@ static int check_status(orb_extractor* h)
         while (want < mx && want < 4096) want <<= 1;
         while (want > 256 && orb_quadtree_lds_bytes(want, h->nodeCap) > 60 * 1024) want >>= 1;
         if (want > h->sortCap) h->sortCap = want;
+    }
+    if (!h->fastStripFixed) {                          // levels whose strips keep overflowing get shorter strips
+        const int* ovf = err + (size_t)(1 + 2 * ORB_MAX_LEVELS) * n + 8;
+        bool changed = false;
+        for (int l = 0; l < h->prm.nlevels; l++)
+            if (h->fastStripK[l] > 1 && (long long)ovf[l] * 8 > (long long)h->fastStripsOfLevel[l] * n) {
+                h->fastStripK[l]--;
+                changed = true;
+            }
+        if (changed) h->geomDirty = true;              // the next call rebuilds the geometry (results do not depend on it)
     }
     for (int f = 0; f < n; f++)
         if (err[f]) {

@@ -47,7 +47,12 @@ struct orb_extractor {
     size_t pyrSlab = 0, candSlab = 0;
     int sortCap = 4096, nodeCap = 0, maxKp = 0;
     int fastPdw = 20, fastRows = 66, fastSdw = 18, fastCandCap = 640;   // LDS sizing of k_fast_strips
-    int fastStripCells = 3;                 // cells per strip aimed at (ORB_FAST_STRIP overrides, 1..8)
+    // cells per strip aimed at, per level.  Starts at 3 and is lowered for a level whose strips keep overflowing the
+    // candidate queue (coarse levels have several times more corners per pixel); ORB_FAST_STRIP=k fixes it (tuning).
+    int fastStripK[ORB_MAX_LEVELS];
+    int fastStripsOfLevel[ORB_MAX_LEVELS];
+    bool fastStripFixed = false;
+    bool geomDirty = false;                 // strip lengths changed: rebuild the geometry on the next call
 
     // device memory
     DevBuf dPattern, dAngTab, dCells, dXtab, dYtab, dXq, dPath;   // constants
@@ -55,14 +60,15 @@ struct orb_extractor {
     std::vector<long long> xqOff;               // per level offset into dXq (uint4 units), -1 = level not eligible
     DevBuf dPyr, dCand, dKpl, dOvf;             // per-batch scratch (dOvf: FAST strips to redo densely)
     // per-batch status words, ONE allocation so that one memset clears it and one copy fetches it:
-    // [err: n][FAST candidates per level: 8n][keypoints per level: 8n][FAST overflow-list length: 1 (+3 pad)]
-    // for the n frames of the current batch
+    // [err: n][FAST candidates per level: 16n][keypoints per level: 16n][FAST overflow: list length, 7 pad, 16 per-level
+    // counts] for the n frames of the current batch
     DevBuf dStat;
     int* errP() const { return (int*)dStat.p; }
     int* candCountP() const { return (int*)dStat.p + lastFrames; }
     int* kpCountP() const { return (int*)dStat.p + (size_t)(1 + ORB_MAX_LEVELS) * lastFrames; }
     int* ovfCountP() const { return (int*)dStat.p + (size_t)(1 + 2 * ORB_MAX_LEVELS) * lastFrames; }
-    static size_t statInts(int n) { return (size_t)(1 + 2 * ORB_MAX_LEVELS) * n + 4; }
+    static const int kOvfInts = 8 + ORB_MAX_LEVELS;
+    static size_t statInts(int n) { return (size_t)(1 + 2 * ORB_MAX_LEVELS) * n + kOvfInts; }
     DevBuf dImgs, dKps, dDesc, dCounts;         // staging for the host-buffer API
     DevBuf dStereo, dStereoIn;                  // stereo search: (SAD, index) pairs; host-API staging
     const int8_t* patternPtr = nullptr;         // device pointer in use (own copy or caller's)

@@ -351,7 +351,10 @@ __global__ __launch_bounds__(WAVE) void k_fast_strips(const OrbGeom G, const uin
     const int nCand = K.nCand;
     if (nCand == 0) return;
     if (nCand > candCap) {                                         // redone by k_fast_strips_dense
-        if (lane == 0) ovfList[atomicAdd(ovfCount, 1)] = (f << 16) | si;
+        if (lane == 0) {
+            ovfList[atomicAdd(ovfCount, 1)] = (f << 16) | si;
+            atomicAdd(&ovfCount[8 + S.level], 1);             // statistics for the host: which levels need shorter strips
+        }
         return;
     }
 

@@ -138,7 +138,11 @@ struct BowSide {
     int angleStride;
     const uint8_t* valid;     // or nullptr
     const uint16_t* nodeOf;   // vocabulary node per feature, NODE_NONE = not in the feature vector
-    int n;
+    int n;                    // -1: the pair is invalid (index outside the store, count outside [0, cap])
+    // the side's feature vector as CSR, built once per frame by k_build_csr (nullptr: built here, once per pair)
+    const uint32_t* csrKeys;  // [n] (node << 16 | index), grouped by node, ascending index inside a node
+    const uint16_t* csrStart; // [nNodes]
+    const uint16_t* csrCnt;   // [nNodes]
 };
 
 // One side's feature vector as CSR in LDS: keys[start[node] .. start[node] + cnt[node]) = (node << 16 | index) with
@@ -199,6 +203,41 @@ __device__ void build_csr(const uint16_t* __restrict__ nodeOf, int n, int nNodes
     __syncthreads();
 }
 
+// the CSR of one side in LDS: copied when the feature store holds it (one coalesced read), else built
+__device__ __forceinline__ void load_or_build_csr(const BowSide& S, int nNodes, uint32_t* keys, uint32_t* tmp, uint32_t* cntw,
+                                                  uint16_t* start, uint16_t* cnt)
+{
+    if (S.csrKeys) {
+        for (int i = threadIdx.x; i < S.n; i += blockDim.x) keys[i] = S.csrKeys[i];
+        for (int t = threadIdx.x; t < nNodes; t += blockDim.x) { start[t] = S.csrStart[t]; cnt[t] = S.csrCnt[t]; }
+        __syncthreads();
+    } else {
+        build_csr(S.nodeOf, S.n, nNodes, keys, tmp, cntw, start, cnt);
+    }
+}
+
+// one workgroup per frame of a feature store: its CSR, kept in HBM next to node_of
+__global__ __launch_bounds__(1024) void k_build_csr(const uint16_t* __restrict__ nodeOf, const int32_t* __restrict__ counts,
+                                                    int cap, int nNodes, uint32_t* __restrict__ keysOut,
+                                                    uint16_t* __restrict__ startOut, uint16_t* __restrict__ cntOut)
+{
+    extern __shared__ uint32_t csm[];
+    uint32_t* keys = csm;
+    uint32_t* tmp = keys + cap;
+    uint32_t* cntw = tmp + cap;
+    uint16_t* start = reinterpret_cast<uint16_t*>(cntw + nNodes);
+    uint16_t* cnt = start + nNodes;
+    const int f = blockIdx.x;
+    const int n = min(max(counts[f], 0), cap);
+    for (int i = threadIdx.x; i < cap; i += blockDim.x) keys[i] = 0xFFFFFFFFu;
+    build_csr(nodeOf + (size_t)f * cap, n, nNodes, keys, tmp, cntw, start, cnt);
+    for (int i = threadIdx.x; i < cap; i += blockDim.x) keysOut[(size_t)f * cap + i] = keys[i];
+    for (int t = threadIdx.x; t < nNodes; t += blockDim.x) {
+        startOut[(size_t)f * nNodes + t] = start[t];
+        cntOut[(size_t)f * nNodes + t] = cnt[t];
+    }
+}
+
 // KK == false: SearchByBoW(KeyFrame*, Frame&)   -> out[iB] = iA   (B = Frame, A = KeyFrame)
 // KK == true : SearchByBoW(KeyFrame*, KeyFrame*) -> out[iA] = iB  (A = KF1, B = KF2), B needs valid, strict <
 //
@@ -206,8 +245,9 @@ __device__ void build_csr(const uint16_t* __restrict__ nodeOf, int n, int nNodes
 // greedy rule), but nothing in it touches memory: each lane keeps ONE B descriptor and its "taken" flag
 // in registers, the A descriptors of the node are preloaded one per lane and broadcast with v_readlane,
 // best / second-best are two DPP min-reductions on packed (distance << 16 | position).
+// (two 16-wave workgroups per CU need 8 waves per SIMD: at most 64 VGPRs)
 template <bool KK>
-__global__ __launch_bounds__(1024) void k_match_bow(const BowSide* __restrict__ sidesA, const BowSide* __restrict__ sidesB,
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_match_bow(const BowSide* __restrict__ sidesA, const BowSide* __restrict__ sidesB,
                                                     int nNodes, int capLds, float ratio, int checkOri,
                                                     int32_t* __restrict__ match, int matchStride,
                                                     int32_t* __restrict__ nmatchesOut)
@@ -233,13 +273,18 @@ __global__ __launch_bounds__(1024) void k_match_bow(const BowSide* __restrict__ 
 
     const BowSide A = sidesA[blockIdx.x], B = sidesB[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63;
+    if (A.n < 0 || B.n < 0 || A.n > capLds || B.n > capLds) {      // invalid pair (k_fill_sides): reported, never run
+        for (int i = tid; i < matchStride; i += blockDim.x) match[(size_t)blockIdx.x * matchStride + i] = -1;
+        if (tid == 0) nmatchesOut[blockIdx.x] = -1;
+        return;
+    }
     const int nRes = KK ? A.n : B.n;
     for (int i = tid; i < nRes; i += blockDim.x) { res[i] = -1; bin[i] = 0xFF; }
     for (int i = tid; i < B.n; i += blockDim.x) takenB[i] = (KK && B.valid && !B.valid[i]) ? 1 : 0;   // :750
     if (tid < HISTO_LENGTH) hist[tid] = 0;
     if (tid == 0) { nm = 0; nextNode = 0; }
-    build_csr(A.nodeOf, A.n, nNodes, keysA, tmp, cntw, startA, cntA);
-    build_csr(B.nodeOf, B.n, nNodes, keysB, tmp, cntw, startB, cntB);
+    load_or_build_csr(A, nNodes, keysA, tmp, cntw, startA, cntA);
+    load_or_build_csr(B, nNodes, keysB, tmp, cntw, startB, cntB);
 
     // nodes differ a lot in size: waves take the next node from a shared counter instead of a fixed stride
     // (a fixed stride left the slowest wave 2.6x behind the fastest)
@@ -265,49 +310,63 @@ __global__ __launch_bounds__(1024) void k_match_bow(const BowSide* __restrict__ 
                 load_desc(B.desc + (size_t)jB * 32, dB);
                 taken = takenB[jB] != 0;
             }
-            for (int abase = 0; abase < na; abase += 4) {
-                const int p = abase + rowI;
-                uint32_t dA[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                int iA = -1;
-                bool okA = false;
-                if (p < na) {
-                    iA = (int)(keysA[a0 + p] & 0xFFFFu);
-                    okA = !(A.valid && !A.valid[iA]);              // :590-595
-                    if (okA) load_desc(A.desc + (size_t)iA * 32, dA);
+            // A features are taken 16 at a time: row r of group g holds A feature abase + 4 g + r, and the descriptors of
+            // all four groups are requested before any is used -- the loop used to pay one global round trip per group
+            for (int abase = 0; abase < na; abase += 16) {
+                uint32_t dA[4][8];
+                int iAg[4];
+                bool okAg[4];
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int p = abase + 4 * g + rowI;
+#pragma unroll
+                    for (int w = 0; w < 8; w++) dA[g][w] = 0;
+                    iAg[g] = -1;
+                    okAg[g] = false;
+                    if (p < na) {
+                        iAg[g] = (int)(keysA[a0 + p] & 0xFFFFu);
+                        okAg[g] = !(A.valid && !A.valid[iAg[g]]);      // :590-595
+                        if (okAg[g]) load_desc(A.desc + (size_t)iAg[g] * 32, dA[g]);
+                    }
                 }
-                unsigned d = 0;
 #pragma unroll
-                for (int w = 0; w < 8; w++) d += __popc(dB[w] ^ dA[w]);
-                const unsigned long long okMask = __ballot(okA);
+                for (int g = 0; g < 4; g++) {
+                    if (abase + 4 * g >= na) continue;
+                    const int iA = iAg[g];
+                    unsigned d = 0;
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    if (abase + r >= na) break;
-                    if (!((okMask >> (16 * r)) & 1)) continue;
-                    const unsigned mine = ((taken ? 256u : d) << 16) | (unsigned)col;
-                    unsigned v1 = mine;
-                    ORB_DPP_STEP_UMIN(v1, 0x111, 0xf);
-                    ORB_DPP_STEP_UMIN(v1, 0x112, 0xf);
-                    ORB_DPP_STEP_UMIN(v1, 0x114, 0xf);
-                    ORB_DPP_STEP_UMIN(v1, 0x118, 0xf);
-                    const unsigned m1 = (unsigned)__builtin_amdgcn_readlane((int)v1, 16 * r + 15);
-                    unsigned v2 = mine == m1 ? 0xFFFFFFFFu : mine;
-                    ORB_DPP_STEP_UMIN(v2, 0x111, 0xf);
-                    ORB_DPP_STEP_UMIN(v2, 0x112, 0xf);
-                    ORB_DPP_STEP_UMIN(v2, 0x114, 0xf);
-                    ORB_DPP_STEP_UMIN(v2, 0x118, 0xf);
-                    const unsigned m2 = (unsigned)__builtin_amdgcn_readlane((int)v2, 16 * r + 15);
-                    const int best1 = (int)(m1 >> 16), best2 = (int)(m2 >> 16);      // 256 when nothing is left
-                    const bool pass = KK ? (best1 < TH_LOW) : (best1 <= TH_LOW);      // :772 vs :625
-                    if (pass && (float)best1 < __fmul_rn(ratio, (float)best2)) {
-                        const int win = (int)(m1 & 0xFFFFu);
-                        if (col == win) {
-                            taken = true;                          // in every row: the column is gone
-                            if (rowI == r) {
-                                takenB[jB] = 1;
-                                const int rIdx = KK ? iA : jB;
-                                res[rIdx] = (int16_t)(KK ? jB : iA);
-                                if (checkOri)
-                                    bin[rIdx] = (uint8_t)rot_bin(A.angle[(size_t)iA * A.angleStride], B.angle[(size_t)jB * B.angleStride]);
+                    for (int w = 0; w < 8; w++) d += __popc(dB[w] ^ dA[g][w]);
+                    const unsigned long long okMask = __ballot(okAg[g]);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        if (abase + 4 * g + r >= na) continue;
+                        if (!((okMask >> (16 * r)) & 1)) continue;
+                        const unsigned mine = ((taken ? 256u : d) << 16) | (unsigned)col;
+                        unsigned v1 = mine;
+                        ORB_DPP_STEP_UMIN(v1, 0x111, 0xf);
+                        ORB_DPP_STEP_UMIN(v1, 0x112, 0xf);
+                        ORB_DPP_STEP_UMIN(v1, 0x114, 0xf);
+                        ORB_DPP_STEP_UMIN(v1, 0x118, 0xf);
+                        const unsigned m1 = (unsigned)__builtin_amdgcn_readlane((int)v1, 16 * r + 15);
+                        unsigned v2 = mine == m1 ? 0xFFFFFFFFu : mine;
+                        ORB_DPP_STEP_UMIN(v2, 0x111, 0xf);
+                        ORB_DPP_STEP_UMIN(v2, 0x112, 0xf);
+                        ORB_DPP_STEP_UMIN(v2, 0x114, 0xf);
+                        ORB_DPP_STEP_UMIN(v2, 0x118, 0xf);
+                        const unsigned m2 = (unsigned)__builtin_amdgcn_readlane((int)v2, 16 * r + 15);
+                        const int best1 = (int)(m1 >> 16), best2 = (int)(m2 >> 16);      // 256 when nothing is left
+                        const bool pass = KK ? (best1 < TH_LOW) : (best1 <= TH_LOW);      // :772 vs :625
+                        if (pass && (float)best1 < __fmul_rn(ratio, (float)best2)) {
+                            const int win = (int)(m1 & 0xFFFFu);
+                            if (col == win) {
+                                taken = true;                          // in every row: the column is gone
+                                if (rowI == r) {
+                                    takenB[jB] = 1;
+                                    const int rIdx = KK ? iA : jB;
+                                    res[rIdx] = (int16_t)(KK ? jB : iA);
+                                    if (checkOri)
+                                        bin[rIdx] = (uint8_t)rot_bin(A.angle[(size_t)iA * A.angleStride], B.angle[(size_t)jB * B.angleStride]);
+                                }
                             }
                         }
                     }
@@ -437,21 +496,27 @@ __global__ __launch_bounds__(1024) void k_match_bow(const BowSide* __restrict__ 
 
 // fills the BowSide descriptors of a batch of pairs from a feature store (device side, no host sync)
 __global__ void k_fill_sides(orb_featstore S, const int32_t* __restrict__ kfIndex, const int32_t* __restrict__ fIndex,
-                             int nPairs, BowSide* __restrict__ sidesA, BowSide* __restrict__ sidesB)
+                             int nPairs, int nNodes, BowSide* __restrict__ sidesA, BowSide* __restrict__ sidesB)
 {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= nPairs) return;
     const int32_t idx[2] = {kfIndex[p], fIndex[p]};
     BowSide* outs[2] = {sidesA + p, sidesB + p};
     for (int s = 0; s < 2; s++) {
-        const size_t row = (size_t)idx[s] * S.cap;
         BowSide b;
+        const bool inStore = idx[s] >= 0 && idx[s] < S.n_frames;
+        const size_t row = inStore ? (size_t)idx[s] * S.cap : 0;
         b.desc = S.desc + row * 32;
         b.angle = &S.kps[row].angle;
         b.angleStride = sizeof(orb_keypoint) / sizeof(float);
         b.valid = (s == 0 && S.valid) ? S.valid + row : nullptr;
         b.nodeOf = S.node_of + row;
-        b.n = S.counts[idx[s]];
+        const int n = inStore ? S.counts[idx[s]] : -1;
+        b.n = (n >= 0 && n <= S.cap) ? n : -1;             // an index or count outside the store: the pair reports nmatches = -1
+        b.csrKeys = S.csr_keys ? S.csr_keys + row : nullptr;
+        b.csrStart = (S.csr_keys && inStore) ? S.csr_start + (size_t)idx[s] * nNodes : nullptr;
+        b.csrCnt = (S.csr_keys && inStore) ? S.csr_cnt + (size_t)idx[s] * nNodes : nullptr;
+        if (!S.csr_start || !S.csr_cnt) b.csrKeys = nullptr;
         *outs[s] = b;
     }
 }
@@ -556,11 +621,26 @@ extern "C" int orb_match_bow_batch_device(orb_matcher* m, const orb_featstore* s
     int rc;
     if ((rc = m->sidesA.ensure(sizeof(BowSide) * (size_t)nPairs)) != ORB_OK) return rc;
     if ((rc = m->sidesB.ensure(sizeof(BowSide) * (size_t)nPairs)) != ORB_OK) return rc;
-    hipLaunchKernelGGL(k_fill_sides, dim3((nPairs + 255) / 256), dim3(256), 0, m->stream, *store, d_kf, d_f, nPairs,
-                       (BowSide*)m->sidesA.p, (BowSide*)m->sidesB.p);
     const int nNodes = store->n_nodes > 0 ? store->n_nodes : 128;
+    hipLaunchKernelGGL(k_fill_sides, dim3((nPairs + 255) / 256), dim3(256), 0, m->stream, *store, d_kf, d_f, nPairs, nNodes,
+                       (BowSide*)m->sidesA.p, (BowSide*)m->sidesB.p);
     return launch_match(m, false, (const BowSide*)m->sidesA.p, (const BowSide*)m->sidesB.p, nPairs, nNodes, store->cap,
                         ratio, checkOri, d_match, store->cap, d_nm);
+}
+
+extern "C" int orb_bow_build_csr_device(orb_matcher* m, const uint16_t* d_node_of, const int32_t* d_counts, int nFrames, int cap,
+                                        int nNodes, uint32_t* d_keys, uint16_t* d_start, uint16_t* d_cnt)
+{
+    if (!m || !d_node_of || !d_counts || !d_keys || !d_start || !d_cnt || nFrames < 0 || nNodes <= 0) return ORB_ERR_INVALID;
+    if (nFrames == 0) return ORB_OK;
+    if (cap <= 0 || cap > 4096) { orb_set_error("featstore cap must be 1..4096"); return ORB_ERR_UNSUPPORTED; }
+    const size_t lds = (size_t)cap * 8 + (size_t)nNodes * 8;
+    if (lds > 64 * 1024) { orb_set_error("feature capacity %d x %d nodes exceeds the CSR kernel's LDS budget", cap, nNodes); return ORB_ERR_UNSUPPORTED; }
+    ORB_HIP_TRY(hipSetDevice(m->device));
+    hipLaunchKernelGGL(k_build_csr, dim3(nFrames), dim3(1024), lds, m->stream, d_node_of, d_counts, cap, nNodes, d_keys, d_start,
+                       d_cnt);
+    ORB_HIP_TRY(hipGetLastError());
+    return ORB_OK;
 }
 
 // CSR feature vectors of both sides -> per-feature compact node index over the COMMON node ids
@@ -627,9 +707,9 @@ static int match_host(orb_matcher* m, bool kk,
         if (src[i]) ORB_HIP_TRY(hipMemcpyAsync(m->stage[i].p, src[i], sz[i], hipMemcpyHostToDevice, st));
     BowSide sides[2];
     sides[0] = {(const uint8_t*)m->stage[0].p, (const float*)m->stage[1].p, 1,
-                validA ? (const uint8_t*)m->stage[2].p : nullptr, (const uint16_t*)m->stage[3].p, nA};
+                validA ? (const uint8_t*)m->stage[2].p : nullptr, (const uint16_t*)m->stage[3].p, nA, nullptr, nullptr, nullptr};
     sides[1] = {(const uint8_t*)m->stage[4].p, (const float*)m->stage[5].p, 1,
-                validB ? (const uint8_t*)m->stage[6].p : nullptr, (const uint16_t*)m->stage[7].p, nB};
+                validB ? (const uint8_t*)m->stage[6].p : nullptr, (const uint16_t*)m->stage[7].p, nB, nullptr, nullptr, nullptr};
     ORB_HIP_TRY(hipMemcpyAsync(m->stage[8].p, sides, sizeof(sides), hipMemcpyHostToDevice, st));
     int32_t* dOut = (int32_t*)m->stage[9].p;
     const int capLds = std::max(nA, nB);

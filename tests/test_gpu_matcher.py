@@ -213,6 +213,27 @@ def test_c5_style_stream_vs_keyframe_db_device_batch():
     best = np.array(best).reshape(nq, nkf)
     assert np.all(best.argmax(axis=1) == np.arange(nq))          # each query recognises its own keyframe
 
+    # the same batch with the per-frame feature vectors precomputed in the store (orb_bow_build_csr_device), plus two
+    # invalid pairs (frame index outside the store / negative): reported as nmatches = -1, never run
+    nn = 128
+    d_ck = torch.zeros(F * cap, dtype=torch.int32, device=dev)
+    d_cs = torch.zeros(F * nn, dtype=torch.int16, device=dev)
+    d_cc = torch.zeros(F * nn, dtype=torch.int16, device=dev)
+    mt.build_csr_device(d_node.data_ptr(), d_counts.data_ptr(), F, cap, nn, d_ck.data_ptr(), d_cs.data_ptr(), d_cc.data_ptr())
+    store2 = dict(store, n_nodes=nn, csr_keys=d_ck.data_ptr(), csr_start=d_cs.data_ptr(), csr_cnt=d_cc.data_ptr())
+    kf2 = torch.cat([kf_idx, torch.tensor([F + 3, 0], dtype=torch.int32, device=dev)])
+    f2 = torch.cat([f_idx, torch.tensor([0, -1], dtype=torch.int32, device=dev)])
+    d_match2 = torch.full(((len(pairs) + 2) * cap,), 7, dtype=torch.int32, device=dev)
+    d_nm2 = torch.zeros(len(pairs) + 2, dtype=torch.int32, device=dev)
+    mt.match_bow_batch_device(store2, kf2.data_ptr(), f2.data_ptr(), len(pairs) + 2, d_match2.data_ptr(), d_nm2.data_ptr())
+    mt.sync(); torch.cuda.synchronize()
+    nm2 = d_nm2.cpu().numpy()
+    match2 = d_match2.cpu().numpy().reshape(len(pairs) + 2, cap)
+    assert np.array_equal(nm2[:len(pairs)], nm) and nm2[-2] == -1 and nm2[-1] == -1
+    for p, (a, b) in enumerate(pairs):
+        assert np.array_equal(match2[p, :counts[b]], match[p, :counts[b]])
+    assert np.all(match2[-2:] == -1)
+
 
 def _proj_scene(feats, a, b, mode, level_mode, seed):
     """Queries = features of frame a 'projected' near their true position in frame b (same scene, fresh noise)."""
