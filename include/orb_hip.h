@@ -345,6 +345,20 @@ int orb_stereo_match_device(orb_extractor* left, orb_extractor* right, int frame
                             const orb_keypoint* d_kps_r, const uint8_t* d_desc_r, int n_r,
                             float mb, float mbf, float* d_u_right, float* d_depth);
 
+/* The whole pyramid of device-resident frame `frame` of the last batch with ONE device-to-host copy and one
+ * synchronisation (the reference keeps it in the public member mvImagePyramid, include/ORBextractor.h:86, read by
+ * Frame::ComputeStereoMatches, src/Frame.cc:520,611,626,633).  Level l of the copy starts at dst + offsets[l], has
+ * rows[l] x cols[l] pixels and a row pitch of pitches[l] bytes (interiors only, no 19-px border).  Call with
+ * dst = NULL to learn the byte size needed (*bytes) and the level layout.  dst may be pageable or pinned
+ * (orb_host_alloc). */
+int orb_get_pyramid(orb_extractor* h, int frame, uint8_t* dst, size_t dst_bytes, size_t* bytes, int32_t* offsets,
+                    int32_t* pitches, int32_t* rows, int32_t* cols);
+
+/* Pinned (page-locked) host memory for callers that keep staging buffers across calls (the C++ shims): copies to
+ * and from it are asynchronous and run at full PCIe rate, and orb_extract_batch skips its own staging for it. */
+void* orb_host_alloc(size_t bytes);
+void orb_host_free(void* p);
+
 /* ---------------------------------------------------------------- misc ---------------------*/
 const char* orb_last_error(void);   /* thread-local description of the last failure */
 const char* orb_version(void);

@@ -87,6 +87,14 @@ static_assert(sizeof(OrbStrip) == 48, "OrbStrip is loaded as one scalar record")
 // fetched up to 8 times.  Grid size: perFrame * 8 * ceil(nFrames / 8); invPerFrame = ceil(2^32 / perFrame),
 // exact while (id >> 3) * perFrame < 2^32 (checked by orb_xcd_grid on the host).
 #ifdef __HIPCC__
+// Device-side failure of frame f (1 candidate slab, 2 quadtree nodes, 4 output capacity): the per-batch word that the
+// next batch's memset clears, and the handle's STICKY word in front of the status block (errFlags[-1]), which only
+// orb_extractor_sync() clears -- batches issued back to back without a sync in between cannot lose a flag.
+__device__ __forceinline__ void orb_flag_error(int* errFlags, int f, int bits)
+{
+    atomicOr(&errFlags[f], bits);
+    atomicOr(&errFlags[-1], bits);
+}
 __device__ __forceinline__ bool orb_xcd_decode(unsigned id, unsigned perFrame, unsigned invPerFrame, int nFrames,
                                                int& frame, int& item)
 {

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
         for (int l = 0; l < G.nlevels; l++) tot += cnt[l];
         if (lane == 0) {
             countsOut[f] = min(tot, cap);
-            if (tot > cap) atomicOr(&errFlags[f], 4);
+            if (tot > cap) orb_flag_error(errFlags, f, 4);
         }
     }
     if (k >= cnt[level] || off + k >= cap) return;

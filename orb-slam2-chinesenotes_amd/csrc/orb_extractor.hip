@@ -389,6 +389,7 @@ static int build_geometry(orb_extractor* h, int rows, int cols)
     h->rows = rows;
     h->cols = cols;
     h->geomDirty = false;
+    h->geomVersion++;
     return ORB_OK;
 }
 
@@ -400,7 +401,11 @@ static int ensure_scratch(orb_extractor* h, int nFrames)
     if ((rc = h->dCand.ensure(h->candSlab * 8 * nFrames)) != ORB_OK) return rc;
     if ((rc = h->dKpl.ensure((size_t)h->G.kpSlab * 4 * nFrames)) != ORB_OK) return rc;
     if ((rc = h->dOvf.ensure((size_t)4 * std::max<size_t>(1, h->strips.size()) * nFrames)) != ORB_OK) return rc;
-    if ((rc = h->dStat.ensure(orb_extractor::statInts(nFrames) * 4)) != ORB_OK) return rc;
+    {
+        const void* before = h->dStat.p;
+        if ((rc = h->dStat.ensure(orb_extractor::statInts(nFrames) * 4)) != ORB_OK) return rc;
+        if (h->dStat.p != before) ORB_HIP_TRY(hipMemsetAsync(h->dStat.p, 0, orb_extractor::kStickyInts * 4, h->stream));   // new block: sticky word starts clear
+    }
     h->framesCap = nFrames;
     return ORB_OK;
 }
@@ -482,6 +487,9 @@ extern "C" void orb_extractor_destroy(orb_extractor* h)
         for (int i = 0; i < 5; i++)
             if (h->ev[k][i]) (void)hipEventDestroy(h->ev[k][i]);
     if (h->waitEv) (void)hipEventDestroy(h->waitEv);
+    orb_pipe_release(h);
+    if (h->graph1.exec) (void)hipGraphExecDestroy(h->graph1.exec);
+    if (h->graph1.graph) (void)hipGraphDestroy(h->graph1.graph);
     if (h->hStage) (void)hipHostFree(h->hStage);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -599,6 +607,7 @@ extern "C" int orb_extract_batch_device(orb_extractor* h, const uint8_t* d_imgs,
     // (Cutting a large batch into sub-batches on several streams was measured: no gain, every kernel already fills
     // the chip -- one stream, one launch chain.)
     h->lastFrames = nFrames;                                   // fixes the layout of the status block
+    h->frameBase = 0;
     h->statFetched = false;
     const int n = nFrames;
     int* scc = h->candCountP();
@@ -608,7 +617,7 @@ extern "C" int orb_extract_batch_device(orb_extractor* h, const uint8_t* d_imgs,
     uint32_t* skpl = (uint32_t*)h->dKpl.p;
     const bool prof = h->profiling;
     hipEvent_t* pe = h->ev[h->profCount % orb_extractor::kProfSlots];
-    ORB_HIP_TRY(hipMemsetAsync(h->dStat.p, 0, orb_extractor::statInts(n) * 4, st));
+    ORB_HIP_TRY(hipMemsetAsync(h->errP(), 0, orb_extractor::batchInts(n) * 4, st));
     if (prof) ORB_HIP_TRY(hipEventRecord(pe[0], st));
     orb_launch_copy_level0(st, d_imgs, rowStride, frameStride, pyr, h->pyrSlab, G.L[0].w, G.L[0].h, G.L[0].pitch, n);
     {
@@ -645,10 +654,11 @@ extern "C" int orb_extract_batch_device(orb_extractor* h, const uint8_t* d_imgs,
 }
 
 // host-side part of a sync: interpret the status block (already in h->hStat)
-static int check_status(orb_extractor* h)
+int orb_check_status(orb_extractor* h)
 {
     const int n = h->lastFrames;
-    const int* err = h->hStat.data();
+    const int sticky = h->hStat[orb_extractor::kStickyInts - 1];
+    const int* err = h->hStat.data() + orb_extractor::kStickyInts;
     const int* cand = err + n;
     {                                                  // adapt the quadtree's LDS sort capacity to the data
         int mx = 0;
@@ -673,6 +683,10 @@ static int check_status(orb_extractor* h)
             orb_set_error("device-side overflow flag 0x%x on frame %d (1 candidates, 2 nodes, 4 output cap)", err[f], f);
             return (err[f] & 4) ? ORB_ERR_CAPACITY : ORB_ERR_INTERNAL;
         }
+    if (sticky) {                                      // raised by an earlier batch that was never synchronised
+        orb_set_error("device-side overflow flag 0x%x in an earlier, unsynchronised batch (1 candidates, 2 nodes, 4 output cap)", sticky);
+        return (sticky & 4) ? ORB_ERR_CAPACITY : ORB_ERR_INTERNAL;
+    }
     return ORB_OK;
 }
 
@@ -685,7 +699,8 @@ extern "C" int orb_extractor_sync(orb_extractor* h)
         h->hStat.resize(orb_extractor::statInts(h->lastFrames));
         ORB_HIP_TRY(hipMemcpy(h->hStat.data(), h->dStat.p, h->hStat.size() * 4, hipMemcpyDeviceToHost));
         h->statFetched = true;
-        return check_status(h);
+        if (h->hStat[orb_extractor::kStickyInts - 1]) ORB_HIP_TRY(hipMemset(h->dStat.p, 0, orb_extractor::kStickyInts * 4));
+        return orb_check_status(h);
     }
     return ORB_OK;
 }
@@ -716,6 +731,9 @@ extern "C" int orb_extract_batch(orb_extractor* h, const uint8_t* imgs, int nFra
     }
     if (!kps || !desc || cap <= 0) return ORB_ERR_INVALID;
     ORB_HIP_TRY(hipSetDevice(h->device));
+    if (nFrames >= 2 * ORB_PIPE_CHUNK_MIN)                       // large batch: H2D(k+1) | kernels(k) | D2H(k-1)
+        return orb_extract_batch_pipelined(h, imgs, nFrames, rows, cols, rowStride, frameStride, kps, desc, cap, counts);
+    h->frameBase = 0;
     int rc;
     const size_t imgBytes = (size_t)rows * cols;
     if ((rc = h->dImgs.ensure(imgBytes * nFrames)) != ORB_OK) return rc;
@@ -735,30 +753,74 @@ extern "C" int orb_extract_batch(orb_extractor* h, const uint8_t* imgs, int nFra
                                              cols, rows, hipMemcpyHostToDevice, h->stream));
         }
     }
-    rc = orb_extract_batch_device(h, (const uint8_t*)h->dImgs.p, nFrames, rows, cols, cols, imgBytes,
-                                  (orb_keypoint*)h->dKps.p, (uint8_t*)h->dDesc.p, cap, (int32_t*)h->dCounts.p);
-    if (rc != ORB_OK) return rc;
-    if (h->lastFrames == 0) {                                  // nothing was launched
-        for (int f = 0; f < nFrames; f++) counts[f] = 0;
-        return ORB_OK;
-    }
     const size_t kStageLimit = (size_t)96 << 20;
     const size_t statB = orb_extractor::statInts(nFrames) * 4, cntB = (size_t)4 * nFrames;
     const size_t kpB = sizeof(orb_keypoint) * (size_t)cap * nFrames, dsB = (size_t)ORB_DESC_BYTES * cap * nFrames;
     const bool whole = statB + cntB + kpB + dsB <= kStageLimit;
     if ((rc = ensure_stage(h, whole ? statB + cntB + kpB + dsB : statB + cntB)) != ORB_OK) return rc;
     uint8_t* stg = (uint8_t*)h->hStage;
-    ORB_HIP_TRY(hipMemcpyAsync(stg, h->dStat.p, statB, hipMemcpyDeviceToHost, h->stream));
-    ORB_HIP_TRY(hipMemcpyAsync(stg + statB, h->dCounts.p, cntB, hipMemcpyDeviceToHost, h->stream));
-    if (whole) {
-        ORB_HIP_TRY(hipMemcpyAsync(stg + statB + cntB, h->dKps.p, kpB, hipMemcpyDeviceToHost, h->stream));
-        ORB_HIP_TRY(hipMemcpyAsync(stg + statB + cntB + kpB, h->dDesc.p, dsB, hipMemcpyDeviceToHost, h->stream));
+    // the chain and the copies back; issued eagerly, or (single frames, the reference's per-call path) as one graph
+    auto chain = [&]() -> int {
+        int r = orb_extract_batch_device(h, (const uint8_t*)h->dImgs.p, nFrames, rows, cols, cols, imgBytes,
+                                         (orb_keypoint*)h->dKps.p, (uint8_t*)h->dDesc.p, cap, (int32_t*)h->dCounts.p);
+        if (r != ORB_OK) return r;
+        ORB_HIP_TRY(hipMemcpyAsync(stg, h->dStat.p, statB, hipMemcpyDeviceToHost, h->stream));
+        ORB_HIP_TRY(hipMemcpyAsync(stg + statB, h->dCounts.p, cntB, hipMemcpyDeviceToHost, h->stream));
+        if (whole) {
+            ORB_HIP_TRY(hipMemcpyAsync(stg + statB + cntB, h->dKps.p, kpB, hipMemcpyDeviceToHost, h->stream));
+            ORB_HIP_TRY(hipMemcpyAsync(stg + statB + cntB + kpB, h->dDesc.p, dsB, hipMemcpyDeviceToHost, h->stream));
+        }
+        return ORB_OK;
+    };
+    orb_extractor::Graph& Gr = h->graph1;
+    const bool graphable = nFrames == 1 && whole && !h->profiling && !Gr.broken && !std::getenv("ORB_NO_GRAPH");
+    const bool sameKey = graphable && Gr.rows == rows && Gr.cols == cols && Gr.cap == cap && Gr.sortCap == h->sortCap &&
+                         Gr.geomVersion == h->geomVersion && Gr.pattern == (const void*)h->patternPtr && Gr.stage == h->hStage &&
+                         rows == h->rows && cols == h->cols && !h->geomDirty;
+    bool launched = false;
+    if (sameKey && !Gr.exec) {
+        // an eager call with this key has been through: everything is allocated and built, so the same calls can be
+        // captured (capturing does not execute them)
+        if (Gr.graph) { (void)hipGraphDestroy(Gr.graph); Gr.graph = nullptr; }
+        ORB_HIP_TRY(hipStreamSynchronize(h->stream));
+        bool ok = hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        if (ok) {
+            const int r = chain();
+            hipGraph_t g = nullptr;
+            const hipError_t e = hipStreamEndCapture(h->stream, &g);
+            ok = r == ORB_OK && e == hipSuccess && g != nullptr;
+            if (ok) { Gr.graph = g; ok = hipGraphInstantiate(&Gr.exec, g, nullptr, nullptr, 0) == hipSuccess; }
+            else if (g) (void)hipGraphDestroy(g);
+        }
+        if (!ok) {                                             // stay eager for the rest of the handle's life
+            (void)hipGetLastError();
+            Gr.broken = true;
+            Gr.exec = nullptr;
+        }
+    }
+    if (sameKey && Gr.exec) {
+        h->lastFrames = 1; h->frameBase = 0; h->statFetched = false;
+        if (hipGraphLaunch(Gr.exec, h->stream) == hipSuccess) launched = true;
+        else { (void)hipGetLastError(); Gr.broken = true; }
+    }
+    if (!launched) {
+        if ((rc = chain()) != ORB_OK) return rc;
+        if (graphable && !Gr.broken && !sameKey && h->lastFrames == 1) {     // remember the key: the next call captures
+            Gr.rows = rows; Gr.cols = cols; Gr.cap = cap; Gr.sortCap = h->sortCap; Gr.geomVersion = h->geomVersion;
+            Gr.pattern = (const void*)h->patternPtr; Gr.stage = h->hStage;
+            if (Gr.exec) { (void)hipGraphExecDestroy(Gr.exec); Gr.exec = nullptr; }
+        }
+    }
+    if (h->lastFrames == 0) {                                  // nothing was launched
+        for (int f = 0; f < nFrames; f++) counts[f] = 0;
+        return ORB_OK;
     }
     ORB_HIP_TRY(hipStreamSynchronize(h->stream));
     h->hStat.assign((const int*)stg, (const int*)stg + orb_extractor::statInts(nFrames));
     h->statFetched = true;
+    if (h->hStat[orb_extractor::kStickyInts - 1]) ORB_HIP_TRY(hipMemset(h->dStat.p, 0, orb_extractor::kStickyInts * 4));
     std::memcpy(counts, stg + statB, cntB);
-    if ((rc = check_status(h)) != ORB_OK) return rc;
+    if ((rc = orb_check_status(h)) != ORB_OK) return rc;
     for (int f = 0; f < nFrames; f++) {
         const int n = counts[f];
         if (n <= 0) continue;
@@ -796,12 +858,52 @@ extern "C" int orb_get_pyramid_level(orb_extractor* h, int frame, int level, uin
     if (rows) *rows = L.h;
     if (cols) *cols = L.w;
     if (!dst) return ORB_OK;
-    if (frame < 0 || frame >= h->lastFrames || dstStride < (size_t)L.w) return ORB_ERR_INVALID;
+    frame -= h->frameBase;                                     // a pipelined host batch keeps its last chunk on the device
+    if (frame < 0 || frame >= h->lastFrames || dstStride < (size_t)L.w) {
+        orb_set_error("frame not resident (device-resident frames of the last batch: %d..%d)", h->frameBase, h->frameBase + h->lastFrames - 1);
+        return ORB_ERR_INVALID;
+    }
     ORB_HIP_TRY(hipSetDevice(h->device));
     ORB_HIP_TRY(hipMemcpy2DAsync(dst, dstStride, (const uint8_t*)h->dPyr.p + h->pyrSlab * frame + L.pyrOff, L.pitch,
                                  L.w, L.h, hipMemcpyDeviceToHost, h->stream));
     ORB_HIP_TRY(hipStreamSynchronize(h->stream));
     return ORB_OK;
+}
+
+extern "C" int orb_get_pyramid(orb_extractor* h, int frame, uint8_t* dst, size_t dstBytes, size_t* bytes, int32_t* offsets,
+                               int32_t* pitches, int32_t* rows, int32_t* cols)
+{
+    if (!h || h->rows == 0) return ORB_ERR_INVALID;
+    for (int l = 0; l < h->prm.nlevels; l++) {
+        const OrbLevelGeom& L = h->G.L[l];
+        if (offsets) offsets[l] = L.pyrOff;
+        if (pitches) pitches[l] = L.pitch;
+        if (rows) rows[l] = L.h;
+        if (cols) cols[l] = L.w;
+    }
+    if (bytes) *bytes = h->pyrSlab;
+    if (!dst) return ORB_OK;
+    frame -= h->frameBase;
+    if (frame < 0 || frame >= h->lastFrames || dstBytes < h->pyrSlab) {
+        orb_set_error("orb_get_pyramid: frame not resident or buffer smaller than %zu bytes", h->pyrSlab);
+        return ORB_ERR_INVALID;
+    }
+    ORB_HIP_TRY(hipSetDevice(h->device));
+    ORB_HIP_TRY(hipMemcpyAsync(dst, (const uint8_t*)h->dPyr.p + h->pyrSlab * frame, h->pyrSlab, hipMemcpyDeviceToHost, h->stream));
+    ORB_HIP_TRY(hipStreamSynchronize(h->stream));
+    return ORB_OK;
+}
+
+extern "C" void* orb_host_alloc(size_t bytes)
+{
+    void* p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+
+extern "C" void orb_host_free(void* p)
+{
+    if (p) (void)hipHostFree(p);
 }
 
 extern "C" int orb_get_level_counts(orb_extractor* h, int frame, int32_t* kept, int32_t* cands)

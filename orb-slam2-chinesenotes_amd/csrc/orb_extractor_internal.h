@@ -4,6 +4,8 @@
 
 #include "orb_kernels.h"
 
+#define ORB_PIPE_CHUNK_MIN 8       // host batches of >= 2 chunks of this size are pipelined
+
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
@@ -63,12 +65,16 @@ struct orb_extractor {
     // [err: n][FAST candidates per level: 16n][keypoints per level: 16n][FAST overflow: list length, 7 pad, 16 per-level
     // counts] for the n frames of the current batch
     DevBuf dStat;
-    int* errP() const { return (int*)dStat.p; }
-    int* candCountP() const { return (int*)dStat.p + lastFrames; }
-    int* kpCountP() const { return (int*)dStat.p + (size_t)(1 + ORB_MAX_LEVELS) * lastFrames; }
-    int* ovfCountP() const { return (int*)dStat.p + (size_t)(1 + 2 * ORB_MAX_LEVELS) * lastFrames; }
+    // In front of the block: kStickyInts ints that no batch clears; the last of them (errP()[-1]) = OR of every error
+    // flag since the last sync.
+    static const int kStickyInts = 4;
+    int* errP() const { return (int*)dStat.p + kStickyInts; }
+    int* candCountP() const { return errP() + lastFrames; }
+    int* kpCountP() const { return errP() + (size_t)(1 + ORB_MAX_LEVELS) * lastFrames; }
+    int* ovfCountP() const { return errP() + (size_t)(1 + 2 * ORB_MAX_LEVELS) * lastFrames; }
     static const int kOvfInts = 8 + ORB_MAX_LEVELS;
-    static size_t statInts(int n) { return (size_t)(1 + 2 * ORB_MAX_LEVELS) * n + kOvfInts; }
+    static size_t batchInts(int n) { return (size_t)(1 + 2 * ORB_MAX_LEVELS) * n + kOvfInts; }     // what a batch clears
+    static size_t statInts(int n) { return kStickyInts + batchInts(n); }
     DevBuf dImgs, dKps, dDesc, dCounts;         // staging for the host-buffer API
     DevBuf dStereo, dStereoIn;                  // stereo search: (SAD, index) pairs; host-API staging
     const int8_t* patternPtr = nullptr;         // device pointer in use (own copy or caller's)
@@ -77,5 +83,36 @@ struct orb_extractor {
     bool statFetched = false;
     void* hStage = nullptr;                     // pinned staging of the host-buffer API
     size_t hStageBytes = 0;
+    // single-frame host calls (the reference's operator() path): the launch chain + the copies back, captured once as a
+    // HIP graph and replayed -- one launch instead of ~17 API calls.  Re-captured when anything it baked in changes.
+    struct Graph {
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        int rows = 0, cols = 0, cap = 0, sortCap = 0, geomVersion = -1;
+        const void* pattern = nullptr;
+        const void* stage = nullptr;
+        int seenSame = 0;                       // eager calls with the current key (capture after the first)
+        bool broken = false;                    // a graph API call failed once: stay eager
+    } graph1;
+    int geomVersion = 0;                        // bumped by every geometry build
+
+    int frameBase = 0;                          // batch index of the device-resident frame 0 (pipelined host batches keep
+                                                // only their last chunk on the device)
+
+    // pipelined host batches (orb_host_pipe.hip): two slots of device in/out buffers and pinned staging, copy streams
+    struct Pipe {
+        hipStream_t h2d = nullptr, d2h = nullptr;
+        hipEvent_t evIn[2] = {nullptr, nullptr}, evK[2] = {nullptr, nullptr}, evOut[2] = {nullptr, nullptr};
+        DevBuf dImg[2], dKps[2], dDesc[2], dCnt[2];
+        void* pinIn[2] = {nullptr, nullptr};
+        void* pinOut[2] = {nullptr, nullptr};
+        size_t pinInBytes = 0, pinOutBytes = 0;
+        bool ready = false;
+    } pipe;
 };
+
+int orb_check_status(orb_extractor* h);        // interprets h->hStat of the batch of h->lastFrames frames
+int orb_extract_batch_pipelined(orb_extractor* h, const uint8_t* imgs, int nFrames, int rows, int cols, size_t rowStride,
+                                size_t frameStride, orb_keypoint* kps, uint8_t* desc, int cap, int32_t* counts);
+void orb_pipe_release(orb_extractor* h);
 

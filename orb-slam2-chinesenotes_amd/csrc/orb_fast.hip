@@ -416,7 +416,7 @@ __global__ __launch_bounds__(WAVE) void k_fast_strips(const OrbGeom G, const uin
     if (lane == 0) base0 = atomicAdd(&candCount[f * ORB_MAX_LEVELS + S.level], total);
     base0 = __builtin_amdgcn_readfirstlane(base0);
     if (base0 + total > L.candCap) {                               // cannot happen: candCap is the NMS bound
-        if (lane == 0) atomicOr(&errFlags[f], 1);
+        if (lane == 0) orb_flag_error(errFlags, f, 1);
         return;
     }
     const uint32_t* xtab = pathTab + L.pathXOff;
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(WAVE) void k_fast_strips_dense(const OrbGeom G, con
             if (lane == 0) base0 = atomicAdd(cnt, tot);
             base0 = __builtin_amdgcn_readfirstlane(base0);
             if (base0 + tot > L.candCap) {                         // cannot happen: candCap is the NMS bound
-                if (lane == 0) atomicOr(&errFlags[f], 1);
+                if (lane == 0) orb_flag_error(errFlags, f, 1);
                 break;
             }
             int run = base0;

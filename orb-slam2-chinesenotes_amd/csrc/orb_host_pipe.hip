@@ -1,0 +1,191 @@
+// orb_host_pipe.hip -- orb_extract_batch for LARGE host batches: the reference API hands over host images
+// (cv::Mat, reference src/ORBextractor.cc:1084-1091, called from src/Frame.cc:262-268), so the PCIe-inclusive path
+// matters next to the device-resident one.  The batch is cut into chunks that flow through three stages on three
+// streams, two slots deep:
+//     H2D(chunk k+1)  ||  kernel chain(chunk k)  ||  D2H(chunk k-1) + host-side unpacking(chunk k-2)
+// Caller buffers that are already pinned (hipHostMalloc / hipHostRegister) are copied from / to directly; pageable
+// ones go through the handle's pinned staging (a CPU memcpy per chunk, the price of pageable memory).
+// The kernel chain, the scratch slabs and the status block are the handle's own (one chain at a time on its stream);
+// only the device in/out buffers and the staging are doubled.
+#include <algorithm>
+#include <cstring>
+
+#include "orb_extractor_internal.h"
+
+static bool is_pinned(const void* p)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();                               // plain malloc'ed memory: not an error
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
+
+static int pipe_init(orb_extractor* h)
+{
+    orb_extractor::Pipe& P = h->pipe;
+    if (P.ready) return ORB_OK;
+    ORB_HIP_TRY(hipStreamCreateWithFlags(&P.h2d, hipStreamNonBlocking));
+    ORB_HIP_TRY(hipStreamCreateWithFlags(&P.d2h, hipStreamNonBlocking));
+    for (int s = 0; s < 2; s++) {
+        ORB_HIP_TRY(hipEventCreateWithFlags(&P.evIn[s], hipEventDisableTiming));
+        ORB_HIP_TRY(hipEventCreateWithFlags(&P.evK[s], hipEventDisableTiming));
+        ORB_HIP_TRY(hipEventCreateWithFlags(&P.evOut[s], hipEventDisableTiming));
+    }
+    P.ready = true;
+    return ORB_OK;
+}
+
+void orb_pipe_release(orb_extractor* h)
+{
+    orb_extractor::Pipe& P = h->pipe;
+    for (int s = 0; s < 2; s++) {
+        P.dImg[s].release(); P.dKps[s].release(); P.dDesc[s].release(); P.dCnt[s].release();
+        if (P.pinIn[s]) (void)hipHostFree(P.pinIn[s]);
+        if (P.pinOut[s]) (void)hipHostFree(P.pinOut[s]);
+        P.pinIn[s] = P.pinOut[s] = nullptr;
+        if (P.evIn[s]) (void)hipEventDestroy(P.evIn[s]);
+        if (P.evK[s]) (void)hipEventDestroy(P.evK[s]);
+        if (P.evOut[s]) (void)hipEventDestroy(P.evOut[s]);
+        P.evIn[s] = P.evK[s] = P.evOut[s] = nullptr;
+    }
+    if (P.h2d) (void)hipStreamDestroy(P.h2d);
+    if (P.d2h) (void)hipStreamDestroy(P.d2h);
+    P.h2d = P.d2h = nullptr;
+    P.pinInBytes = P.pinOutBytes = 0;
+    P.ready = false;
+}
+
+static int ensure_pinned(void** p, size_t* have, size_t need, void** q)
+{
+    if (need <= *have && *p && *q) return ORB_OK;
+    if (*p) (void)hipHostFree(*p);
+    if (*q) (void)hipHostFree(*q);
+    *p = *q = nullptr;
+    *have = 0;
+    ORB_HIP_TRY(hipHostMalloc(p, need, hipHostMallocDefault));
+    ORB_HIP_TRY(hipHostMalloc(q, need, hipHostMallocDefault));
+    *have = need;
+    return ORB_OK;
+}
+
+int orb_extract_batch_pipelined(orb_extractor* h, const uint8_t* imgs, int nFrames, int rows, int cols, size_t rowStride,
+                                size_t frameStride, orb_keypoint* kps, uint8_t* desc, int cap, int32_t* counts)
+{
+    int rc;
+    if ((rc = pipe_init(h)) != ORB_OK) return rc;
+    orb_extractor::Pipe& P = h->pipe;
+    const size_t imgBytes = (size_t)rows * cols;
+    // chunk: large enough for the kernels to fill the chip, small enough for several chunks to be in flight
+    const int C = std::max(ORB_PIPE_CHUNK_MIN, std::min(64, (nFrames + 3) / 4));
+    const int nChunks = (nFrames + C - 1) / C;
+    const bool inPinned = is_pinned(imgs), outPinned = is_pinned(kps) && is_pinned(desc);
+    const size_t kpSlab = sizeof(orb_keypoint) * (size_t)cap, dsSlab = (size_t)ORB_DESC_BYTES * cap;
+    const size_t statB = orb_extractor::statInts(C) * 4, cntB = (size_t)4 * C;
+    // pinned out slot: [status | counts | keypoints | descriptors] (the two slabs only for pageable caller buffers)
+    const size_t outB = statB + cntB + (outPinned ? 0 : (kpSlab + dsSlab) * C);
+    for (int s = 0; s < 2; s++) {
+        if ((rc = P.dImg[s].ensure(imgBytes * C)) != ORB_OK || (rc = P.dKps[s].ensure(kpSlab * C)) != ORB_OK ||
+            (rc = P.dDesc[s].ensure(dsSlab * C)) != ORB_OK || (rc = P.dCnt[s].ensure(cntB)) != ORB_OK)
+            return rc;
+    }
+    if (!inPinned && (rc = ensure_pinned(&P.pinIn[0], &P.pinInBytes, imgBytes * C, &P.pinIn[1])) != ORB_OK) return rc;
+    if ((rc = ensure_pinned(&P.pinOut[0], &P.pinOutBytes, outB, &P.pinOut[1])) != ORB_OK) return rc;
+    const bool contiguous = rowStride == (size_t)cols && frameStride == imgBytes;
+    hipStream_t cs = h->stream;
+    int firstErr = ORB_OK;
+
+    auto issue = [&](int k) -> int {
+        const int s = k & 1, f0 = k * C, c = std::min(C, nFrames - f0);
+        const uint8_t* src = imgs + frameStride * f0;
+        size_t srcRow = rowStride, srcFrame = frameStride;
+        if (!inPinned) {                                       // pageable input: CPU copy into this slot's pinned buffer
+            uint8_t* st = (uint8_t*)P.pinIn[s];
+            for (int f = 0; f < c; f++)
+                for (int y = 0; y < (rowStride == (size_t)cols ? 1 : rows); y++)
+                    std::memcpy(st + imgBytes * f + (size_t)y * cols, imgs + frameStride * (f0 + f) + rowStride * y,
+                                rowStride == (size_t)cols ? imgBytes : (size_t)cols);
+            src = st; srcRow = cols; srcFrame = imgBytes;
+        }
+        if (srcRow == (size_t)cols && srcFrame == imgBytes) {
+            ORB_HIP_TRY(hipMemcpyAsync(P.dImg[s].p, src, imgBytes * c, hipMemcpyHostToDevice, P.h2d));
+        } else {
+            for (int f = 0; f < c; f++) {
+                if (srcRow == (size_t)cols)
+                    ORB_HIP_TRY(hipMemcpyAsync((uint8_t*)P.dImg[s].p + imgBytes * f, src + srcFrame * f, imgBytes, hipMemcpyHostToDevice, P.h2d));
+                else
+                    ORB_HIP_TRY(hipMemcpy2DAsync((uint8_t*)P.dImg[s].p + imgBytes * f, cols, src + srcFrame * f, srcRow, cols, rows,
+                                                 hipMemcpyHostToDevice, P.h2d));
+            }
+        }
+        (void)contiguous;
+        ORB_HIP_TRY(hipEventRecord(P.evIn[s], P.h2d));
+        ORB_HIP_TRY(hipStreamWaitEvent(cs, P.evIn[s], 0));
+        if (k >= 2) ORB_HIP_TRY(hipStreamWaitEvent(cs, P.evOut[s], 0));       // this slot's outputs of chunk k-2 have left
+        int r = orb_extract_batch_device(h, (const uint8_t*)P.dImg[s].p, c, rows, cols, cols, imgBytes, (orb_keypoint*)P.dKps[s].p,
+                                         (uint8_t*)P.dDesc[s].p, cap, (int32_t*)P.dCnt[s].p);
+        if (r != ORB_OK) return r;
+        // the status block is the handle's single one: it leaves on the compute stream, before the next chunk clears it
+        uint8_t* po = (uint8_t*)P.pinOut[s];
+        ORB_HIP_TRY(hipMemcpyAsync(po, h->dStat.p, orb_extractor::statInts(c) * 4, hipMemcpyDeviceToHost, cs));
+        ORB_HIP_TRY(hipEventRecord(P.evK[s], cs));
+        ORB_HIP_TRY(hipStreamWaitEvent(P.d2h, P.evK[s], 0));
+        ORB_HIP_TRY(hipMemcpyAsync(po + statB, P.dCnt[s].p, (size_t)4 * c, hipMemcpyDeviceToHost, P.d2h));
+        if (outPinned) {
+            ORB_HIP_TRY(hipMemcpyAsync(kps + (size_t)cap * f0, P.dKps[s].p, kpSlab * c, hipMemcpyDeviceToHost, P.d2h));
+            ORB_HIP_TRY(hipMemcpyAsync(desc + dsSlab * f0, P.dDesc[s].p, dsSlab * c, hipMemcpyDeviceToHost, P.d2h));
+        } else {
+            ORB_HIP_TRY(hipMemcpyAsync(po + statB + cntB, P.dKps[s].p, kpSlab * c, hipMemcpyDeviceToHost, P.d2h));
+            ORB_HIP_TRY(hipMemcpyAsync(po + statB + cntB + kpSlab * C, P.dDesc[s].p, dsSlab * c, hipMemcpyDeviceToHost, P.d2h));
+        }
+        ORB_HIP_TRY(hipEventRecord(P.evOut[s], P.d2h));
+        return ORB_OK;
+    };
+
+    auto retire = [&](int k) -> int {
+        const int s = k & 1, f0 = k * C, c = std::min(C, nFrames - f0);
+        ORB_HIP_TRY(hipEventSynchronize(P.evOut[s]));
+        const uint8_t* po = (const uint8_t*)P.pinOut[s];
+        const int keepFrames = h->lastFrames;                  // orb_check_status reads the block of `c` frames
+        h->lastFrames = c;
+        h->hStat.assign((const int*)po, (const int*)po + orb_extractor::statInts(c));
+        int r = orb_check_status(h);
+        h->lastFrames = keepFrames;
+        std::memcpy(counts + f0, po + statB, (size_t)4 * c);
+        if (r != ORB_OK) return r;
+        if (!outPinned)
+            for (int f = 0; f < c; f++) {
+                const int n = counts[f0 + f];
+                if (n <= 0) continue;
+                std::memcpy(kps + (size_t)cap * (f0 + f), po + statB + cntB + kpSlab * f, sizeof(orb_keypoint) * (size_t)n);
+                std::memcpy(desc + dsSlab * (f0 + f), po + statB + cntB + kpSlab * C + dsSlab * f, (size_t)ORB_DESC_BYTES * n);
+            }
+        return ORB_OK;
+    };
+
+    int issued = 0;
+    for (int k = 0; k <= nChunks; k++) {
+        if (k < nChunks && firstErr == ORB_OK) {
+            const int r = issue(k);
+            if (r != ORB_OK) firstErr = r; else issued = k + 1;
+        }
+        if (k >= 1 && k - 1 < issued) {
+            const int r = retire(k - 1);
+            if (r != ORB_OK && firstErr == ORB_OK) firstErr = r;
+        }
+    }
+    if (firstErr != ORB_OK) {                                  // leave nothing in flight behind an error
+        (void)hipStreamSynchronize(P.h2d);
+        (void)hipStreamSynchronize(cs);
+        (void)hipStreamSynchronize(P.d2h);
+        return firstErr;
+    }
+    // the device keeps the last chunk (pyramids included): frames [frameBase, frameBase + lastFrames) of this batch
+    h->frameBase = (nChunks - 1) * C;
+    h->lastFrames = nFrames - h->frameBase;
+    h->statFetched = true;
+    const int hadSticky = h->hStat.empty() ? 0 : h->hStat[orb_extractor::kStickyInts - 1];
+    if (hadSticky) ORB_HIP_TRY(hipMemset(h->dStat.p, 0, orb_extractor::kStickyInts * 4));
+    return ORB_OK;
+}

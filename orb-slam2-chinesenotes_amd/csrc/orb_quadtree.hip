@@ -264,7 +264,7 @@ __device__ __forceinline__ void qt_body(unsigned long long* keys, int n, const O
     const QtNode* fin = sh_inB ? B : A;
     const int size = sh_size;
     if (size > L.kpCap) {
-        if (tid == 0) { atomicOr(&errFlags[f], 2); *outCount = 0; }
+        if (tid == 0) { orb_flag_error(errFlags, f, 2); *outCount = 0; }
         return;
     }
     uint32_t* out = kpl + (size_t)f * G.kpSlab + L.kpBase;

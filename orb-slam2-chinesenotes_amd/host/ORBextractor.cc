@@ -4,6 +4,7 @@
 #include "ORBextractor.h"
 
 #include <cassert>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -15,6 +16,15 @@ namespace ORB_SLAM2
 
 static_assert(sizeof(cv::KeyPoint) == sizeof(orb_keypoint), "cv::KeyPoint must be the 28-byte POD the C ABI writes");
 
+static int gDefaultDevice = -1;
+void ORBextractor::SetDefaultDevice(int device) { gDefaultDevice = device; }
+static int defaultDevice()
+{
+    if (gDefaultDevice >= 0) return gDefaultDevice;
+    const char* e = std::getenv("ORB_HIP_DEVICE");
+    return e ? std::atoi(e) : 0;
+}
+
 static void orbCheck(int rc, const char* what)
 {
     if (rc != ORB_OK)
@@ -23,7 +33,7 @@ static void orbCheck(int rc, const char* what)
 
 ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int _iniThFAST, int _minThFAST)
     : nfeatures(_nfeatures), scaleFactor(_scaleFactor), nlevels(_nlevels), iniThFAST(_iniThFAST),
-      minThFAST(_minThFAST), mpHandle(nullptr), mbDownloadPyramid(true)
+      minThFAST(_minThFAST), mpHandle(nullptr), mbDownloadPyramid(true), mpStage(nullptr), mnStageBytes(0), mnPyramidBytes(0)
 {
     orb_extractor_params p;
     p.nfeatures = _nfeatures;
@@ -31,7 +41,7 @@ ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int
     p.nlevels = _nlevels;
     p.ini_th_fast = _iniThFAST;
     p.min_th_fast = _minThFAST;
-    orbCheck(orb_extractor_create(&p, 0, &mpHandle), "orb_extractor_create");
+    orbCheck(orb_extractor_create(&p, defaultDevice(), &mpHandle), "orb_extractor_create");
     mvScaleFactor.resize(nlevels);
     mvInvScaleFactor.resize(nlevels);
     mvLevelSigma2.resize(nlevels);
@@ -44,6 +54,8 @@ ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int
 
 ORBextractor::~ORBextractor()
 {
+    mvImagePyramid.clear();
+    orb_host_free(mpStage);
     orb_extractor_destroy(mpHandle);
 }
 
@@ -56,33 +68,52 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, s
     assert(image.type() == CV_8UC1);                         // reference :1091
 
     const int cap = orb_extractor_max_keypoints(mpHandle);
-    std::vector<orb_keypoint> kps(cap);
-    std::vector<unsigned char> desc((size_t)cap * ORB_DESC_BYTES);
+    // staging layout: [keypoints cap x 28 | descriptors cap x 32 | pyramid slab]; grown on demand, kept across calls
+    const size_t kpB = sizeof(orb_keypoint) * (size_t)cap, dsB = (size_t)cap * ORB_DESC_BYTES;
+    auto ensureStage = [&](size_t pyrBytes) {
+        const size_t need = kpB + dsB + pyrBytes;
+        if (need <= mnStageBytes) return;
+        for (auto& m : mvImagePyramid) m.release();          // headers over the old buffer
+        orb_host_free(mpStage);
+        mpStage = orb_host_alloc(need);
+        mnStageBytes = mpStage ? need : 0;
+        if (!mpStage) throw std::runtime_error("ORBextractor(HIP): pinned staging allocation failed");
+    };
+    ensureStage(mnPyramidBytes);
+    orb_keypoint* kps = static_cast<orb_keypoint*>(mpStage);
+    unsigned char* desc = static_cast<unsigned char*>(mpStage) + kpB;
     int n = 0;
-    orbCheck(orb_extract(mpHandle, image.data, image.rows, image.cols, (size_t)image.step, kps.data(), desc.data(),
-                         cap, &n), "orb_extract");
+    orbCheck(orb_extract(mpHandle, image.data, image.rows, image.cols, (size_t)image.step, kps, desc, cap, &n), "orb_extract");
 
     if (n == 0)
         _descriptors.release();                              // reference :1107-1108
     else {
         _descriptors.create(n, 32, CV_8U);
         cv::Mat d = _descriptors.getMat();
-        for (int i = 0; i < n; i++)
-            std::memcpy(d.ptr<unsigned char>(i), &desc[(size_t)i * ORB_DESC_BYTES], ORB_DESC_BYTES);
+        if (d.isContinuous())
+            std::memcpy(d.data, desc, (size_t)n * ORB_DESC_BYTES);
+        else
+            for (int i = 0; i < n; i++) std::memcpy(d.ptr<unsigned char>(i), desc + (size_t)i * ORB_DESC_BYTES, ORB_DESC_BYTES);
     }
     _keypoints.clear();
     _keypoints.resize(n);
     if (n)
-        std::memcpy(static_cast<void*>(_keypoints.data()), kps.data(), sizeof(orb_keypoint) * (size_t)n);
+        std::memcpy(static_cast<void*>(_keypoints.data()), kps, sizeof(orb_keypoint) * (size_t)n);
 
     if (mbDownloadPyramid) {
-        for (int level = 0; level < nlevels; ++level) {
-            int r = 0, c = 0;
-            orbCheck(orb_get_pyramid_level(mpHandle, 0, level, nullptr, 0, &r, &c), "orb_get_pyramid_level");
-            mvImagePyramid[level].create(r, c, CV_8UC1);
-            orbCheck(orb_get_pyramid_level(mpHandle, 0, level, mvImagePyramid[level].data,
-                                           (size_t)mvImagePyramid[level].step, &r, &c), "orb_get_pyramid_level");
+        // ONE device-to-host copy and one synchronisation for all levels; mvImagePyramid[level] are headers over the
+        // staging buffer (valid until the next operator() call, like the reference's own buffers)
+        size_t bytes = 0;
+        std::vector<int32_t> off(nlevels), pitch(nlevels), r(nlevels), c(nlevels);
+        orbCheck(orb_get_pyramid(mpHandle, 0, nullptr, 0, &bytes, off.data(), pitch.data(), r.data(), c.data()), "orb_get_pyramid");
+        if (bytes != mnPyramidBytes || kpB + dsB + bytes > mnStageBytes) {
+            mnPyramidBytes = bytes;
+            ensureStage(bytes);
         }
+        unsigned char* pyr = static_cast<unsigned char*>(mpStage) + kpB + dsB;
+        orbCheck(orb_get_pyramid(mpHandle, 0, pyr, bytes, &bytes, off.data(), pitch.data(), r.data(), c.data()), "orb_get_pyramid");
+        for (int level = 0; level < nlevels; ++level)
+            mvImagePyramid[level] = cv::Mat(r[level], c[level], CV_8UC1, pyr + off[level], (size_t)pitch[level]);
     }
 }
 

@@ -43,6 +43,9 @@ public:
     std::vector<cv::Mat> mvImagePyramid;
     void SetPyramidDownload(bool on) { mbDownloadPyramid = on; }
     orb_extractor* Handle() { return mpHandle; }      // for orb_stereo_match on the device-resident pyramids
+    // GPU that extractors constructed from now on live on (the constructor signature is the reference's and has no
+    // room for it); also read from the environment variable ORB_HIP_DEVICE.  Default 0.
+    static void SetDefaultDevice(int device);
 
 protected:
     int nfeatures;
@@ -58,6 +61,11 @@ protected:
 
     orb_extractor* mpHandle;
     bool mbDownloadPyramid;
+    // per-object pinned staging, kept across calls: keypoints, descriptors and the whole pyramid slab (the level
+    // cv::Mats of mvImagePyramid are headers over it)
+    void* mpStage;
+    size_t mnStageBytes;
+    size_t mnPyramidBytes;
 };
 
 } //namespace ORB_SLAM

@@ -61,7 +61,7 @@ SYMBOLS = [
     "orb_extractor_create", "orb_extractor_destroy", "orb_extractor_get_tables", "orb_extractor_max_keypoints",
     "orb_extractor_set_pattern", "orb_extractor_set_pattern_device", "orb_builtin_pattern", "orb_extract",
     "orb_extract_batch", "orb_extract_batch_device", "orb_extractor_sync", "orb_get_pyramid_level",
-    "orb_get_level_counts", "orb_extractor_set_profiling", "orb_extractor_get_stage_ms", "orb_extractor_profiled_frames", "orb_extractor_stream",
+    "orb_get_level_counts", "orb_get_pyramid", "orb_host_alloc", "orb_host_free", "orb_extractor_set_profiling", "orb_extractor_get_stage_ms", "orb_extractor_profiled_frames", "orb_extractor_stream",
     "orb_hamming", "orb_three_maxima", "orb_matcher_create", "orb_matcher_destroy", "orb_matcher_sync",
     "orb_match_bow", "orb_match_bow_kk", "orb_match_init", "orb_match_projection", "orb_match_projection_best", "orb_match_triangulation", "orb_vocab_create", "orb_vocab_destroy", "orb_vocab_level_nodes", "orb_bow_transform",
     "orb_bow_transform_device", "orb_distinctive_descriptors", "orb_distinctive_descriptors_device", "orb_bow_assign_device", "orb_match_bow_batch_device", "orb_bow_build_csr_device",
@@ -95,6 +95,11 @@ def lib():
     L.orb_extractor_sync.argtypes = [vp]
     L.orb_get_pyramid_level.argtypes = [vp, ci, ci, vp, sz, C.POINTER(ci), C.POINTER(ci)]
     L.orb_get_level_counts.argtypes = [vp, ci, vp, vp]
+    L.orb_get_pyramid.argtypes = [vp, ci, vp, sz, C.POINTER(sz), vp, vp, vp, vp]
+    L.orb_host_alloc.argtypes = [sz]
+    L.orb_host_alloc.restype = vp
+    L.orb_host_free.argtypes = [vp]
+    L.orb_host_free.restype = None
     L.orb_extractor_set_profiling.argtypes = [vp, ci]
     L.orb_extractor_get_stage_ms.argtypes = [vp, vp]
     L.orb_extractor_profiled_frames.argtypes = [vp]
@@ -230,6 +235,14 @@ class Extractor:
                                         _p(desc), cap, _p(counts)))
         return [(kps[i, :counts[i]].copy(), desc[i, :counts[i]].copy()) for i in range(f)]
 
+    def extract_batch_into(self, imgs, kps, desc, counts):
+        """Host batch into caller-owned arrays (pinned ones are copied to / from directly): imgs (f, rows, cols) u8,
+        kps (f, cap) KP_DTYPE or raw bytes, desc (f, cap, 32) u8, counts (f) i32."""
+        f, rows, cols = imgs.shape
+        cap = self.max_keypoints
+        _check(self.L.orb_extract_batch(self.h, _p(imgs), f, rows, cols, imgs.strides[1], imgs.strides[0], _p(kps),
+                                        _p(desc), cap, _p(counts)))
+
     def extract_batch_device(self, d_imgs, n_frames, rows, cols, row_stride, frame_stride, d_kps, d_desc, cap, d_counts):
         """Raw device pointers (ints); asynchronous on the handle's stream."""
         _check(self.L.orb_extract_batch_device(self.h, C.c_void_p(d_imgs), n_frames, rows, cols, row_stride, frame_stride,
@@ -244,6 +257,16 @@ class Extractor:
         out = np.zeros((r.value, c.value), np.uint8)
         _check(self.L.orb_get_pyramid_level(self.h, frame, level, _p(out), out.strides[0], C.byref(r), C.byref(c)))
         return out
+
+    def pyramid(self, frame=0):
+        """All levels of one frame with a single device-to-host copy: list of (rows, cols) u8 arrays (views)."""
+        nl = self.nlevels
+        need = C.c_size_t(0)
+        off = np.zeros(nl, np.int32); pit = np.zeros(nl, np.int32); rw = np.zeros(nl, np.int32); cl = np.zeros(nl, np.int32)
+        _check(self.L.orb_get_pyramid(self.h, frame, None, 0, C.byref(need), _p(off), _p(pit), _p(rw), _p(cl)))
+        buf = np.zeros(need.value, np.uint8)
+        _check(self.L.orb_get_pyramid(self.h, frame, _p(buf), need.value, C.byref(need), _p(off), _p(pit), _p(rw), _p(cl)))
+        return [buf[off[l]:off[l] + pit[l] * rw[l]].reshape(rw[l], pit[l])[:, :cl[l]] for l in range(nl)]
 
     def level_counts(self, frame=0):
         kept = np.zeros(self.nlevels, np.int32)

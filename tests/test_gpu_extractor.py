@@ -224,6 +224,89 @@ def test_fast_strip_sizes_and_queue_overflow(monkeypatch, strip, cap):
     _cmp((128 + rng.integers(-9, 10, (240, 320))).astype(np.uint8), nfeatures=500)
 
 
+def test_error_flag_of_an_unsynchronised_batch_is_not_lost():
+    """batch k overflows the caller's output capacity, batch k+1 is issued WITHOUT a sync in between and is
+    fine; the next orb_extractor_sync must still report batch k's failure (sticky word), and the one after is clean."""
+    import torch
+    dev = torch.device("cuda", 0)
+    ex = capi.Extractor()
+    img = synth.synth_frame(2)
+    H, W = img.shape
+    d_img = torch.from_numpy(img).to(dev)
+    cap = ex.max_keypoints
+    d_kps = torch.zeros(cap * 28, dtype=torch.uint8, device=dev)
+    d_desc = torch.zeros(cap * 32, dtype=torch.uint8, device=dev)
+    d_cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    ex.extract_batch_device(d_img.data_ptr(), 1, H, W, W, W * H, d_kps.data_ptr(), d_desc.data_ptr(), 10, d_cnt.data_ptr())    # cap 10: overflow
+    ex.extract_batch_device(d_img.data_ptr(), 1, H, W, W, W * H, d_kps.data_ptr(), d_desc.data_ptr(), cap, d_cnt.data_ptr())   # fine
+    with pytest.raises(capi.OrbError) as e:
+        ex.sync()
+    assert e.value.code == -4                                   # ORB_ERR_CAPACITY
+    ex.extract_batch_device(d_img.data_ptr(), 1, H, W, W, W * H, d_kps.data_ptr(), d_desc.data_ptr(), cap, d_cnt.data_ptr())
+    ex.sync()                                                   # cleared
+    rk, rd = oracle.Extractor().extract(img)
+    n = int(d_cnt.cpu()[0])
+    assert n == len(rk) and d_kps.cpu().numpy()[:n * 28].tobytes() == rk.tobytes()
+    ex.close()
+
+
+def test_host_batch_pipeline_pageable_and_pinned():
+    """orb_extract_batch on 45 host frames goes through the chunked H2D | kernels | D2H pipeline (orb_host_pipe.hip):
+    same results as frame-by-frame calls and as the oracle, for pageable and for pinned caller buffers, for a
+    non-multiple chunk tail, and the device keeps the last chunk (pyramid of the last frame)."""
+    import torch
+    n, W, H = 45, 320, 240
+    imgs = synth.synth_sequence(40, n, W, H)
+    ex = capi.Extractor(500)
+    ref = oracle.Extractor(500)
+    want = [ref.extract(im) for im in imgs]
+    got = ex.extract_batch(imgs)                                  # pageable in, pageable out
+    for (k, d), (rk, rd) in zip(got, want):
+        assert k.tobytes() == rk.tobytes() and np.array_equal(d, rd)
+    ref.extract(imgs[n - 1])
+    for l in range(8):
+        assert np.array_equal(ex.pyramid_level(n - 1, l), ref.pyramid_level(l))
+    with pytest.raises(capi.OrbError):
+        ex.pyramid_level(0, 0)                                   # frame 0 left the device with the first chunk
+    cap = ex.max_keypoints
+    p_img = torch.from_numpy(imgs).pin_memory()
+    p_kps = torch.zeros((n, cap, 28), dtype=torch.uint8).pin_memory()
+    p_desc = torch.zeros((n, cap, 32), dtype=torch.uint8).pin_memory()
+    counts = np.zeros(n, np.int32)
+    ex.extract_batch_into(p_img.numpy(), p_kps.numpy(), p_desc.numpy(), counts)      # pinned in, pinned out
+    for f, (rk, rd) in enumerate(want):
+        assert counts[f] == len(rk)
+        assert p_kps.numpy()[f, :len(rk)].tobytes() == rk.tobytes() and np.array_equal(p_desc.numpy()[f, :len(rk)], rd)
+    one = ex.extract(imgs[3])                                    # and the single-frame path still works afterwards
+    assert one[0].tobytes() == want[3][0].tobytes()
+    ex.close()
+
+
+def test_single_frame_graph_replay_is_bit_exact():
+    """Repeated orb_extract calls of one size are captured as a HIP graph after the second call and replayed: results
+    stay bit-exact across different images, a size change in between, and two handles."""
+    ex, ex2 = capi.Extractor(), capi.Extractor(700, 1.2, 6, 20, 7)
+    ref, ref2 = oracle.Extractor(), oracle.Extractor(700, 1.2, 6, 20, 7)
+    for i in range(6):
+        img = synth.synth_frame(60 + i)
+        k, d = ex.extract(img)
+        rk, rd = ref.extract(img)
+        assert k.tobytes() == rk.tobytes() and np.array_equal(d, rd), i
+        k2, d2 = ex2.extract(img)
+        rk2, rd2 = ref2.extract(img)
+        assert k2.tobytes() == rk2.tobytes() and np.array_equal(d2, rd2), i
+        if i == 3:
+            small = synth.synth_frame(70, 400, 300)
+            k, d = ex.extract(small)
+            rk, rd = ref.extract(small)
+            assert k.tobytes() == rk.tobytes() and np.array_equal(d, rd)
+    pyr = ex.pyramid(0)                                          # one-copy pyramid fetch == per-level fetch
+    for l in range(8):
+        assert np.array_equal(pyr[l], ex.pyramid_level(0, l))
+    ex.close(); ex2.close()
+
+
 def test_randomized_geometry_and_parameter_sweep():
     """40 seeded random (size, nfeatures, levels, scale factor, thresholds) combinations, each bit-exact against the
     oracle stage by stage: exercises odd widths/heights, degenerate upper levels, every resize path, cell grids with

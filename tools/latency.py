@@ -13,6 +13,8 @@ from orbhip import capi, synth
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    import os
+    print("HIP graph replay: %s" % ("off (ORB_NO_GRAPH)" if os.environ.get("ORB_NO_GRAPH") else "on"))
     for (w, h, nf) in ((640, 480, 1000), (752, 480, 1000), (1241, 376, 2000)):
         ex = capi.Extractor(nf, 1.2, 8, 20, 7)
         imgs = [synth.synth_frame(i, w, h) for i in range(8)]
