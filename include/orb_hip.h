@@ -359,6 +359,26 @@ int orb_get_pyramid(orb_extractor* h, int frame, uint8_t* dst, size_t dst_bytes,
 void* orb_host_alloc(size_t bytes);
 void orb_host_free(void* p);
 
+/* ---------------------------------------------------------------- batched frames over the GPUs of one node ----
+ * BASELINE.json configs[3] / north_star: "a batched-frames mode shards independent frames across the 8 GPUs of one
+ * node with RCCL broadcast of the BRIEF pattern over xGMI".  One extractor handle and one host thread per entry of
+ * `devices`; frames are cut into contiguous blocks (orb_shard_range) with no data-path collective; the pattern goes
+ * from devices[0] to the others with ncclBroadcast (librccl is opened at run time).  The same device may be listed
+ * more than once (several handles on one GPU).  Frame.cc / Tracking.cc never see this: it is the batch entry a
+ * dataset-processing caller uses instead of a loop over ORBextractor::operator() (src/ORBextractor.cc:1084-1150). */
+typedef struct orb_multi orb_multi;
+int orb_multi_create(const orb_extractor_params* p, const int* devices, int n_devices, orb_multi** out);
+void orb_multi_destroy(orb_multi* m);
+int orb_multi_devices(const orb_multi* m);
+orb_extractor* orb_multi_handle(orb_multi* m, int i);          /* handle i (e.g. for orb_get_pyramid on its last chunk) */
+/* host pattern -> devices[0] -> RCCL broadcast -> every handle */
+int orb_multi_set_pattern(orb_multi* m, const int8_t* pattern_xy_1024);
+/* orb_extract_batch over all devices: same buffers, layouts and results as the single-GPU call */
+int orb_multi_extract_batch(orb_multi* m, const uint8_t* imgs, int n_frames, int rows, int cols, size_t row_stride,
+                            size_t frame_stride, orb_keypoint* kps, uint8_t* desc32, int cap, int32_t* counts);
+/* the partition rule: rank r of `world` owns frames [first, first + count) of `total` (host only, no device needed) */
+void orb_shard_range(int total, int world, int rank, int* first, int* count);
+
 /* ---------------------------------------------------------------- misc ---------------------*/
 const char* orb_last_error(void);   /* thread-local description of the last failure */
 const char* orb_version(void);

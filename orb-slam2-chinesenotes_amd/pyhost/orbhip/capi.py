@@ -65,7 +65,8 @@ SYMBOLS = [
     "orb_hamming", "orb_three_maxima", "orb_matcher_create", "orb_matcher_destroy", "orb_matcher_sync",
     "orb_match_bow", "orb_match_bow_kk", "orb_match_init", "orb_match_projection", "orb_match_projection_best", "orb_match_triangulation", "orb_vocab_create", "orb_vocab_destroy", "orb_vocab_level_nodes", "orb_bow_transform",
     "orb_bow_transform_device", "orb_distinctive_descriptors", "orb_distinctive_descriptors_device", "orb_bow_assign_device", "orb_match_bow_batch_device", "orb_bow_build_csr_device",
-    "orb_matcher_stream", "orb_stereo_match", "orb_stereo_match_device", "orb_extractor_wait_for", "orb_matcher_wait_for", "orb_last_error", "orb_version",
+    "orb_matcher_stream", "orb_stereo_match", "orb_stereo_match_device", "orb_extractor_wait_for", "orb_matcher_wait_for", "orb_last_error", "orb_version", "orb_multi_create", "orb_multi_destroy", "orb_multi_devices", "orb_multi_handle",
+    "orb_multi_set_pattern", "orb_multi_extract_batch", "orb_shard_range",
 ]
 
 
@@ -138,6 +139,16 @@ def lib():
     L.orb_stereo_match.argtypes = [vp, vp, vp, vp, ci, vp, vp, ci, cf, cf, vp, vp]
     L.orb_stereo_match_device.argtypes = [vp, vp, ci, ci, vp, vp, ci, vp, vp, ci, cf, cf, vp, vp]
     L.orb_matcher_wait_for.argtypes = [vp, vp]
+    L.orb_multi_create.argtypes = [C.POINTER(Params), vp, ci, C.POINTER(vp)]
+    L.orb_multi_destroy.argtypes = [vp]
+    L.orb_multi_destroy.restype = None
+    L.orb_multi_devices.argtypes = [vp]
+    L.orb_multi_handle.argtypes = [vp, ci]
+    L.orb_multi_handle.restype = vp
+    L.orb_multi_set_pattern.argtypes = [vp, vp]
+    L.orb_multi_extract_batch.argtypes = [vp, vp, ci, ci, ci, sz, sz, vp, vp, ci, vp]
+    L.orb_shard_range.argtypes = [ci, ci, ci, C.POINTER(ci), C.POINTER(ci)]
+    L.orb_shard_range.restype = None
     L.orb_last_error.restype = C.c_char_p
     L.orb_version.restype = C.c_char_p
     _lib = L
@@ -291,6 +302,49 @@ class Extractor:
 
     def wait_for(self, hip_stream):
         _check(self.L.orb_extractor_wait_for(self.h, C.c_void_p(hip_stream)))
+
+
+def shard_range(total, world, rank):
+    """The C ABI's partition rule (host only)."""
+    a, b = C.c_int(0), C.c_int(0)
+    lib().orb_shard_range(total, world, rank, C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+class MultiExtractor:
+    """orb_multi_*: one extractor per listed device, frames sharded in contiguous blocks, BRIEF pattern broadcast
+    from devices[0] with RCCL."""
+
+    def __init__(self, devices, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7):
+        self.L = lib()
+        self.h = C.c_void_p()
+        self.nlevels = nlevels
+        prm = Params(nfeatures, scale_factor, nlevels, ini_th, min_th)
+        dev = np.ascontiguousarray(devices, np.int32)
+        _check(self.L.orb_multi_create(C.byref(prm), _p(dev), dev.size, C.byref(self.h)))
+        self.max_keypoints = self.L.orb_extractor_max_keypoints(self.L.orb_multi_handle(self.h, 0))
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.L.orb_multi_destroy(self.h)
+            self.h = C.c_void_p()
+
+    __del__ = close
+
+    def set_pattern(self, pattern):
+        pattern = np.ascontiguousarray(pattern, np.int8)
+        _check(self.L.orb_multi_set_pattern(self.h, _p(pattern)))
+
+    def extract_batch(self, imgs):
+        imgs = np.ascontiguousarray(imgs, dtype=np.uint8)
+        f, rows, cols = imgs.shape
+        cap = self.max_keypoints
+        kps = np.zeros((f, cap), KP_DTYPE)
+        desc = np.zeros((f, cap, 32), np.uint8)
+        counts = np.zeros(f, np.int32)
+        _check(self.L.orb_multi_extract_batch(self.h, _p(imgs), f, rows, cols, imgs.strides[1], imgs.strides[0], _p(kps), _p(desc),
+                                              cap, _p(counts)))
+        return [(kps[i, :counts[i]].copy(), desc[i, :counts[i]].copy()) for i in range(f)]
 
 
 def _fv(node_ids, offsets, indices):

@@ -61,3 +61,28 @@ def test_no_device_is_a_loud_error():
     with pytest.raises(capi.OrbError) as e:
         capi.Extractor()
     assert e.value.code in (-3, -2)
+
+
+def test_shard_range_is_a_partition_and_matches_the_python_rule():
+    """orb_shard_range (the C ABI's frame partition of orb_multi_extract_batch) covers every frame exactly once, in
+    order, with blocks that differ by at most one frame, and is the rule bench.py / orbhip.shard use."""
+    from orbhip import shard
+    for total in (0, 1, 7, 64, 512, 513, 1000):
+        for world in (1, 2, 3, 4, 8, 16):
+            nxt, sizes = 0, []
+            for r in range(world):
+                first, count = capi.shard_range(total, world, r)
+                assert (first, count) == shard.frame_range(total, world, r)
+                assert first == nxt and count >= 0
+                nxt += count
+                sizes.append(count)
+            assert nxt == total and max(sizes) - min(sizes) <= 1
+    assert capi.shard_range(10, 0, 0) == (0, 0) and capi.shard_range(10, 4, 4) == (0, 0)
+
+
+def test_multi_without_a_device_is_a_loud_error():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(capi.OrbError):
+        capi.MultiExtractor([0, 1])

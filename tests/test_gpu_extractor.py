@@ -332,3 +332,29 @@ def test_randomized_geometry_and_parameter_sweep():
         except AssertionError as e:
             raise AssertionError("config %d: %dx%d nfeatures=%d levels=%d sf=%g ini=%d min=%d: %s" % (t, w, h, nf, levels, sf, ini, mn, e))
     assert done >= 30
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0, 0]])
+def test_multi_extractor_shards_and_broadcasts(devices):
+    """orb_multi_*: the product-level batched-frames mode (one handle + host thread per listed device, contiguous
+    blocks, RCCL broadcast of the pattern from the first device).  On the one-GPU box the device is listed up to three
+    times: partition, threads, merge and the pattern hand-over are exercised, the xGMI hop is not."""
+    imgs = synth.synth_sequence(200, 41, 320, 240)
+    mx = capi.MultiExtractor(devices, 500)
+    ref = oracle.Extractor(500)
+    want = [ref.extract(im) for im in imgs]
+    got = mx.extract_batch(imgs)
+    assert len(got) == len(want)
+    for (k, d), (rk, rd) in zip(got, want):
+        assert k.tobytes() == rk.tobytes() and np.array_equal(d, rd)
+    # a different pattern reaches every handle: swap the two points of every pair -> every descriptor bit flips
+    pat = capi.builtin_pattern().reshape(256, 2, 2)[:, ::-1, :].copy().reshape(-1)
+    mx.set_pattern(pat)
+    got2 = mx.extract_batch(imgs)
+    one = capi.Extractor(500)
+    one.set_pattern(pat)
+    for i in (0, 20, 40):
+        k1, d1 = one.extract(imgs[i])
+        assert got2[i][0].tobytes() == k1.tobytes() and np.array_equal(got2[i][1], d1)
+        assert not np.array_equal(got2[i][1], got[i][1])
+    mx.close(); one.close()
