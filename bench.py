@@ -583,7 +583,7 @@ def run_c5(args, rank, local_rank, world, dev, comm_dev, dist):
     match_ms = statistics.median(t_m) * 1e3
     if rank != 0:
         return None
-    last = (args.steps - 1) % 2                    # slot of the last matched stream frame (frame index steps-1)
+    last, last_q = 3 % 2, 3 % n_q                  # slot / stream frame of the last match above (i = 3)
     nm = d_nm[last].cpu().numpy()
     cnts = d_counts.cpu().numpy()
     n1 = float(cnts[:n_kf].mean())
@@ -612,7 +612,7 @@ def run_c5(args, rank, local_rank, world, dev, comm_dev, dist):
         kps_all = d_kps.cpu().numpy().view(capi.KP_DTYPE).reshape(F, cap)
         desc_all = d_desc.cpu().numpy().reshape(F, cap, 32)
         mg = d_match[last].cpu().numpy().reshape(n_kf, cap)
-        qi = (args.steps - 1) % n_q
+        qi = last_q
         t0 = time.perf_counter()
         kq, dq = ref.extract(stream_np[qi])
         t_ext = time.perf_counter() - t0

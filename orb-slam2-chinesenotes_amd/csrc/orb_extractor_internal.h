@@ -3,6 +3,7 @@
 #include <vector>
 
 #include "orb_kernels.h"
+#include "orb_geometry_host.h"
 
 #define ORB_PIPE_CHUNK_MIN 8       // host batches of >= 2 chunks of this size are pipelined
 
@@ -40,6 +41,7 @@ struct orb_extractor {
     std::vector<float> scale, invScale, sigma2, invSigma2;
     std::vector<int> quota;
     int umax[16];
+    OrbHostTables tables;                   // the same, as orb_geometry_host.h computes them
 
     // geometry for the current image size
     int rows = 0, cols = 0;

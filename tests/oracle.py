@@ -16,6 +16,8 @@ assert KP_DTYPE.itemsize == 28
 
 
 def build():
+    if os.environ.get("ORBREF_LIB"):                   # e.g. oracle/liborbref_asan.so (tests/test_oracle_pins.py)
+        return os.environ["ORBREF_LIB"]
     srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".cpp", ".hpp"))]
     if (not os.path.exists(_LIB)) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "liborbref.so"], stdout=subprocess.DEVNULL)

@@ -19,7 +19,7 @@ def _last_json(out):
 
 def test_single_gpu_line_has_every_contract_field():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--frames-per-gpu", "32",
-                        "--cpu-seconds", "2"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                        "--cpu-frames", "4", "--no-cpu-all-cores"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _last_json(r.stdout)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
@@ -27,19 +27,57 @@ def test_single_gpu_line_has_every_contract_field():
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["value"] > 0 and d["unit"] == "frames/s"
     assert d["scaling"] == "weak" and d["dtype"] == "u8" and d["vs_baseline"] is None and "workload" in d["config"]
+    assert d["config"]["lanes"] == 2 and d["config"]["mean_bow_matches"] > 30          # related frames: the accept path runs
+    assert d["config"]["host_in_host_out_fps"]["pinned"] > 0
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    if "roofline_valu" in d:
+        rv = d["roofline_valu"]
+        assert rv["bound"] == "valu_issue" and abs(rv["frac"] - rv["achieved"] / rv["peak"]) < 1e-3
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["gpu_matches_oracle_on_sample"] is True
 
 
-def test_two_ranks_gloo_rehearsal_on_one_gpu():
+@pytest.mark.parametrize("cfg,steps", [("c3", "2"), ("c5", "6")])
+def test_other_baseline_configs_print_the_contract_line_with_parity(cfg, steps):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", cfg, "--steps", steps, "--warmup", "1",
+                        "--cpu-frames", "20"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    assert d["value"] > 0 and d["unit"] == "frames/s" and d["roofline"]["bound"] == "hbm"
+    assert d["cpu_baseline"]["gpu_matches_oracle_on_sample"] is True
+
+
+def _two_ranks(extra):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--frames-per-gpu", "16", "--backend", "gloo", "--single-device", "--no-cpu-baseline"]
+           "--frames-per-gpu", "16", "--backend", "gloo", "--single-device", "--no-cpu-baseline"] + extra
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
-    d = _last_json(r.stdout)
+    return _last_json(r.stdout)
+
+
+def test_two_ranks_gloo_rehearsal_on_one_gpu():
+    d = _two_ranks([])
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
     assert d["config"]["frames_per_gpu"] == 16
+
+
+def test_two_ranks_strong_scaling_splits_one_batch():
+    d = _two_ranks(["--scaling", "strong"])                     # BASELINE configs[3] as written: ONE batch over the GPUs
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["frames_per_gpu"] == 8
+
+
+def test_gpus_flag_alone_starts_the_ranks_and_a_mismatch_is_refused():
+    """`python bench.py --gpus 2` must not run one rank and print n_gpus=1."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--frames-per-gpu", "16", "--backend", "gloo", "--single-device", "--no-cpu-baseline", "--master-port",
+                        "29541"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    assert _last_json(r.stdout)["n_gpus"] == 2
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1"], capture_output=True,
+                         text=True, timeout=300, cwd=ROOT, env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
+    assert bad.returncode != 0 and "refusing" in (bad.stderr + bad.stdout)

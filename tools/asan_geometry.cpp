@@ -1,0 +1,109 @@
+// asan_geometry.cpp -- the extractor's HOST-ONLY set-up code (orb_geometry_host.h: constructor tables, level sizes, FAST
+// strips, quadtree path tables, cv::resize coefficient tables, slab layout) under AddressSanitizer + UBSan on the CPU,
+// over a sweep of image sizes and parameters, with the invariants the kernels rely on checked explicitly.
+// build + run: make -C orb-slam2-chinesenotes_amd asan-geometry   (hipcc --cuda-host-only -fsanitize=address,undefined)
+#include <cstdarg>
+#include <cstdio>
+#include <random>
+
+#include "../orb-slam2-chinesenotes_amd/csrc/orb_geometry_host.h"
+
+static char g_err[512];
+void orb_set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+#define CHECK(c)                                                                                        \
+    do {                                                                                                \
+        if (!(c)) { fprintf(stderr, "asan_geometry: check failed at %s:%d: %s (%dx%d nf %d nl %d sf %g)\n", __FILE__, __LINE__, #c, \
+                            cols, rows, prm.nfeatures, prm.nlevels, (double)prm.scale_factor); return 1; }                        \
+    } while (0)
+
+static int one(const orb_extractor_params& prm, int rows, int cols, const int* stripK, int& planned)
+{
+    OrbHostTables T;
+    orb_build_tables(prm, T);
+    int sum = 0;
+    for (int l = 0; l < prm.nlevels; l++) { CHECK(T.quota[l] >= 0); sum += T.quota[l]; }
+    CHECK(sum >= prm.nfeatures || prm.nfeatures == 0 || T.quota[prm.nlevels - 1] == 0);
+    for (int v = 0; v < 16; v++) CHECK(T.umax[v] >= 0 && T.umax[v] <= 15);
+    OrbGeomPlan P;
+    const int rc = orb_plan_geometry(prm, T, stripK, rows, cols, P);
+    if (rc != ORB_OK) return rc == ORB_ERR_UNSUPPORTED ? 0 : 1;          // outside the envelope: reported, fine
+    planned++;
+    const OrbGeom& G = P.G;
+    size_t strip = 0;
+    for (int l = 0; l < prm.nlevels; l++) {
+        const OrbLevelGeom& L = G.L[l];
+        CHECK(L.w >= 1 && L.h >= 1 && L.pitch >= L.w && L.pitch % 64 == 0);
+        CHECK((size_t)L.pyrOff + (size_t)L.pitch * L.h <= P.pyrSlab);
+        CHECK((size_t)L.pathXOff + std::max(L.boxW, 0) <= P.pathTab.size() && (size_t)L.pathYOff + std::max(L.boxH, 0) <= P.pathTab.size());
+        CHECK(L.kpBase + L.kpCap <= G.kpSlab && L.candBase + L.candCap <= (int)P.candSlab + 1);
+        // the strips of the level: every cell of every cell row exactly once, inside the image, within the tile limits
+        int cells = 0;
+        for (int s = 0; s < P.stripsOfLevel[l]; s++, strip++) {
+            const OrbStrip& S = P.strips[strip];
+            CHECK(S.level == l && S.nc >= 1 && S.nc <= 8);
+            CHECK(S.x0 >= 16 && S.y0 >= 16 && S.x0 + S.w <= L.w - 16 && S.y0 + S.h <= L.h - 16 && S.w >= 7 && S.h >= 7);
+            CHECK(S.xoff == (S.x0 & 7) && S.xoff + S.w <= 255 && S.h <= 66);
+            CHECK(S.zLo == S.xoff + 3 && S.zHi == S.zLo + S.w - 6 && S.zh == S.h - 6);
+            CHECK(2 * S.nx8 <= P.fastPdw && S.h <= P.fastRows && S.nh <= P.fastSdw);
+            CHECK(S.qLo * 4 <= S.zLo && (S.qLo + S.nq) * 4 >= S.zHi && S.hLo <= S.qLo && S.hLo + S.nh >= S.qLo + S.nq);
+            CHECK((S.zHi - S.zLo + S.wCell - 1) / S.wCell == S.nc);       // zone columns cut into exactly nc cells
+            CHECK(S.cxBase + S.zLo >= 0 && S.cxBase + S.zHi <= L.boxW && S.ci * L.hCell + 3 + S.zh <= L.boxH);
+            CHECK(S.zonePx == (S.zHi - S.zLo) * S.zh);
+            cells += S.nc;
+        }
+        (void)cells;
+        // resize tables of the level: every source index inside the previous level
+        if (l >= 1) {
+            const OrbLevelGeom& Sp = G.L[l - 1];
+            for (int x = 0; x < L.w; x++) {
+                const int2 e = P.xt[P.xtabOff[l] + x];
+                CHECK(e.x >= 0 && e.x <= Sp.w - 1);
+            }
+            for (int y = 0; y < L.h; y++) {
+                const int2 e = P.yt[P.ytabOff[l] + y];
+                CHECK((e.x & 0xffff) <= Sp.h - 1 && ((unsigned)e.x >> 16) <= (unsigned)(Sp.h - 1));
+            }
+            if (P.xqOff[l] >= 0) CHECK((size_t)P.xqOff[l] * 4 + (size_t)((L.w + 3) / 4) * 12 <= P.xq.size());
+        }
+    }
+    CHECK(strip == P.strips.size());
+    return 0;
+}
+
+int main()
+{
+    std::mt19937 rng(20261004);
+    int planned = 0, total = 0;
+    const int fixed[][2] = {{640, 480}, {752, 480}, {1241, 376}, {320, 240}, {333, 257}, {211, 157}, {90, 80}, {4095, 300}, {4200, 100},
+                            {100, 900}, {64, 64}, {33, 33}, {1, 1}, {1920, 1080}};
+    for (const auto& f : fixed)
+        for (int k = 1; k <= 8; k += 2) {
+            orb_extractor_params prm = {1000, 1.2f, 8, 20, 7};
+            int K[ORB_MAX_LEVELS];
+            for (int& v : K) v = k;
+            total++;
+            if (one(prm, f[1], f[0], K, planned)) return 1;
+        }
+    for (int t = 0; t < 600; t++) {
+        orb_extractor_params prm;
+        prm.nfeatures = (int)(rng() % 6000);
+        const float sfs[] = {1.05f, 1.1f, 1.2f, 1.25f, 1.5f, 2.0f, 2.5f};
+        prm.scale_factor = sfs[rng() % 7];
+        prm.nlevels = 1 + (int)(rng() % ORB_MAX_LEVELS);
+        prm.ini_th_fast = 20; prm.min_th_fast = 7;
+        int K[ORB_MAX_LEVELS];
+        for (int& v : K) v = 1 + (int)(rng() % 8);
+        const int cols = 1 + (int)(rng() % 2500), rows = 1 + (int)(rng() % 1500);
+        total++;
+        if (one(prm, rows, cols, K, planned)) return 1;
+    }
+    printf("asan_geometry: %d configurations, %d inside the envelope, no sanitizer report, all invariants hold\n", total, planned);
+    return 0;
+}
