@@ -45,8 +45,10 @@ static int build_geometry(orb_extractor* h, int rows, int cols)
     // It starts small (more resident workgroups: the kernel is latency-bound) and orb_extractor_sync() grows it to
     // the largest candidate count actually seen, so steady-state batches sort in LDS.
     int sortCap = 1024;
-    while (sortCap > 256 && orb_quadtree_lds_bytes(sortCap, nodeCap) > 60 * 1024) sortCap >>= 1;
-    if (orb_quadtree_lds_bytes(sortCap, nodeCap) > 64 * 1024) {
+    // per-workgroup LDS budget: 60 KB (several workgroups per CU) unless the node arrays alone need more
+    const size_t qtBudget = orb_quadtree_lds_bytes(256, nodeCap) > 60 * 1024 ? (size_t)ORB_QT_LDS_MAX : (size_t)60 * 1024;
+    while (sortCap > 256 && orb_quadtree_lds_bytes(sortCap, nodeCap) > qtBudget) sortCap >>= 1;
+    if (orb_quadtree_lds_bytes(sortCap, nodeCap) > ORB_QT_LDS_MAX) {
         orb_set_error("nfeatures too large for the quadtree kernel's LDS budget");
         return ORB_ERR_UNSUPPORTED;
     }
@@ -380,7 +382,8 @@ int orb_check_status(orb_extractor* h)
         for (size_t i = 0; i < (size_t)ORB_MAX_LEVELS * n; i++) mx = std::max(mx, cand[i]);
         int want = 1024;
         while (want < mx && want < 4096) want <<= 1;
-        while (want > 256 && orb_quadtree_lds_bytes(want, h->nodeCap) > 60 * 1024) want >>= 1;
+        const size_t budget = orb_quadtree_lds_bytes(256, h->nodeCap) > 60 * 1024 ? (size_t)ORB_QT_LDS_MAX : (size_t)60 * 1024;
+        while (want > 256 && orb_quadtree_lds_bytes(want, h->nodeCap) > budget) want >>= 1;
         if (want > h->sortCap) h->sortCap = want;
     }
     if (!h->fastStripFixed) {                          // levels whose strips keep overflowing get shorter strips

@@ -5,6 +5,7 @@
 #include "orb_kernels.h"
 #include "orb_geometry_host.h"
 
+#define ORB_QT_LDS_MAX (156 * 1024)  // k_quadtree may take (almost) the CU's whole 160 KB for huge per-level quotas
 #define ORB_PIPE_CHUNK_MIN 8       // host batches of >= 2 chunks of this size are pipelined
 
 struct DevBuf {

@@ -337,6 +337,9 @@ void orb_launch_quadtree(hipStream_t st, const OrbGeom& G, unsigned long long* c
                          int nodeCap, int nFrames)
 {
     const size_t lds = orb_quadtree_lds_bytes(sortCap, nodeCap);
+    // quotas beyond ~1000 per level (nFeatures >~ 4500) need more than the default 64 KB of dynamic LDS: a workgroup may
+    // use the CU's whole 160 KB (one workgroup per CU then -- only the huge-quota configurations pay that)
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_quadtree, dim3(nFrames, G.nlevels), dim3(256), lds, st, G, cand, candSlab, candCount,
                        kpl, kpCount, errFlags, sortCap, nodeCap);
 }

@@ -358,3 +358,11 @@ def test_multi_extractor_shards_and_broadcasts(devices):
         assert got2[i][0].tobytes() == k1.tobytes() and np.array_equal(got2[i][1], d1)
         assert not np.array_equal(got2[i][1], got[i][1])
     mx.close(); one.close()
+
+
+@pytest.mark.parametrize("nf", [4000, 6000, 10000])
+def test_large_feature_counts_kitti_size(nf):
+    """Reference src/Tracking.cc:117-126 builds the initialisation extractor with 2 x nFeatures (KITTI: 4000): per-level
+    quotas beyond ~1000 make k_quadtree take more than 64 KB of LDS (up to the CU's 160 KB).  Bit-exact at 1241x376."""
+    n = _cmp(synth.synth_frame(100, 1241, 376), nfeatures=nf)
+    assert n > min(nf, 4000) * 0.8

@@ -525,3 +525,70 @@ def test_projection_family_and_triangulation_randomized_subsets(feats):
         assert tgn == twn and np.array_equal(tgm, twm), ("triangulation", t, nq, n, ori)
         total += twn
     assert total > 100
+
+
+def test_c5_full_size_1000_keyframe_db():
+    """BASELINE configs[4] at full size: a 752x480 stream frame against a 1000-keyframe descriptor DB in HBM (the
+    Relocalization candidate loop, reference src/Tracking.cc:1471-1492), DBoW2-shaped vocabulary (k=10, L=5 here).
+    Size-independent properties over all 1000 pairs (the query recognises the keyframes of its own scene; the batch
+    equals itself when repeated and when the matcher builds the feature vectors itself instead of reading the
+    store's CSR; match arrays are injective) + oracle parity on a seeded sample of 40 pairs."""
+    import torch
+    W, H, n_kf, nq = 752, 480, 1000, 3
+    dev = torch.device("cuda", 0)
+    ex, mt = capi.Extractor(), capi.Matcher(0.75, True)
+    cap = ex.max_keypoints
+    F = n_kf + nq
+    z = lambda n, dt: torch.zeros(n, dtype=dt, device=dev)
+    d_kps, d_desc, d_counts, d_node = z(F * cap * 28, torch.uint8), z(F * cap * 32, torch.uint8), z(F, torch.int32), z(F * cap, torch.int16)
+    valid_np = np.stack([synth.synth_valid_flags(cap, 7000 + i) for i in range(F)])
+    d_valid = torch.from_numpy(valid_np).to(dev)
+    tree = synth.synth_vocab_tree_balanced(10, 5, seed=5)
+    voc = capi.Vocabulary(tree)
+    nn = voc.level_nodes(3)                                          # level 2: 100 nodes
+    q_scene = [17, 60, 101]
+    q_frames = np.stack([synth.synth_sequence(8 * s + 3, 1, W, H, noise=5)[0] for s in q_scene])
+    for k0 in range(0, F, 40):
+        n = min(40, F - k0)
+        fr = synth.synth_sequence(k0, n, W, H) if k0 + n <= n_kf else np.concatenate([synth.synth_sequence(k0, n_kf - k0, W, H), q_frames])[:n]
+        d_b = torch.from_numpy(fr).to(dev)
+        ex.extract_batch_device(d_b.data_ptr(), n, H, W, W, W * H, d_kps.data_ptr() + k0 * cap * 28, d_desc.data_ptr() + k0 * cap * 32,
+                                cap, d_counts.data_ptr() + k0 * 4)
+        ex.sync()
+    voc.transform_device(mt, d_desc.data_ptr(), d_counts.data_ptr(), F, cap, 3, d_node_of=d_node.data_ptr())
+    d_ck, d_cs, d_cc = z(F * cap, torch.int32), z(F * nn, torch.int16), z(F * nn, torch.int16)
+    mt.build_csr_device(d_node.data_ptr(), d_counts.data_ptr(), F, cap, nn, d_ck.data_ptr(), d_cs.data_ptr(), d_cc.data_ptr())
+    base = dict(desc=d_desc.data_ptr(), kps=d_kps.data_ptr(), valid=d_valid.data_ptr(), counts=d_counts.data_ptr(),
+                node_of=d_node.data_ptr(), cap=cap, n_frames=F, n_nodes=nn)
+    with_csr = dict(base, csr_keys=d_ck.data_ptr(), csr_start=d_cs.data_ptr(), csr_cnt=d_cc.data_ptr())
+    kf_idx = torch.arange(n_kf, dtype=torch.int32, device=dev)
+    counts = d_counts.cpu().numpy()
+    kps = d_kps.cpu().numpy().view(capi.KP_DTYPE).reshape(F, cap)
+    desc = d_desc.cpu().numpy().reshape(F, cap, 32)
+    rng = np.random.default_rng(11)
+    for q in range(nq):
+        f_idx = torch.full((n_kf,), n_kf + q, dtype=torch.int32, device=dev)
+        res = []
+        for store in (with_csr, with_csr, base):
+            d_m, d_n = z(n_kf * cap, torch.int32), z(n_kf, torch.int32)
+            mt.match_bow_batch_device(store, kf_idx.data_ptr(), f_idx.data_ptr(), n_kf, d_m.data_ptr(), d_n.data_ptr())
+            mt.sync()
+            res.append((d_m.cpu().numpy().reshape(n_kf, cap), d_n.cpu().numpy()))
+        (m0, n0), (m1, n1), (m2, n2) = res
+        assert np.array_equal(m0, m1) and np.array_equal(n0, n1)            # idempotent
+        assert np.array_equal(m0, m2) and np.array_equal(n0, n2)            # store CSR == CSR built inside the matcher
+        nqf = int(counts[n_kf + q])
+        assert np.all(n0 == (m0[:, :nqf] >= 0).sum(axis=1))                  # rows are written for the query's features only
+        for kf in rng.choice(n_kf, 25, replace=False):                      # a keyframe feature is matched at most once
+            mm = m0[kf, :nqf][m0[kf, :nqf] >= 0]
+            assert mm.size == np.unique(mm).size and (mm.size == 0 or mm.max() < counts[kf])
+        own = np.arange(8 * q_scene[q], 8 * q_scene[q] + 8)
+        assert n0[own].min() > 4 * np.delete(n0, own).max() / 3 and n0.argmax() in own   # recognises its own scene
+        kq, dq = kps[n_kf + q, :nqf], desc[n_kf + q, :nqf]
+        fvq = oracle.featvec_from_nodes(oracle.vocab_transform(tree, dq, 3)[1])
+        sample = list(rng.choice(n_kf, 10, replace=False)) + list(own[:4])
+        for kf in sample:
+            n = int(counts[kf])
+            fvk = oracle.featvec_from_nodes(oracle.vocab_transform(tree, desc[kf, :n], 3)[1])
+            wn, wm = oracle.search_by_bow(desc[kf, :n], kps[kf, :n]["angle"], valid_np[kf][:n], fvk, dq, kq["angle"], fvq, 0.75, True)
+            assert wn == n0[kf] and np.array_equal(wm, m0[kf, :nqf]), (q, kf)
