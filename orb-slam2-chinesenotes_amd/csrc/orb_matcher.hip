@@ -153,7 +153,7 @@ struct BowSide {
 //   3 scatter the indices to tmp[start[node] + slot]
 //   4 rank every index inside its node's segment (segments are ~10 long; O(m) per feature) -> keys[]
 // Features whose node is not in [0, nNodes) take no part (they are in no feature vector).
-#define ORB_CSR_MAXPT 4        // features per thread: cap <= 4096, 1024 threads
+#define ORB_CSR_MAXPT 8        // features per thread: cap <= 8192, 1024 threads
 __device__ void build_csr(const uint16_t* __restrict__ nodeOf, int n, int nNodes, uint32_t* keys, uint32_t* tmp,
                           uint32_t* cntw, uint16_t* start, uint16_t* cnt)
 {
@@ -596,9 +596,13 @@ static int launch_match(orb_matcher* m, bool kk, const BowSide* dA, const BowSid
                         int capLds, float ratio, int checkOri, int32_t* dMatch, int matchStride, int32_t* dNm)
 {
     const size_t lds = match_lds_bytes(capLds, nNodes);
-    if (lds > 64 * 1024) {
+    if (lds > 156 * 1024 || capLds > 1024 * ORB_CSR_MAXPT) {
         orb_set_error("feature capacity %d x %d nodes exceeds the match kernel's LDS budget", capLds, nNodes);
         return ORB_ERR_UNSUPPORTED;
+    }
+    if (lds > 64 * 1024) {                                 // frames of > ~3900 features: the CU's whole LDS for one pair
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_match_bow<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_match_bow<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
     if (kk)
         hipLaunchKernelGGL(k_match_bow<true>, dim3(nPairs), dim3(1024), lds, m->stream, dA, dB, nNodes, capLds, ratio,
@@ -616,7 +620,7 @@ extern "C" int orb_match_bow_batch_device(orb_matcher* m, const orb_featstore* s
 {
     if (!m || !store || !d_kf || !d_f || !d_match || !d_nm || nPairs < 0) return ORB_ERR_INVALID;
     if (nPairs == 0) return ORB_OK;
-    if (store->cap <= 0 || store->cap > 4096) { orb_set_error("featstore cap must be 1..4096"); return ORB_ERR_UNSUPPORTED; }
+    if (store->cap <= 0 || store->cap > 8192) { orb_set_error("featstore cap must be 1..8192"); return ORB_ERR_UNSUPPORTED; }
     ORB_HIP_TRY(hipSetDevice(m->device));
     int rc;
     if ((rc = m->sidesA.ensure(sizeof(BowSide) * (size_t)nPairs)) != ORB_OK) return rc;
@@ -633,9 +637,10 @@ extern "C" int orb_bow_build_csr_device(orb_matcher* m, const uint16_t* d_node_o
 {
     if (!m || !d_node_of || !d_counts || !d_keys || !d_start || !d_cnt || nFrames < 0 || nNodes <= 0) return ORB_ERR_INVALID;
     if (nFrames == 0) return ORB_OK;
-    if (cap <= 0 || cap > 4096) { orb_set_error("featstore cap must be 1..4096"); return ORB_ERR_UNSUPPORTED; }
+    if (cap <= 0 || cap > 8192) { orb_set_error("featstore cap must be 1..8192"); return ORB_ERR_UNSUPPORTED; }
     const size_t lds = (size_t)cap * 8 + (size_t)nNodes * 8;
-    if (lds > 64 * 1024) { orb_set_error("feature capacity %d x %d nodes exceeds the CSR kernel's LDS budget", cap, nNodes); return ORB_ERR_UNSUPPORTED; }
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_csr), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 156 * 1024) { orb_set_error("feature capacity %d x %d nodes exceeds the CSR kernel's LDS budget", cap, nNodes); return ORB_ERR_UNSUPPORTED; }
     ORB_HIP_TRY(hipSetDevice(m->device));
     hipLaunchKernelGGL(k_build_csr, dim3(nFrames), dim3(1024), lds, m->stream, d_node_of, d_counts, cap, nNodes, d_keys, d_start,
                        d_cnt);

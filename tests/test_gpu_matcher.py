@@ -592,3 +592,23 @@ def test_c5_full_size_1000_keyframe_db():
             fvk = oracle.featvec_from_nodes(oracle.vocab_transform(tree, desc[kf, :n], 3)[1])
             wn, wm = oracle.search_by_bow(desc[kf, :n], kps[kf, :n]["angle"], valid_np[kf][:n], fvk, dq, kq["angle"], fvq, 0.75, True)
             assert wn == n0[kf] and np.array_equal(wm, m0[kf, :nqf]), (q, kf)
+
+
+def test_search_by_bow_frames_of_6000_features():
+    """Frames as large as the 2 x nFeatures initialisation extractor produces (reference src/Tracking.cc:121): more than
+    64 KB of LDS per pair in k_match_bow (the CU's whole 160 KB is available to one workgroup)."""
+    ref = oracle.Extractor(6000)
+    base = synth.synth_frame(100, 1241, 376, noise=0).astype(np.int16)
+    fe = []
+    for s in range(2):
+        nz = (synth.splitmix64(555 + s, 0, base.size) % np.uint64(13)).astype(np.int16).reshape(base.shape) - 6
+        fe.append(ref.extract(np.clip(base + nz, 0, 255).astype(np.uint8)))
+    (ka, da), (kb, db) = fe
+    assert len(ka) > 4500 and len(kb) > 4500
+    fva, ta = _fv(da)
+    fvb, tb = _fv(db)
+    valid = synth.synth_valid_flags(len(ka), 3)
+    m = capi.Matcher(0.7, True)
+    wn, wm = oracle.search_by_bow(da, ka["angle"], valid, fva, db, kb["angle"], fvb, 0.7, True)
+    n, out = m.search_by_bow(da, ka["angle"], valid, ta, db, kb["angle"], tb)
+    assert n == wn and np.array_equal(out, wm) and n > 500
