@@ -93,6 +93,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=200, help="timed frames of the single-thread cpu_baseline (+10 warm-up)")
     ap.add_argument("--no-cpu-all-cores", action="store_true")
+    ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive host_in_host_out_fps measurement "
+                    "(profiling runs: keeps every kernel launch at the benchmark's batch size)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) or gloo (CPU rehearsal of the N>1 path)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses GPU 0")
     ap.add_argument("--master-port", type=int, default=29511)
@@ -258,7 +260,7 @@ def run_c4(args, rank, local_rank, world, dev, comm_dev, dist):
     # ---- PCIe-inclusive host path (never `value`): the same B frames from HOST memory through orb_extract_batch
     # (chunked H2D | kernel chain | D2H pipeline), once with pinned and once with pageable caller buffers; extract only
     host_fps = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_host_path:
         host_fps = {}
         fr = frames_sets[0]
         for kind in ("pinned", "pageable"):

@@ -345,6 +345,10 @@ int orb_stereo_match_device(orb_extractor* left, orb_extractor* right, int frame
                             const orb_keypoint* d_kps_r, const uint8_t* d_desc_r, int n_r,
                             float mb, float mbf, float* d_u_right, float* d_depth);
 
+/* Diagnostics of the last synchronised batch: per level, how many FAST strips overflowed their candidate queue and were
+ * redone by the dense kernel (same results, more time), and how many strips a frame has on that level. */
+int orb_get_fast_overflows(orb_extractor* h, int32_t* overflowed, int32_t* strips_per_frame);
+
 /* The whole pyramid of device-resident frame `frame` of the last batch with ONE device-to-host copy and one
  * synchronisation (the reference keeps it in the public member mvImagePyramid, include/ORBextractor.h:86, read by
  * Frame::ComputeStereoMatches, src/Frame.cc:520,611,626,633).  Level l of the copy starts at dst + offsets[l], has

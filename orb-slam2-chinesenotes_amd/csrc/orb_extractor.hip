@@ -157,9 +157,11 @@ extern "C" int orb_extractor_create(const orb_extractor_params* p, int device_id
     h->invSigma2 = h->tables.invSigma2; h->quota = h->tables.quota;
     std::memcpy(h->umax, h->tables.umax, sizeof(h->umax));
     {
-        int k = 3;
+        // cells per FAST strip: 3, and 2 on the coarse levels (scale >= 2.4: several times more corners per pixel, so
+        // three cells overflow the candidate queue now and then -- few cells live there, the shorter strips cost ~1 %)
+        int k = 0;
         if (const char* e = std::getenv("ORB_FAST_STRIP")) { k = std::max(1, std::min(8, std::atoi(e))); h->fastStripFixed = true; }
-        for (int l = 0; l < ORB_MAX_LEVELS; l++) h->fastStripK[l] = k;
+        for (int l = 0; l < ORB_MAX_LEVELS; l++) h->fastStripK[l] = k ? k : ((l < h->prm.nlevels && h->scale[l] >= 2.4f) ? 2 : 3);
     }
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete h; orb_set_error("hipStreamCreate: %s", hipGetErrorString(e)); return ORB_ERR_HIP; }
@@ -390,7 +392,7 @@ int orb_check_status(orb_extractor* h)
         const int* ovf = err + (size_t)(1 + 2 * ORB_MAX_LEVELS) * n + 8;
         bool changed = false;
         for (int l = 0; l < h->prm.nlevels; l++)
-            if (h->fastStripK[l] > 1 && (long long)ovf[l] * 8 > (long long)h->fastStripsOfLevel[l] * n) {
+            if (h->fastStripK[l] > 1 && ovf[l] > 0) {   // one redone strip already costs the batch ~35 us of serial latency
                 h->fastStripK[l]--;
                 changed = true;
             }
@@ -622,6 +624,19 @@ extern "C" void* orb_host_alloc(size_t bytes)
 extern "C" void orb_host_free(void* p)
 {
     if (p) (void)hipHostFree(p);
+}
+
+// diagnostics: FAST strips per level of the last SYNCHRONISED batch that overflowed their candidate queue and were redone
+// by k_fast_strips_dense (results are the same either way; many overflows cost time), and strips per level and frame
+extern "C" int orb_get_fast_overflows(orb_extractor* h, int32_t* overflowed, int32_t* strips_per_frame)
+{
+    if (!h || h->hStat.size() < orb_extractor::statInts(h->lastFrames) || !h->statFetched) return ORB_ERR_INVALID;
+    const int* ovf = h->hStat.data() + orb_extractor::kStickyInts + (size_t)(1 + 2 * ORB_MAX_LEVELS) * h->lastFrames + 8;
+    for (int l = 0; l < h->prm.nlevels; l++) {
+        if (overflowed) overflowed[l] = ovf[l];
+        if (strips_per_frame) strips_per_frame[l] = h->fastStripsOfLevel[l];
+    }
+    return ORB_OK;
 }
 
 extern "C" int orb_get_level_counts(orb_extractor* h, int frame, int32_t* kept, int32_t* cands)

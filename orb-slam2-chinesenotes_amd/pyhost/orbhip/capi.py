@@ -61,7 +61,7 @@ SYMBOLS = [
     "orb_extractor_create", "orb_extractor_destroy", "orb_extractor_get_tables", "orb_extractor_max_keypoints",
     "orb_extractor_set_pattern", "orb_extractor_set_pattern_device", "orb_builtin_pattern", "orb_extract",
     "orb_extract_batch", "orb_extract_batch_device", "orb_extractor_sync", "orb_get_pyramid_level",
-    "orb_get_level_counts", "orb_get_pyramid", "orb_host_alloc", "orb_host_free", "orb_extractor_set_profiling", "orb_extractor_get_stage_ms", "orb_extractor_profiled_frames", "orb_extractor_stream",
+    "orb_get_level_counts", "orb_get_fast_overflows", "orb_get_pyramid", "orb_host_alloc", "orb_host_free", "orb_extractor_set_profiling", "orb_extractor_get_stage_ms", "orb_extractor_profiled_frames", "orb_extractor_stream",
     "orb_hamming", "orb_three_maxima", "orb_matcher_create", "orb_matcher_destroy", "orb_matcher_sync",
     "orb_match_bow", "orb_match_bow_kk", "orb_match_init", "orb_match_projection", "orb_match_projection_best", "orb_match_triangulation", "orb_vocab_create", "orb_vocab_destroy", "orb_vocab_level_nodes", "orb_bow_transform",
     "orb_bow_transform_device", "orb_distinctive_descriptors", "orb_distinctive_descriptors_device", "orb_bow_assign_device", "orb_match_bow_batch_device", "orb_bow_build_csr_device",
@@ -96,6 +96,7 @@ def lib():
     L.orb_extractor_sync.argtypes = [vp]
     L.orb_get_pyramid_level.argtypes = [vp, ci, ci, vp, sz, C.POINTER(ci), C.POINTER(ci)]
     L.orb_get_level_counts.argtypes = [vp, ci, vp, vp]
+    L.orb_get_fast_overflows.argtypes = [vp, vp, vp]
     L.orb_get_pyramid.argtypes = [vp, ci, vp, sz, C.POINTER(sz), vp, vp, vp, vp]
     L.orb_host_alloc.argtypes = [sz]
     L.orb_host_alloc.restype = vp
@@ -278,6 +279,11 @@ class Extractor:
         buf = np.zeros(need.value, np.uint8)
         _check(self.L.orb_get_pyramid(self.h, frame, _p(buf), need.value, C.byref(need), _p(off), _p(pit), _p(rw), _p(cl)))
         return [buf[off[l]:off[l] + pit[l] * rw[l]].reshape(rw[l], pit[l])[:, :cl[l]] for l in range(nl)]
+
+    def fast_overflows(self):
+        o = np.zeros(self.nlevels, np.int32); s = np.zeros(self.nlevels, np.int32)
+        _check(self.L.orb_get_fast_overflows(self.h, _p(o), _p(s)))
+        return o, s
 
     def level_counts(self, frame=0):
         kept = np.zeros(self.nlevels, np.int32)
