@@ -254,7 +254,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
 {
     extern __shared__ uint32_t msm[];
     // carve-up: keysA[cap] keysB[cap] tmp[cap] cntw[nNodes] (u32) | startA cntA startB cntB [nNodes] (u16) |
-    //           res[cap] (i16) | bin[cap] takenB[cap] (u8)
+    //           res[cap] (i16) | bin[cap] takenB[cap] okA[cap] (u8)
     uint32_t* keysA = msm;
     uint32_t* keysB = keysA + capLds;
     uint32_t* tmp = keysB + capLds;
@@ -266,6 +266,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     int16_t* res = reinterpret_cast<int16_t*>(cntB + nNodes);
     uint8_t* bin = reinterpret_cast<uint8_t*>(res + capLds);
     uint8_t* takenB = bin + capLds;
+    uint8_t* okALds = takenB + capLds;                // A-side "has a good MapPoint" flags (:590-595), read once
     __shared__ int hist[HISTO_LENGTH];
     __shared__ int keepBins[3];
     __shared__ int nm;
@@ -281,6 +282,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     const int nRes = KK ? A.n : B.n;
     for (int i = tid; i < nRes; i += blockDim.x) { res[i] = -1; bin[i] = 0xFF; }
     for (int i = tid; i < B.n; i += blockDim.x) takenB[i] = (KK && B.valid && !B.valid[i]) ? 1 : 0;   // :750
+    for (int i = tid; i < A.n; i += blockDim.x) okALds[i] = (A.valid && !A.valid[i]) ? 0 : 1;
     if (tid < HISTO_LENGTH) hist[tid] = 0;
     if (tid == 0) { nm = 0; nextNode = 0; }
     load_or_build_csr(A, nNodes, keysA, tmp, cntw, startA, cntA);
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
                     okAg[g] = false;
                     if (p < na) {
                         iAg[g] = (int)(keysA[a0 + p] & 0xFFFFu);
-                        okAg[g] = !(A.valid && !A.valid[iAg[g]]);      // :590-595
+                        okAg[g] = okALds[iAg[g]] != 0;                // :590-595
                         if (okAg[g]) load_desc(A.desc + (size_t)iAg[g] * 32, dA[g]);
                     }
                 }
@@ -364,23 +366,28 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
                                     takenB[jB] = 1;
                                     const int rIdx = KK ? iA : jB;
                                     res[rIdx] = (int16_t)(KK ? jB : iA);
-                                    if (checkOri)
-                                        bin[rIdx] = (uint8_t)rot_bin(A.angle[(size_t)iA * A.angleStride], B.angle[(size_t)jB * B.angleStride]);
                                 }
                             }
                         }
                     }
                 }
             }
-        } else if (nb <= WAVE) {
-            // ---- medium node: the node's B features fit the wave; everything stays in registers
-            uint32_t dB[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            int jB = -1;
-            bool taken = true;
+        } else if (nb <= 2 * WAVE) {
+            // ---- medium node: the node's B features fit the wave's registers, one or two per lane (positions lane and
+            // lane + 64); nothing in the serial A loop touches memory
+            uint32_t dB0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dB1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            int jB0 = -1, jB1 = -1;
+            bool taken0 = true, taken1 = true;
             if (lane < nb) {
-                jB = (int)(keysB[b0 + lane] & 0xFFFFu);
-                load_desc(B.desc + (size_t)jB * 32, dB);
-                taken = takenB[jB] != 0;
+                jB0 = (int)(keysB[b0 + lane] & 0xFFFFu);
+                load_desc(B.desc + (size_t)jB0 * 32, dB0);
+                taken0 = takenB[jB0] != 0;
+            }
+            const bool two = nb > WAVE;                            // wave-uniform
+            if (lane + WAVE < nb) {
+                jB1 = (int)(keysB[b0 + WAVE + lane] & 0xFFFFu);
+                load_desc(B.desc + (size_t)jB1 * 32, dB1);
+                taken1 = takenB[jB1] != 0;
             }
             for (int abase = 0; abase < na; abase += WAVE) {
                 const int nChunk = min(WAVE, na - abase);
@@ -389,42 +396,51 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
                 bool okA = false;
                 if (lane < nChunk) {
                     iAl = (int)(keysA[a0 + abase + lane] & 0xFFFFu);
-                    okA = !(A.valid && !A.valid[iAl]);                     // :590-595
+                    okA = okALds[iAl] != 0;                               // :590-595
                     if (okA) load_desc(A.desc + (size_t)iAl * 32, dA);
                 }
                 const unsigned long long okMask = __ballot(okA);
                 for (int p = 0; p < nChunk; p++) {
                     if (!((okMask >> p) & 1)) continue;
-                    unsigned d = 256u;
-                    if (!taken) {
-                        d = 0;
+                    uint32_t a8[8];
 #pragma unroll
-                        for (int w = 0; w < 8; w++) d += __popc(dB[w] ^ (uint32_t)__builtin_amdgcn_readlane((int)dA[w], p));
+                    for (int w = 0; w < 8; w++) a8[w] = (uint32_t)__builtin_amdgcn_readlane((int)dA[w], p);
+                    unsigned d0 = 256u, d1 = 256u;
+                    if (!taken0) {
+                        d0 = 0;
+#pragma unroll
+                        for (int w = 0; w < 8; w++) d0 += __popc(dB0[w] ^ a8[w]);
                     }
-                    const unsigned mine = (d << 16) | (unsigned)lane;
-                    const unsigned m1 = orb_wave_umin(mine);
-                    const unsigned m2 = orb_wave_umin(mine == m1 ? 0xFFFFFFFFu : mine);
-                    const int best1 = (int)(m1 >> 16), best2 = (int)(m2 >> 16);      // 256 when nothing is left
-                    const bool pass = KK ? (best1 < TH_LOW) : (best1 <= TH_LOW);      // :772 vs :625
+                    if (two && !taken1) {
+                        d1 = 0;
+#pragma unroll
+                        for (int w = 0; w < 8; w++) d1 += __popc(dB1[w] ^ a8[w]);
+                    }
+                    // packed (distance << 16 | position): the lane's smaller and larger value, then the wave's two smallest
+                    const unsigned v0 = (d0 << 16) | (unsigned)lane, v1 = (d1 << 16) | (unsigned)(lane + WAVE);
+                    const unsigned lo = min(v0, v1), hi = max(v0, v1);
+                    const unsigned m1 = orb_wave_umin(lo);
+                    const unsigned m2 = orb_wave_umin(lo == m1 ? hi : lo);
+                    const int best1 = (int)(m1 >> 16), best2 = (int)min(256u, m2 >> 16);   // 256 when nothing is left
+                    const bool pass = KK ? (best1 < TH_LOW) : (best1 <= TH_LOW);          // :772 vs :625
                     if (pass && (float)best1 < __fmul_rn(ratio, (float)best2)) {
                         const int win = (int)(m1 & 0xFFFFu);
                         const int iA = __builtin_amdgcn_readlane(iAl, p);
-                        if (lane == win) {
-                            taken = true;
+                        if ((win & (WAVE - 1)) == lane) {
+                            const int jB = win < WAVE ? jB0 : jB1;
+                            if (win < WAVE) taken0 = true; else taken1 = true;
                             takenB[jB] = 1;
                             const int rIdx = KK ? iA : jB;
                             res[rIdx] = (int16_t)(KK ? jB : iA);
-                            if (checkOri)
-                                bin[rIdx] = (uint8_t)rot_bin(A.angle[(size_t)iA * A.angleStride], B.angle[(size_t)jB * B.angleStride]);
                         }
                     }
                 }
             }
         } else {
-            // ---- general path (> 64 B features in one node): chunked, taken flags in LDS
+            // ---- general path (> 128 B features in one node): chunked, taken flags in LDS
             for (int p = a0; p < a0 + na; p++) {
                 const int iA = (int)(keysA[p] & 0xFFFFu);
-                if (A.valid && !A.valid[iA]) continue;
+                if (!okALds[iA]) continue;
                 uint32_t dA[8], dB[8];
                 load_desc(A.desc + (size_t)iA * 32, dA);
                 unsigned best = (256u << 16) | 0xFFFFu, second = 256u;
@@ -453,8 +469,6 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
                         takenB[jB] = 1;
                         const int rIdx = KK ? iA : jB;
                         res[rIdx] = (int16_t)(KK ? jB : iA);
-                        if (checkOri)
-                            bin[rIdx] = (uint8_t)rot_bin(A.angle[(size_t)iA * A.angleStride], B.angle[(size_t)jB * B.angleStride]);
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -465,11 +479,18 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     __syncthreads();
 
     // ---- rotation histogram + top-3 filter (:663-684)
+    // the rotation bin of every match (:634-641) is computed here, for all matches at once: inside the node loop the two
+    // angle loads were a dependent global round trip per accepted match
     int local = 0;
     for (int i = tid; i < nRes; i += blockDim.x)
         if (res[i] >= 0) {
             local++;
-            if (checkOri) atomicAdd(&hist[bin[i]], 1);
+            if (checkOri) {
+                const int iA = KK ? i : res[i], jB = KK ? res[i] : i;
+                const int bb = rot_bin(A.angle[(size_t)iA * A.angleStride], B.angle[(size_t)jB * B.angleStride]);
+                bin[i] = (uint8_t)bb;
+                atomicAdd(&hist[bb], 1);
+            }
         }
     if (local) atomicAdd(&nm, local);
     __syncthreads();
@@ -524,7 +545,7 @@ __global__ void k_fill_sides(orb_featstore S, const int32_t* __restrict__ kfInde
 // ------------------------------------------------------------------ host side
 static size_t match_lds_bytes(int capLds, int nNodes)
 {
-    return (size_t)capLds * (4 + 4 + 4 + 2 + 1 + 1) + (size_t)nNodes * (4 + 8) + 16;
+    return (size_t)capLds * (4 + 4 + 4 + 2 + 1 + 1 + 1) + (size_t)nNodes * (4 + 8) + 16;
 }
 
 extern "C" int orb_matcher_create(int device_id, orb_matcher** out)

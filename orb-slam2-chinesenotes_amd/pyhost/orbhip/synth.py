@@ -163,3 +163,80 @@ def synth_vocab_tree_balanced(k: int = 10, L: int = 6, seed: int = 0xB0CAB) -> d
     word_id[leaves] = np.arange(leaves.size, dtype=np.int32)
     node_desc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
     return dict(node_desc=node_desc, child_begin=child_begin.astype(np.int32), children=children, word_id=word_id, L=L, k=k)
+
+
+_POP8 = np.array([bin(i).count("1") for i in range(256)], np.uint16)
+
+
+def _hamming_to(desc: np.ndarray, cent: np.ndarray) -> np.ndarray:
+    """(n, 32) u8 x (k, 32) u8 -> (n, k) Hamming distances."""
+    return _POP8[desc[:, None, :] ^ cent[None, :, :]].sum(axis=2)
+
+
+def _k_majority(desc: np.ndarray, k: int, rng, iters: int = 8) -> np.ndarray:
+    """k-means in Hamming space with bitwise-majority centroids (what DBoW2's training does for binary descriptors);
+    returns (k, 32) u8 centroids.  Empty clusters are re-seeded from the largest one."""
+    n = desc.shape[0]
+    cent = desc[rng.choice(n, k, replace=n < k)].copy()
+    bits = np.unpackbits(desc, axis=1)
+    for _ in range(iters):
+        lab = _hamming_to(desc, cent).argmin(axis=1)
+        for c in range(k):
+            m = lab == c
+            if not m.any():
+                big = np.bincount(lab, minlength=k).argmax()
+                cent[c] = desc[rng.choice(np.nonzero(lab == big)[0])]
+                continue
+            cent[c] = np.packbits(bits[m].mean(axis=0) >= 0.5)
+    return cent
+
+
+def synth_vocab_tree_trained(desc_sample: np.ndarray, k: int = 10, L: int = 6, seed: int = 0xB0CAB) -> dict:
+    """A complete k-ary tree of depth L in the layout of synth_vocab_tree whose two top levels are TRAINED on a sample
+    of descriptors by hierarchical k-majority clustering, as a DBoW2 vocabulary is (ORBvoc itself is absent): the
+    level-2 nodes -- the FeatureVector nodes SearchByBoW iterates over at levelsup = 4 -- then hold a few features of
+    a frame each (the regime the reference runs in, "~10 features per node").  A tree of uniformly random node
+    descriptors is badly unbalanced instead: real descriptors are not uniform, one node swallows a quarter of a frame.
+    Levels 3..L are seeded random refinements of their parent (a shrinking number of flipped bits), so the descent does
+    the full 6 x 10 Hamming comparisons per feature.  Node ids are permuted as in synth_vocab_tree_balanced."""
+    rng = np.random.default_rng(seed)
+    desc_sample = np.ascontiguousarray(desc_sample, np.uint8)
+    n_inner = (k ** L - 1) // (k - 1)
+    n = n_inner + k ** L
+    bfs_desc = np.zeros((n, 32), np.uint8)
+    c1 = _k_majority(desc_sample, k, rng)
+    bfs_desc[1:1 + k] = c1
+    lab1 = _hamming_to(desc_sample, c1).argmin(axis=1)
+    for a in range(k):
+        sub = desc_sample[lab1 == a]
+        if sub.shape[0] < k:
+            sub = desc_sample
+        b0 = k * (1 + a) + 1                                       # BFS index of the first child of level-1 node a
+        bfs_desc[b0:b0 + k] = _k_majority(sub, k, rng)
+    flips = [0, 0, 0, 24, 16, 10, 6, 4, 3, 2]
+    level_start = [(k ** d - 1) // (k - 1) for d in range(L + 2)]
+    for d in range(3, L + 1):
+        lo, hi = level_start[d], level_start[d + 1]
+        parents = (np.arange(lo, hi) - 1) // k
+        child = bfs_desc[parents].copy()
+        nb = flips[min(d, len(flips) - 1)]
+        pos = rng.integers(0, 256, (hi - lo, nb))
+        for j in range(nb):
+            child[np.arange(hi - lo), pos[:, j] >> 3] ^= (1 << (pos[:, j] & 7)).astype(np.uint8)
+        bfs_desc[lo:hi] = child
+    t = synth_vocab_tree_balanced(k, L, seed)                       # the id permutation and the topology
+    # synth_vocab_tree_balanced draws perm first from the same seed: recover BFS index of every node id from its children
+    cb, ch = t["child_begin"], t["children"]
+    inv = np.full(n, -1, np.int64)                                  # node id -> BFS index
+    inv[0] = 0
+    frontier = np.array([0])
+    while frontier.size:
+        kids_cnt = cb[frontier + 1] - cb[frontier]
+        par = frontier[kids_cnt > 0]
+        if par.size == 0:
+            break
+        kid_ids = ch[(cb[par][:, None] + np.arange(k)[None, :])]
+        inv[kid_ids] = inv[par][:, None] * k + 1 + np.arange(k)[None, :]
+        frontier = kid_ids.reshape(-1)
+    t["node_desc"] = bfs_desc[inv]
+    return t
