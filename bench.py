@@ -194,7 +194,7 @@ def run_c4(args, rank, local_rank, world, dev, comm_dev, dist):
                   nodeof=torch.zeros(B * cap, dtype=torch.int16, device=dev), match=torch.zeros(B * cap, dtype=torch.int32, device=dev),
                   nm=torch.zeros(B, dtype=torch.int32, device=dev), set=0,
                   ckeys=torch.zeros(B * cap, dtype=torch.int32, device=dev), cstart=torch.zeros(B * n_nodes, dtype=torch.int16, device=dev),
-                  ccnt=torch.zeros(B * n_nodes, dtype=torch.int16, device=dev))
+                  ccnt=torch.zeros(B * n_nodes, dtype=torch.int16, device=dev), words=torch.zeros(B * cap, dtype=torch.int32, device=dev))
         ln["store"] = dict(desc=ln["desc"].data_ptr(), kps=ln["kps"].data_ptr(), valid=d_valid.data_ptr(),
                            counts=ln["counts"].data_ptr(), node_of=ln["nodeof"].data_ptr(), cap=cap, n_frames=B, n_nodes=n_nodes,
                            csr_keys=ln["ckeys"].data_ptr(), csr_start=ln["cstart"].data_ptr(), csr_cnt=ln["ccnt"].data_ptr())
@@ -221,7 +221,9 @@ def run_c4(args, rank, local_rank, world, dev, comm_dev, dist):
                                 ln["counts"].data_ptr())
         if not args.no_match:
             lm.wait_for(lx.stream)
-            voc.transform_device(lm, ln["desc"].data_ptr(), ln["counts"].data_ptr(), B, cap, 4, d_node_of=ln["nodeof"].data_ptr())
+            # word id (the BowVector's key) and level-(L-4) node (the FeatureVector's key) of every feature: the full descent
+            voc.transform_device(lm, ln["desc"].data_ptr(), ln["counts"].data_ptr(), B, cap, 4, d_word_of=ln["words"].data_ptr(),
+                                 d_node_of=ln["nodeof"].data_ptr())
             # the FeatureVector of every frame once (Frame::ComputeBoW), not once per pair inside the matcher
             lm.build_csr_device(ln["nodeof"].data_ptr(), ln["counts"].data_ptr(), B, cap, n_nodes, ln["ckeys"].data_ptr(),
                                 ln["cstart"].data_ptr(), ln["ccnt"].data_ptr())
