@@ -36,30 +36,50 @@ def kname(n):
     return n.split("(")[0].split("<")[0]
 
 
+def first_batch_dispatch(d):
+    """bench.py first extracts a handful of frames to train its vocabulary; the benchmark's own launches start with the
+    first k_copy_level0 of the full batch size.  Dispatches before that one are left out of every average."""
+    rows = []
+    for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
+        rows += [r for r in csv.DictReader(open(f)) if kname(r["Kernel_Name"]) == "k_copy_level0"]
+    if not rows:
+        return 0
+    size = lambda r: int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
+    big = max(size(r) for r in rows)
+    return min(int(r["Dispatch_Id"]) for r in rows if size(r) == big)
+
+
 def counters(d):
-    """{kernel: {counter: average per launch}}, plus launches per kernel"""
+    """{kernel: {counter: average per launch}} over the benchmark's own launches"""
+    cut = first_batch_dispatch(d)
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            agg[kname(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            if int(r["Dispatch_Id"]) >= cut:
+                agg[kname(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in agg.items() if k.startswith("k_")}
 
 
 def kernel_stats(d):
-    rows = []
-    for f in glob.glob(d + "/**/*kernel_stats.csv", recursive=True):
-        for r in csv.DictReader(open(f)):
-            rows.append((kname(r["Name"]), int(r["Calls"]), float(r["AverageNs"]), float(r["TotalDurationNs"]),
-                         float(r["Percentage"])))
-    return rows
-
-
-def durations(d):
-    """average duration (ns) per kernel from a pass's kernel_trace"""
+    """(kernel, calls, avg ns, total ns, percent) from the kernel trace of the --stats pass, benchmark launches only"""
+    cut = first_batch_dispatch(d)
     agg = collections.defaultdict(list)
     for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            agg[kname(r["Kernel_Name"])].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+            if int(r["Dispatch_Id"]) >= cut:
+                agg[kname(r["Kernel_Name"])].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+    tot = sum(sum(v) for k, v in agg.items() if k.startswith("k_")) or 1.0
+    return [(k, len(v), sum(v) / len(v), sum(v), 100.0 * sum(v) / tot) for k, v in agg.items()]
+
+
+def durations(d):
+    """average duration (ns) per kernel from a pass's kernel_trace, benchmark launches only"""
+    cut = first_batch_dispatch(d)
+    agg = collections.defaultdict(list)
+    for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if int(r["Dispatch_Id"]) >= cut:
+                agg[kname(r["Kernel_Name"])].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
     return {k: sum(v) / len(v) for k, v in agg.items()}
 
 
