@@ -89,7 +89,13 @@ int orb_extract(orb_extractor* h, const uint8_t* img, int rows, int cols, size_t
 
 /* Batched-frames mode, host buffers (frames are independent: reference operator() carries no
  * state across calls except mvImagePyramid, which is overwritten).  Frame f starts at
- * imgs + f*frame_stride.  kps/desc32 hold n_frames*cap entries; counts[n_frames]. */
+ * imgs + f*frame_stride.  kps/desc32 hold n_frames*cap entries; counts[n_frames].
+ * Batches of 16 frames or more run as a pipeline of chunks (host-to-device copy of chunk k+1 beside the kernels of
+ * chunk k beside the copy back of chunk k-1); caller buffers that are pinned (orb_host_alloc, hipHostRegister) are
+ * copied from / to directly, pageable ones through the handle's pinned staging.  Afterwards the device holds the
+ * LAST chunk only: orb_get_pyramid* / orb_stereo_match address frames of that chunk (by their index in the batch).
+ * A single frame (the reference's per-call path) is replayed as a captured HIP graph from the third call of one
+ * image size on (environment variable ORB_NO_GRAPH=1 keeps it eager); results are identical. */
 int orb_extract_batch(orb_extractor* h, const uint8_t* imgs, int n_frames, int rows, int cols,
                       size_t row_stride, size_t frame_stride,
                       orb_keypoint* kps, uint8_t* desc32, int cap, int32_t* counts);
@@ -119,8 +125,8 @@ int orb_get_level_counts(orb_extractor* h, int frame, int32_t* kept, int32_t* ca
  * stages: 0 pyramid, 1 FAST cells, 2 quadtree, 3 orientation+descriptors, 4 total. */
 int orb_extractor_set_profiling(orb_extractor* h, int enable);
 int orb_extractor_get_stage_ms(orb_extractor* h, float* ms5);
-/* Large batches are cut into sub-batches that run the kernel chain on separate streams; the stage
- * times above are those of sub-batch 0.  This returns how many frames each timed launch covered. */
+/* How many frames each timed launch covered: the batch size of the last profiled orb_extract_batch_device call
+ * (a batch is ONE launch chain on the handle's stream; host batches are chunked, see orb_extract_batch). */
 int orb_extractor_profiled_frames(const orb_extractor* h);
 
 /* The HIP stream (hipStream_t) the handle launches on, for callers that need to order their own
