@@ -75,6 +75,12 @@ __device__ __forceinline__ unsigned pk_add_u16(unsigned a, unsigned b)
     asm("v_pk_add_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
     return d;
 }
+__device__ __forceinline__ unsigned pk_add_u16_s(unsigned a, unsigned sUniform)
+{
+    unsigned d;
+    asm("v_pk_add_u16 %0, %1, %2" : "=v"(d) : "v"(a), "s"(sUniform));
+    return d;
+}
 __device__ __forceinline__ unsigned pk_max_i16(unsigned a, unsigned b)
 {
     unsigned d;
@@ -236,56 +242,56 @@ __device__ __forceinline__ void fast_detect(const OrbStrip& S, const uint32_t* t
     const unsigned thK = (unsigned)(0x7fff - lowTh) * 0x10001u;
     const int nItems = nq * zh;
     int cntA = 0, cntB = 0, headA = 0, headB = 0;                  // wave-uniform ring state
-    // item -> (zone row ry, quad qi) is advanced incrementally (64 items per step): no per-item division
-    int ry = (int)(((unsigned)lane * S.invQ) >> 20);
-    int qi = lane - ry * nq;
+    // item -> (zone row, quad) is advanced incrementally (64 items per step), as ONE packed counter ent = row << 8 | quad
+    // (also the queue entry) and ONE running dword offset of the item's window: no per-item division or multiply
+    const int ry0 = (int)(((unsigned)lane * S.invQ) >> 20), qi0 = lane - ry0 * nq;
     const int stepR = S.stepR, stepQ = WAVE - stepR * nq;
+    const int qHi = qLo + nq;
+    int ent = ((3 + ry0) << 8) | (qLo + qi0);
+    int pOff = (3 + ry0) * FT_PDW + qLo + qi0 - 1;
+    const int entStep = (stepR << 8) + stepQ, offStep = stepR * FT_PDW + stepQ;
+    const int entWrap = 256 - nq, offWrap = FT_PDW - nq;
+    const int offMax = (3 + zh - 1) * FT_PDW + qHi - 2;            // lanes past the last item read here (results unused)
     for (int base = 0;; base += WAVE) {
         const bool more = base < nItems;
         if (more) {
-            const int item = base + lane;
-            bool pa = false, pb = false;
-            const int q = qLo + qi;
-            const int row = 3 + ry;
-            if (item < nItems) {
-                const uint32_t* p = tileDw + row * FT_PDW + q - 1;
-                const unsigned c0 = p[0], c1 = p[1], c2 = p[2];                                   // row y
-                const unsigned u1 = p[-3 * FT_PDW + 1], d1 = p[3 * FT_PDW + 1];                   // rows y-3, y+3: x .. x+3
-                const unsigned a0 = p[-2 * FT_PDW], a1 = p[-2 * FT_PDW + 1], a2 = p[-2 * FT_PDW + 2];   // row y-2
-                const unsigned b0 = p[2 * FT_PDW], b1 = p[2 * FT_PDW + 1], b2 = p[2 * FT_PDW + 2];      // row y+2
-                if (DENSE) smapQ[row * sdw + q] = 0;
-                unsigned u[2];
+            const uint32_t* p = tileDw + min(pOff, offMax);
+            const unsigned c0 = p[0], c1 = p[1], c2 = p[2];                                   // row y
+            const unsigned u1 = p[-3 * FT_PDW + 1], d1 = p[3 * FT_PDW + 1];                   // rows y-3, y+3: x .. x+3
+            const unsigned a0 = p[-2 * FT_PDW], a1 = p[-2 * FT_PDW + 1], a2 = p[-2 * FT_PDW + 2];   // row y-2
+            const unsigned b0 = p[2 * FT_PDW], b1 = p[2 * FT_PDW + 1], b2 = p[2 * FT_PDW + 2];      // row y+2
+            const bool valid = base + lane < nItems;
+            if (DENSE && valid) smapQ[(ent >> 8) * sdw + (ent & 0xff)] = 0;
+            unsigned u[2];
 #pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    // window byte index of the pair's first pixel: 4 (pixels 4q,4q+1) or 6 (4q+2,4q+3)
-                    const unsigned cc = h ? pick2<6>(c0, c1, c2) : pick2<4>(c0, c1, c2);
-                    const unsigned r0 = h ? pick2<6>(0, d1, 0) : pick2<4>(0, d1, 0);              // k=0  (0,+3)
-                    const unsigned r8 = h ? pick2<6>(0, u1, 0) : pick2<4>(0, u1, 0);              // k=8  (0,-3)
-                    const unsigned r4 = h ? pick2<9>(c0, c1, c2) : pick2<7>(c0, c1, c2);          // k=4  (+3,0)
-                    const unsigned r12 = h ? pick2<3>(c0, c1, c2) : pick2<1>(c0, c1, c2);         // k=12 (-3,0)
-                    const unsigned r2 = h ? pick2<8>(b0, b1, b2) : pick2<6>(b0, b1, b2);          // k=2  (+2,+2)
-                    const unsigned r10 = h ? pick2<4>(a0, a1, a2) : pick2<2>(a0, a1, a2);         // k=10 (-2,-2)
-                    const unsigned r6 = h ? pick2<8>(a0, a1, a2) : pick2<6>(a0, a1, a2);          // k=6  (+2,-2)
-                    const unsigned r14 = h ? pick2<4>(b0, b1, b2) : pick2<2>(b0, b1, b2);         // k=14 (-2,+2)
-                    const unsigned mlo = pk_max3(pk_min2(r0, r8), pk_min2(r4, r12), pk_max2(pk_min2(r2, r10), pk_min2(r6, r14)));
-                    const unsigned mhi = pk_min3(pk_max2(r0, r8), pk_max2(r4, r12), pk_min2(pk_max2(r2, r10), pk_max2(r6, r14)));
-                    u[h] = pk_max_i16(pk_sub_i16(cc, mlo), pk_sub_i16(mhi, cc));                  // U per 16-bit half (signed)
-                }
-                // a pair is queued if one of its pixels has U > lowTh: adding 0x7fff - lowTh to a signed half in
-                // [-255, 255] sets bit 15 exactly then.  Pixels of a neighbouring strip inside an edge quad may queue
-                // a pair needlessly; phase B zeroes their scores, so zone membership is not tested here.
-                pa = (pk_add_u16(u[0], thK) & 0x80008000u) != 0;
-                pb = (pk_add_u16(u[1], thK) & 0x80008000u) != 0;
+            for (int h = 0; h < 2; h++) {
+                // window byte index of the pair's first pixel: 4 (pixels 4q,4q+1) or 6 (4q+2,4q+3)
+                const unsigned cc = h ? pick2<6>(c0, c1, c2) : pick2<4>(c0, c1, c2);
+                const unsigned r0 = h ? pick2<6>(0, d1, 0) : pick2<4>(0, d1, 0);              // k=0  (0,+3)
+                const unsigned r8 = h ? pick2<6>(0, u1, 0) : pick2<4>(0, u1, 0);              // k=8  (0,-3)
+                const unsigned r4 = h ? pick2<9>(c0, c1, c2) : pick2<7>(c0, c1, c2);          // k=4  (+3,0)
+                const unsigned r12 = h ? pick2<3>(c0, c1, c2) : pick2<1>(c0, c1, c2);         // k=12 (-3,0)
+                const unsigned r2 = h ? pick2<8>(b0, b1, b2) : pick2<6>(b0, b1, b2);          // k=2  (+2,+2)
+                const unsigned r10 = h ? pick2<4>(a0, a1, a2) : pick2<2>(a0, a1, a2);         // k=10 (-2,-2)
+                const unsigned r6 = h ? pick2<8>(a0, a1, a2) : pick2<6>(a0, a1, a2);          // k=6  (+2,-2)
+                const unsigned r14 = h ? pick2<4>(b0, b1, b2) : pick2<2>(b0, b1, b2);         // k=14 (-2,+2)
+                const unsigned mlo = pk_max3(pk_min2(r0, r8), pk_min2(r4, r12), pk_max2(pk_min2(r2, r10), pk_min2(r6, r14)));
+                const unsigned mhi = pk_min3(pk_max2(r0, r8), pk_max2(r4, r12), pk_min2(pk_max2(r2, r10), pk_max2(r6, r14)));
+                u[h] = pk_max_i16(pk_sub_i16(cc, mlo), pk_sub_i16(mhi, cc));                  // U per 16-bit half (signed)
             }
+            // a pair is queued if one of its pixels has U > lowTh: adding 0x7fff - lowTh to a signed half in
+            // [-255, 255] sets bit 15 exactly then.  Pixels of a neighbouring strip inside an edge quad may queue
+            // a pair needlessly; phase B zeroes their scores, so zone membership is not tested here.
+            const bool pa = valid && (pk_add_u16_s(u[0], thK) & 0x80008000u) != 0;
+            const bool pb = valid && (pk_add_u16_s(u[1], thK) & 0x80008000u) != 0;
             const unsigned long long ba = __ballot(pa), bb = __ballot(pb);
-            const uint16_t ent = (uint16_t)((row << 8) | q);          // queue entries carry (row, quad) directly
-            if (pa) pairQ[(headA + cntA + mbcnt64(ba)) & (FT_QRING - 1)] = ent;
-            if (pb) pairQ[FT_QRING + ((headB + cntB + mbcnt64(bb)) & (FT_QRING - 1))] = ent;
+            if (pa) pairQ[(headA + cntA + mbcnt64(ba)) & (FT_QRING - 1)] = (uint16_t)ent;   // entries carry (row, quad) directly
+            if (pb) pairQ[FT_QRING + ((headB + cntB + mbcnt64(bb)) & (FT_QRING - 1))] = (uint16_t)ent;
             cntA += __popcll(ba);
             cntB += __popcll(bb);
-            qi += stepQ;
-            ry += stepR;
-            if (qi >= nq) { qi -= nq; ry++; }
+            ent += entStep;
+            pOff += offStep;
+            if ((ent & 0xff) >= qHi) { ent += entWrap; pOff += offWrap; }
         }
         // phase B: exact V for queued pairs, a full wave at a time (the last pass flushes the remainders).  LDS
         // operations of one wave execute in order; the barrier only keeps the compiler from reordering them.
