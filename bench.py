@@ -75,8 +75,8 @@ def algorithmic_bytes_per_frame(cols, rows, pyr_px, n_kp):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200, help="timed steps (default 200: a timed region of ~0.35 s at 512 frames per step)")
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="c4", choices=["c4", "c3", "c5"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--input-sets", type=int, default=2,
@@ -252,6 +252,13 @@ def run_c4(args, rank, local_rank, world, dev, comm_dev, dist):
     elapsed = time.perf_counter() - t0
     elapsed = shard.max_over_ranks(dist, elapsed, comm_dev)
     frames_done = shard.sum_over_ranks(dist, B * args.steps, comm_dev)
+    # the same K steps once more, untimed for `value`: a clock ramp or a cold start inside the timed region would show
+    # as a difference between the two
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    full_sync()
+    repeat_ms = (time.perf_counter() - t0) / args.steps * 1e3
 
     # ---- single-lane pass, outside the timed region: per-kernel durations that describe each kernel running alone
     # (HIP events on the extractor's own stream)
@@ -313,6 +320,7 @@ def run_c4(args, rank, local_rank, world, dev, comm_dev, dist):
                    "mean_keypoints": round(mean_kp, 1), "mean_bow_matches": round(float(nm.mean()), 1),
                    "vocabulary": "complete k=10 L=6 tree, top two levels k-majority-trained on 8 frames, %d nodes, %d level-(L-4) nodes" % (tree["node_desc"].shape[0], n_nodes),
                    "frames_per_launch": launch_frames,
+                   "repeat_ms_per_step": round(repeat_ms, 4),
                    "single_lane_ms_per_step": round(single_ms, 4),
                    "single_lane_frames_per_s": round(B / single_ms * 1e3, 1),
                    "stage_ms_per_launch_single_lane": {n: round(float(v), 4) for n, v in zip(STAGES + ["extract_total"], stage_ms)},
