@@ -32,6 +32,31 @@ def test_shims_compile_and_link():
     assert os.path.exists(build_driver())
 
 
+def test_matcher_binding_without_editing_the_reference_source(tmp_path):
+    """INTEGRATION.md section 2, the no-edit recipe: an object that defines the four replaced ORBmatcher functions itself
+    (standing in for the reference's src/ORBmatcher.cc compiled unchanged) gets those four symbols weakened by
+    tools/weaken_matcher_symbols.sh and is linked beside ORBmatcherHip.o: the strong HIP-backed definitions win (checked
+    with DescriptorDistance, which is host-only), everything else in the object stays."""
+    capi.build_library()
+    inc = ["-I" + SUP, "-I" + os.path.join(SUP, "mini_slam"), "-I" + os.path.join(PKG, "host"), "-I" + os.path.join(ROOT, "include")]
+    ref_o, hip_o, main_cpp, exe = (str(tmp_path / n) for n in ("ref.o", "hip.o", "main.cpp", "bind"))
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-c"] + inc + [os.path.join(SUP, "unedited_matcher_standin.cpp"), "-o", ref_o])
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-c"] + inc + [os.path.join(PKG, "host", "ORBmatcherHip.cc"), "-o", hip_o])
+    open(main_cpp, "w").write(
+        '#include <cstdio>\n#include "ORBmatcher.h"\nextern "C" int standin_not_replaced();\n'
+        'int main() { cv::Mat a(1, 32, CV_8UC1), b(1, 32, CV_8UC1);\n'
+        '  for (int i = 0; i < 32; i++) { a.data[i] = (unsigned char)i; b.data[i] = (unsigned char)(i ^ 0x0f); }\n'
+        '  std::printf("%d %d\\n", ORB_SLAM2::ORBmatcher::DescriptorDistance(a, b), standin_not_replaced()); return 0; }\n')
+    # without the weakening the link must fail (duplicate definitions) ...
+    link = ["g++", "-std=c++17"] + inc + [main_cpp, ref_o, hip_o, "-L" + PKG, "-lorbhip", "-Wl,-rpath," + PKG, "-o", exe]
+    assert subprocess.run(link, capture_output=True).returncode != 0
+    # ... with it the HIP-backed functions are the ones linked in
+    subprocess.check_call([os.path.join(ROOT, "tools", "weaken_matcher_symbols.sh"), ref_o])
+    subprocess.check_call(link)
+    out = subprocess.check_output([exe], text=True).split()
+    assert out == ["128", "777"], out                           # 32 bytes x 4 differing bits, not the stand-in's -12345
+
+
 @pytest.mark.gpu
 def test_extractor_shim_matches_oracle(tmp_path):
     build_driver()
