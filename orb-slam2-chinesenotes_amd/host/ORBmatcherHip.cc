@@ -17,6 +17,7 @@
 // to MapPoint*.  No CPU fallback: a failing GPU call throws std::runtime_error.
 #include "ORBmatcher.h"
 
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 
@@ -27,11 +28,19 @@ namespace ORB_SLAM2
 
 namespace
 {
+// the GPU the matcher handles live on: the environment variable ORB_HIP_DEVICE (the same one the extractor shim reads;
+// the reference's constructors have no room for a device index), default 0
+int matcherDevice()
+{
+    const char* e = std::getenv("ORB_HIP_DEVICE");
+    return e ? std::atoi(e) : 0;
+}
+
 struct MatcherHandle {                       // one stream + scratch per host thread (Tracking,
     orb_matcher* m = nullptr;                // LocalMapping and LoopClosing each own a thread)
     MatcherHandle()
     {
-        if (orb_matcher_create(0, &m) != ORB_OK)
+        if (orb_matcher_create(matcherDevice(), &m) != ORB_OK)
             throw std::runtime_error(std::string("ORBmatcher(HIP): orb_matcher_create failed: ") + orb_last_error());
     }
     ~MatcherHandle() { orb_matcher_destroy(m); }
