@@ -366,3 +366,35 @@ def test_large_feature_counts_kitti_size(nf):
     quotas beyond ~1000 make k_quadtree take more than 64 KB of LDS (up to the CU's 160 KB).  Bit-exact at 1241x376."""
     n = _cmp(synth.synth_frame(100, 1241, 376), nfeatures=nf)
     assert n > min(nf, 4000) * 0.8
+
+
+@pytest.mark.parametrize("kind", ["checker1", "checker2", "checker3", "stripes", "blocks", "saltpepper", "gradient_noise", "dots"])
+def test_adversarial_patterns_for_the_strip_detector(kind):
+    """Images built to stress what k_fast_strips does differently from a per-cell loop: every pixel a candidate (pair
+    rings and the candidate queue overflow -> dense kernel), plateaus of equal scores across cell seams (cell-local NMS,
+    iniTh -> minTh fallback decided per cell), corners exactly on zone / strip borders, isolated maxima one pixel from a
+    seam.  Bit-exact against the oracle stage by stage."""
+    rng = np.random.default_rng(sum(ord(c) for c in kind))                # deterministic per pattern
+    H, W = 300, 420
+    yy, xx = np.mgrid[0:H, 0:W]
+    if kind.startswith("checker"):
+        p = int(kind[-1])
+        img = (((yy // p + xx // p) & 1) * 200 + 20).astype(np.uint8)
+    elif kind == "stripes":
+        img = ((((xx + 2 * yy) // 5) & 1) * 120 + 60 + rng.integers(-3, 4, (H, W))).astype(np.uint8)
+    elif kind == "blocks":
+        img = np.kron(rng.integers(0, 256, (H // 6 + 1, W // 6 + 1)), np.ones((6, 6)))[:H, :W].astype(np.uint8)
+    elif kind == "saltpepper":
+        img = np.full((H, W), 128, np.uint8)
+        m = rng.random((H, W))
+        img[m < 0.03] = 255
+        img[m > 0.97] = 0
+    elif kind == "gradient_noise":
+        img = np.clip(xx * 255 // W + rng.integers(-12, 13, (H, W)), 0, 255).astype(np.uint8)
+    else:                                                        # bright dots on a 31-px lattice: one per cell, next to the seams
+        img = np.full((H, W), 40, np.uint8)
+        for dy in range(16, H - 16, 31):
+            for dx in range(16, W - 16, 31):
+                img[dy + 3:dy + 5, dx + 3:dx + 5] = 250
+                img[dy + 29:dy + 31, dx + 29:dx + 31] = 250
+    _cmp(np.ascontiguousarray(img), nfeatures=800)
