@@ -107,7 +107,7 @@ def test_two_handles_two_threads():
 
     def work(i):
         ex = capi.Extractor()
-        for _ in range(3):
+        for _ in range(6):                              # eager, graph capture and graph replay all happen on both threads
             res[i] = ex.extract(imgs[i])
 
     ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
