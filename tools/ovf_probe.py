@@ -1,3 +1,5 @@
+"""Diagnostic (run on the GPU box): per level, how many FAST strips of a 256-frame batch overflowed their candidate queue
+and were redone by k_fast_strips_dense, before and after the host shortens that level's strips (orb_get_fast_overflows)."""
 import sys; sys.path.insert(0,'orb-slam2-chinesenotes_amd/pyhost')
 import torch, numpy as np
 from orbhip import capi, synth
