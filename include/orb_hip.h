@@ -389,6 +389,15 @@ int orb_multi_extract_batch(orb_multi* m, const uint8_t* imgs, int n_frames, int
 /* the partition rule: rank r of `world` owns frames [first, first + count) of `total` (host only, no device needed) */
 void orb_shard_range(int total, int world, int rank, int* first, int* count);
 
+/* Batch of stereo pairs in ONE launch: pair p = frames (first_frame_l + p, first_frame_r + p) of the two handles' last
+ * batches, its keypoints / descriptors / results at rows [p * cap, (p + 1) * cap) of the arrays orb_extract_batch_device
+ * wrote, its keypoint counts read on the device from the extractors' d_counts (no host round trip between extraction
+ * and search).  d_u_right / d_depth: [n_pairs * cap] floats.  Asynchronous on the LEFT handle's stream. */
+int orb_stereo_match_batch_device(orb_extractor* left, orb_extractor* right, int first_frame_l, int first_frame_r,
+                                  int n_pairs, const orb_keypoint* d_kps_l, const uint8_t* d_desc_l,
+                                  const int32_t* d_counts_l, const orb_keypoint* d_kps_r, const uint8_t* d_desc_r,
+                                  const int32_t* d_counts_r, int cap, float mb, float mbf, float* d_u_right, float* d_depth);
+
 /* ---------------------------------------------------------------- misc ---------------------*/
 const char* orb_last_error(void);   /* thread-local description of the last failure */
 const char* orb_version(void);

@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <vector>
 
+#include "orb_block_sort.h"
 #include "orb_extractor_internal.h"
 
 #pragma clang fp contract(off)
@@ -28,21 +29,37 @@ __device__ __forceinline__ unsigned st_umin_dpp(unsigned v)
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
-__global__ __launch_bounds__(WAVE) void k_stereo_match(const OrbGeom G, const uint8_t* __restrict__ pyrL,
-                                                       const uint8_t* __restrict__ pyrR,
-                                                       const orb_keypoint* __restrict__ kL,
-                                                       const uint8_t* __restrict__ dL, int N,
-                                                       const orb_keypoint* __restrict__ kR,
-                                                       const uint8_t* __restrict__ dR, int Nr, float maxD,
-                                                       float mbf, float* __restrict__ uRight,
-                                                       float* __restrict__ depth,
-                                                       unsigned long long* __restrict__ pairs,
-                                                       int* __restrict__ pairCount)
+// grid (left keypoint, pair): pair p uses frames frame0 + p of the two pyramids and rows [p * stride, ...) of the
+// keypoint / descriptor / result arrays; the keypoint counts come from the host (single pair) or from device arrays
+// (batch: the extractors' d_counts, no host round trip between extraction and search).
+__global__ __launch_bounds__(WAVE) void k_stereo_match(const OrbGeom G, const uint8_t* __restrict__ pyrL0, size_t slabL,
+                                                       const uint8_t* __restrict__ pyrR0, size_t slabR,
+                                                       const orb_keypoint* __restrict__ kL0,
+                                                       const uint8_t* __restrict__ dL0, int nL,
+                                                       const int32_t* __restrict__ countsL,
+                                                       const orb_keypoint* __restrict__ kR0,
+                                                       const uint8_t* __restrict__ dR0, int nR,
+                                                       const int32_t* __restrict__ countsR, size_t stride, float maxD,
+                                                       float mbf, float* __restrict__ uRight0,
+                                                       float* __restrict__ depth0,
+                                                       unsigned long long* __restrict__ pairs0,
+                                                       int* __restrict__ pairCount0)
 {
     __shared__ int IL[11][11];
     __shared__ int IR[11][21];
     __shared__ int part[11][11];
-    const int iL = blockIdx.x, lane = threadIdx.x;
+    const int iL = blockIdx.x, lane = threadIdx.x, pr = blockIdx.y;
+    const int N = countsL ? min(countsL[pr], (int)stride) : nL, Nr = countsR ? min(countsR[pr], (int)stride) : nR;
+    const uint8_t* pyrL = pyrL0 + slabL * pr;
+    const uint8_t* pyrR = pyrR0 + slabR * pr;
+    const orb_keypoint* kL = kL0 + stride * pr;
+    const orb_keypoint* kR = kR0 + stride * pr;
+    const uint8_t* dL = dL0 + stride * pr * 32;
+    const uint8_t* dR = dR0 + stride * pr * 32;
+    float* uRight = uRight0 + stride * pr;
+    float* depth = depth0 + stride * pr;
+    unsigned long long* pairs = pairs0 + stride * pr;
+    int* pairCount = pairCount0 + pr;
     if (iL >= N) return;
     if (lane == 0) { uRight[iL] = -1.0f; depth[iL] = -1.0f; }
     const orb_keypoint kpL = kL[iL];
@@ -141,32 +158,47 @@ __global__ __launch_bounds__(WAVE) void k_stereo_match(const OrbGeom G, const ui
     }
 }
 
-__global__ __launch_bounds__(1024) void k_stereo_outliers(unsigned long long* __restrict__ pairs,
-                                                          const int* __restrict__ pairCount,
-                                                          float* __restrict__ uRight, float* __restrict__ depth)
+// one workgroup per pair: sort (SAD, index), median, cut >= 1.5 * 1.4 * median (:685-698).  The pairs are sorted in LDS
+// (orb_block_sort) when they fit ldsCap entries, in global memory otherwise.
+__global__ __launch_bounds__(1024) void k_stereo_outliers(unsigned long long* __restrict__ pairs0, size_t stride,
+                                                          const int* __restrict__ pairCount0,
+                                                          float* __restrict__ uRight0, float* __restrict__ depth0, int ldsCap)
 {
-    const int n = *pairCount;
+    extern __shared__ unsigned long long spairs[];
+    const int pr = blockIdx.x;
+    unsigned long long* gp = pairs0 + stride * pr;
+    float* uRight = uRight0 + stride * pr;
+    float* depth = depth0 + stride * pr;
+    const int n = pairCount0[pr];
     if (n == 0) return;                                            // reference: UB on the empty vector (:686)
-    int np2 = 1;
-    while (np2 < n) np2 <<= 1;
-    for (int k = 2; k <= np2; k <<= 1) {
-        for (int i = threadIdx.x; i < np2; i += blockDim.x) {
-            const int p = i ^ (k - 1);
-            if (p > i && p < n) {
-                const unsigned long long x = pairs[i], y = pairs[p];
-                if (x > y) { pairs[i] = y; pairs[p] = x; }
-            }
-        }
+    unsigned long long* pairs = gp;
+    if (n <= ldsCap) {
+        for (int i = threadIdx.x; i < n; i += blockDim.x) spairs[i] = gp[i];
         __syncthreads();
-        for (int j = k >> 2; j > 0; j >>= 1) {
+        orb_block_sort(spairs, n);
+        pairs = spairs;
+    } else {
+        int np2 = 1;
+        while (np2 < n) np2 <<= 1;
+        for (int k = 2; k <= np2; k <<= 1) {
             for (int i = threadIdx.x; i < np2; i += blockDim.x) {
-                const int p = i ^ j;
+                const int p = i ^ (k - 1);
                 if (p > i && p < n) {
-                    const unsigned long long x = pairs[i], y = pairs[p];
-                    if (x > y) { pairs[i] = y; pairs[p] = x; }
+                    const unsigned long long x = gp[i], y = gp[p];
+                    if (x > y) { gp[i] = y; gp[p] = x; }
                 }
             }
             __syncthreads();
+            for (int j = k >> 2; j > 0; j >>= 1) {
+                for (int i = threadIdx.x; i < np2; i += blockDim.x) {
+                    const int p = i ^ j;
+                    if (p > i && p < n) {
+                        const unsigned long long x = gp[i], y = gp[p];
+                        if (x > y) { gp[i] = y; gp[p] = x; }
+                    }
+                }
+                __syncthreads();
+            }
         }
     }
     const float median = (float)(int)(pairs[n / 2] >> 32);
@@ -181,6 +213,44 @@ __global__ __launch_bounds__(1024) void k_stereo_outliers(unsigned long long* __
     }
 }
 
+static int stereo_check(orb_extractor* left, orb_extractor* right)
+{
+    if (left->rows == 0 || left->rows != right->rows || left->cols != right->cols ||
+        left->prm.nlevels != right->prm.nlevels || left->prm.scale_factor != right->prm.scale_factor) {
+        orb_set_error("stereo: both extractors must have processed images of the same size with the same pyramid");
+        return ORB_ERR_INVALID;
+    }
+    if (left->device != right->device) return ORB_ERR_UNSUPPORTED;
+    return ORB_OK;
+}
+
+// launches both kernels for nPairs pairs; counts from the host (cL/cR null) or from the device
+static int stereo_launch(orb_extractor* left, orb_extractor* right, int frameL, int frameR, int nPairs, size_t stride,
+                         const orb_keypoint* kL, const uint8_t* dL, int nL, const int32_t* cL, const orb_keypoint* kR,
+                         const uint8_t* dR, int nR, const int32_t* cR, float mb, float mbf, float* uR, float* dep)
+{
+    ORB_HIP_TRY(hipSetDevice(left->device));
+    int rc;
+    const size_t perPair = stride;                                  // (SAD, index) slots per pair
+    if ((rc = left->dStereo.ensure((size_t)8 * perPair * nPairs + (size_t)4 * nPairs + 16)) != ORB_OK) return rc;
+    hipStream_t st = left->stream;
+    ORB_HIP_TRY(hipEventRecord(left->waitEv, right->stream));      // the right pyramid must be complete
+    ORB_HIP_TRY(hipStreamWaitEvent(st, left->waitEv, 0));
+    unsigned long long* pairs = (unsigned long long*)left->dStereo.p;
+    int* pairCount = (int*)(pairs + perPair * nPairs);
+    ORB_HIP_TRY(hipMemsetAsync(pairCount, 0, (size_t)4 * nPairs, st));
+    const float maxD = mbf / mb;                                   // :546
+    const int gridX = cL ? (int)stride : nL;
+    hipLaunchKernelGGL(k_stereo_match, dim3(gridX, nPairs), dim3(WAVE), 0, st, left->G,
+                       (const uint8_t*)left->dPyr.p + left->pyrSlab * frameL, left->pyrSlab,
+                       (const uint8_t*)right->dPyr.p + right->pyrSlab * frameR, right->pyrSlab, kL, dL, nL, cL, kR, dR, nR, cR,
+                       stride, maxD, mbf, uR, dep, pairs, pairCount);
+    const int ldsCap = (int)std::min<size_t>(stride, 4096);         // <= 32 KB of (SAD, index) pairs
+    hipLaunchKernelGGL(k_stereo_outliers, dim3(nPairs), dim3(1024), (size_t)8 * ldsCap, st, pairs, perPair, pairCount, uR, dep, ldsCap);
+    ORB_HIP_TRY(hipGetLastError());
+    return ORB_OK;
+}
+
 extern "C" int orb_stereo_match_device(orb_extractor* left, orb_extractor* right, int frame_l, int frame_r,
                                        const orb_keypoint* d_kps_l, const uint8_t* d_desc_l, int n_l,
                                        const orb_keypoint* d_kps_r, const uint8_t* d_desc_r, int n_r, float mb,
@@ -189,30 +259,38 @@ extern "C" int orb_stereo_match_device(orb_extractor* left, orb_extractor* right
     if (!left || !right || n_l < 0 || n_r < 0) return ORB_ERR_INVALID;
     if (n_l == 0) return ORB_OK;
     if (!d_kps_l || !d_desc_l || !d_u_right || !d_depth || (n_r > 0 && (!d_kps_r || !d_desc_r))) return ORB_ERR_INVALID;
-    if (left->rows == 0 || left->rows != right->rows || left->cols != right->cols ||
-        left->prm.nlevels != right->prm.nlevels || left->prm.scale_factor != right->prm.scale_factor) {
-        orb_set_error("stereo: both extractors must have processed images of the same size with the same pyramid");
-        return ORB_ERR_INVALID;
-    }
-    if (frame_l < 0 || frame_l >= left->lastFrames || frame_r < 0 || frame_r >= right->lastFrames) return ORB_ERR_INVALID;
-    if (n_l > 65535 || n_r > 65535 || left->device != right->device) return ORB_ERR_UNSUPPORTED;
-    ORB_HIP_TRY(hipSetDevice(left->device));
     int rc;
-    if ((rc = left->dStereo.ensure((size_t)8 * n_l + 16)) != ORB_OK) return rc;
-    hipStream_t st = left->stream;
-    ORB_HIP_TRY(hipEventRecord(left->waitEv, right->stream));      // the right pyramid must be complete
-    ORB_HIP_TRY(hipStreamWaitEvent(st, left->waitEv, 0));
-    unsigned long long* pairs = (unsigned long long*)left->dStereo.p;
-    int* pairCount = (int*)(pairs + n_l);
-    ORB_HIP_TRY(hipMemsetAsync(pairCount, 0, 4, st));
-    const float maxD = mbf / mb;                                   // :546
-    hipLaunchKernelGGL(k_stereo_match, dim3(n_l), dim3(WAVE), 0, st, left->G,
-                       (const uint8_t*)left->dPyr.p + left->pyrSlab * frame_l,
-                       (const uint8_t*)right->dPyr.p + right->pyrSlab * frame_r, d_kps_l, d_desc_l, n_l, d_kps_r,
-                       d_desc_r, n_r, maxD, mbf, d_u_right, d_depth, pairs, pairCount);
-    hipLaunchKernelGGL(k_stereo_outliers, dim3(1), dim3(1024), 0, st, pairs, pairCount, d_u_right, d_depth);
-    ORB_HIP_TRY(hipGetLastError());
-    return ORB_OK;
+    if ((rc = stereo_check(left, right)) != ORB_OK) return rc;
+    frame_l -= left->frameBase;
+    frame_r -= right->frameBase;
+    if (frame_l < 0 || frame_l >= left->lastFrames || frame_r < 0 || frame_r >= right->lastFrames) return ORB_ERR_INVALID;
+    if (n_l > 65535 || n_r > 65535) return ORB_ERR_UNSUPPORTED;
+    return stereo_launch(left, right, frame_l, frame_r, 1, (size_t)n_l, d_kps_l, d_desc_l, n_l, nullptr, d_kps_r, d_desc_r, n_r,
+                         nullptr, mb, mbf, d_u_right, d_depth);
+}
+
+// Batch: pair p = frames (first_frame_l + p, first_frame_r + p) of the two handles' last batches; keypoints, descriptors
+// and results of pair p at rows [p * cap, (p + 1) * cap) of the arrays the extractors wrote (orb_extract_batch_device
+// layout), keypoint counts read on the DEVICE from the extractors' d_counts.  One launch for all pairs.
+extern "C" int orb_stereo_match_batch_device(orb_extractor* left, orb_extractor* right, int first_frame_l, int first_frame_r,
+                                             int n_pairs, const orb_keypoint* d_kps_l, const uint8_t* d_desc_l,
+                                             const int32_t* d_counts_l, const orb_keypoint* d_kps_r,
+                                             const uint8_t* d_desc_r, const int32_t* d_counts_r, int cap, float mb, float mbf,
+                                             float* d_u_right, float* d_depth)
+{
+    if (!left || !right || n_pairs < 0 || cap <= 0) return ORB_ERR_INVALID;
+    if (n_pairs == 0) return ORB_OK;
+    if (!d_kps_l || !d_desc_l || !d_counts_l || !d_kps_r || !d_desc_r || !d_counts_r || !d_u_right || !d_depth) return ORB_ERR_INVALID;
+    int rc;
+    if ((rc = stereo_check(left, right)) != ORB_OK) return rc;
+    first_frame_l -= left->frameBase;
+    first_frame_r -= right->frameBase;
+    if (first_frame_l < 0 || first_frame_l + n_pairs > left->lastFrames || first_frame_r < 0 ||
+        first_frame_r + n_pairs > right->lastFrames)
+        return ORB_ERR_INVALID;
+    if (cap > 65535 || n_pairs > 65535) return ORB_ERR_UNSUPPORTED;
+    return stereo_launch(left, right, first_frame_l, first_frame_r, n_pairs, (size_t)cap, d_kps_l, d_desc_l, 0, d_counts_l, d_kps_r,
+                         d_desc_r, 0, d_counts_r, mb, mbf, d_u_right, d_depth);
 }
 
 extern "C" int orb_stereo_match(orb_extractor* left, orb_extractor* right, const orb_keypoint* kps_l,

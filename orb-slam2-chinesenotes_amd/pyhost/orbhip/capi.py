@@ -65,7 +65,7 @@ SYMBOLS = [
     "orb_hamming", "orb_three_maxima", "orb_matcher_create", "orb_matcher_destroy", "orb_matcher_sync",
     "orb_match_bow", "orb_match_bow_kk", "orb_match_init", "orb_match_projection", "orb_match_projection_best", "orb_match_triangulation", "orb_vocab_create", "orb_vocab_destroy", "orb_vocab_level_nodes", "orb_bow_transform",
     "orb_bow_transform_device", "orb_distinctive_descriptors", "orb_distinctive_descriptors_device", "orb_bow_assign_device", "orb_match_bow_batch_device", "orb_bow_build_csr_device",
-    "orb_matcher_stream", "orb_stereo_match", "orb_stereo_match_device", "orb_extractor_wait_for", "orb_matcher_wait_for", "orb_last_error", "orb_version", "orb_multi_create", "orb_multi_destroy", "orb_multi_devices", "orb_multi_handle",
+    "orb_matcher_stream", "orb_stereo_match", "orb_stereo_match_device", "orb_stereo_match_batch_device", "orb_extractor_wait_for", "orb_matcher_wait_for", "orb_last_error", "orb_version", "orb_multi_create", "orb_multi_destroy", "orb_multi_devices", "orb_multi_handle",
     "orb_multi_set_pattern", "orb_multi_extract_batch", "orb_shard_range",
 ]
 
@@ -139,6 +139,7 @@ def lib():
     L.orb_extractor_wait_for.argtypes = [vp, vp]
     L.orb_stereo_match.argtypes = [vp, vp, vp, vp, ci, vp, vp, ci, cf, cf, vp, vp]
     L.orb_stereo_match_device.argtypes = [vp, vp, ci, ci, vp, vp, ci, vp, vp, ci, cf, cf, vp, vp]
+    L.orb_stereo_match_batch_device.argtypes = [vp, vp, ci, ci, ci, vp, vp, vp, vp, vp, vp, ci, cf, cf, vp, vp]
     L.orb_matcher_wait_for.argtypes = [vp, vp]
     L.orb_multi_create.argtypes = [C.POINTER(Params), vp, ci, C.POINTER(vp)]
     L.orb_multi_destroy.argtypes = [vp]
@@ -520,6 +521,15 @@ def stereo_match_device(ex_left, ex_right, frame_l, frame_r, d_kps_l, d_desc_l, 
     _check(lib().orb_stereo_match_device(ex_left.h, ex_right.h, frame_l, frame_r, C.c_void_p(d_kps_l), C.c_void_p(d_desc_l), n_l,
                                          C.c_void_p(d_kps_r), C.c_void_p(d_desc_r), n_r, C.c_float(mb), C.c_float(mbf),
                                          C.c_void_p(d_u_right), C.c_void_p(d_depth)))
+
+
+def stereo_match_batch_device(ex_left, ex_right, first_l, first_r, n_pairs, d_kps_l, d_desc_l, d_counts_l, d_kps_r, d_desc_r,
+                              d_counts_r, cap, mb, mbf, d_u_right, d_depth):
+    """All pairs of the two handles' last batches in one launch; counts are read on the device."""
+    _check(lib().orb_stereo_match_batch_device(ex_left.h, ex_right.h, first_l, first_r, n_pairs, C.c_void_p(d_kps_l),
+                                               C.c_void_p(d_desc_l), C.c_void_p(d_counts_l), C.c_void_p(d_kps_r),
+                                               C.c_void_p(d_desc_r), C.c_void_p(d_counts_r), cap, C.c_float(mb), C.c_float(mbf),
+                                               C.c_void_p(d_u_right), C.c_void_p(d_depth)))
 
 
 class Vocabulary:

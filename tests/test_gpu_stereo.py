@@ -67,3 +67,40 @@ def test_stereo_other_sizes_and_feature_counts(idx, w, h, nf):
         want_u, want_z = oracle.stereo_matches(rl, rr, *a, MB, MBF)
         got_u, got_z = capi.stereo_match(exl, exr, *a, MB, MBF)
         assert got_u.tobytes() == want_u.tobytes() and got_z.tobytes() == want_z.tobytes(), (nl, nr)
+
+
+def test_stereo_batch_of_pairs_in_one_launch():
+    """orb_stereo_match_batch_device: 5 KITTI-sized pairs extracted as two device batches, the stereo search of all of
+    them in ONE launch with the keypoint counts read on the device; every pair bit-exact against the oracle (which
+    extracts and searches the pairs one at a time), incl. a pair whose right image is blank (no right features)."""
+    import torch
+    W, H, nf, S = 1241, 376, 2000, 5
+    dev = torch.device("cuda", 0)
+    lefts = np.stack([synth.synth_frame(400 + i, W, H) for i in range(S)])
+    rights = np.stack([synth.synth_stereo_right(400 + i, W, H) for i in range(S)])
+    rights[3] = 77                                               # flat right image: zero right keypoints for pair 3
+    exl, exr = capi.Extractor(nf), capi.Extractor(nf)
+    cap = exl.max_keypoints
+    z = lambda n, dt: torch.zeros(n, dtype=dt, device=dev)
+    d_l, d_r = torch.from_numpy(lefts).to(dev), torch.from_numpy(rights).to(dev)
+    kl, kr = z(S * cap * 28, torch.uint8), z(S * cap * 28, torch.uint8)
+    dl, dr = z(S * cap * 32, torch.uint8), z(S * cap * 32, torch.uint8)
+    cl, cr = z(S, torch.int32), z(S, torch.int32)
+    ur, dp = z(S * cap, torch.float32), z(S * cap, torch.float32)
+    torch.cuda.synchronize()
+    exl.extract_batch_device(d_l.data_ptr(), S, H, W, W, W * H, kl.data_ptr(), dl.data_ptr(), cap, cl.data_ptr())
+    exr.extract_batch_device(d_r.data_ptr(), S, H, W, W, W * H, kr.data_ptr(), dr.data_ptr(), cap, cr.data_ptr())
+    capi.stereo_match_batch_device(exl, exr, 0, 0, S, kl.data_ptr(), dl.data_ptr(), cl.data_ptr(), kr.data_ptr(), dr.data_ptr(),
+                                   cr.data_ptr(), cap, MB, MBF, ur.data_ptr(), dp.data_ptr())
+    exl.sync(); exr.sync(); torch.cuda.synchronize()
+    u, zz = ur.cpu().numpy().reshape(S, cap), dp.cpu().numpy().reshape(S, cap)
+    nl, nr = cl.cpu().numpy(), cr.cpu().numpy()
+    assert nr[3] == 0 and nl[3] > 1000
+    for i in range(S):
+        rl, rr = oracle.Extractor(nf), oracle.Extractor(nf)
+        k1, d1 = rl.extract(lefts[i])
+        k2, d2 = rr.extract(rights[i])
+        assert len(k1) == nl[i] and len(k2) == nr[i]
+        wu, wz = oracle.stereo_matches(rl, rr, k1, d1, k2, d2, MB, MBF)
+        assert u[i, :nl[i]].tobytes() == wu.tobytes() and zz[i, :nl[i]].tobytes() == wz.tobytes(), i
+    assert np.all(u[3, :nl[3]] == -1)
