@@ -1,0 +1,35 @@
+#!/bin/bash
+# Run ON THE GPU BOX: kernel trace of the single-frame host call (tools/latency.py), per-kernel average duration and
+# the GPU-side span of one call (first kernel start -> last kernel end).
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/lat_trace
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+ORB_NO_GRAPH=1 rocprofv3 --kernel-trace --output-format csv -d "$OUT" -o run -- python3 "$ROOT/tools/latency.py" 60 > "$OUT.log" 2>&1 || { tail -5 "$OUT.log"; exit 1; }
+python3 - "$OUT" <<'PY'
+import csv, glob, sys, collections
+rows = []
+for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
+    rows += list(csv.DictReader(open(f)))
+rows = [r for r in rows if r["Kernel_Name"].replace("void ", "").startswith("k_")]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+# first size only (640x480): calls = groups starting at k_copy_level0
+calls, cur = [], []
+for r in rows:
+    n = r["Kernel_Name"].replace("void ", "").split("(")[0]
+    if n == "k_copy_level0" and cur:
+        calls.append(cur); cur = []
+    cur.append((n, int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+calls.append(cur)
+calls = calls[20:60]
+agg = collections.defaultdict(list)
+spans, busy = [], []
+for c in calls:
+    spans.append((c[-1][2] - c[0][1]) / 1e3)
+    busy.append(sum(e - s for _, s, e in c) / 1e3)
+    for n, s, e in c:
+        agg[n].append((e - s) / 1e3)
+print("GPU span per call: %.1f us, sum of kernel durations %.1f us, %d launches" % (sum(spans) / len(spans), sum(busy) / len(busy), len(calls[0])))
+for n, v in agg.items():
+    print("  %-24s x%d  %.1f us each" % (n, len(v) // len(calls), sum(v) / len(v)))
+PY
