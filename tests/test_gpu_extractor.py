@@ -398,3 +398,30 @@ def test_adversarial_patterns_for_the_strip_detector(kind):
                 img[dy + 3:dy + 5, dx + 3:dx + 5] = 250
                 img[dy + 29:dy + 31, dx + 29:dx + 31] = 250
     _cmp(np.ascontiguousarray(img), nfeatures=800)
+
+
+def test_host_batch_pipeline_strided_rows_and_tiny_tail():
+    """The chunked host pipeline with a row stride larger than the width (pageable: row-wise staging; pinned: 2-D copies),
+    17 frames (chunks of 8, 8 and a tail of 1) and more handles' worth of frames than devices in orb_multi (3 frames on
+    [0,0,0,0]: one rank gets nothing)."""
+    import torch
+    n, W, H, S = 17, 300, 200, 352
+    imgs = synth.synth_sequence(900, n, W, H)
+    wide = np.zeros((n, H, S), np.uint8)
+    wide[:, :, :W] = imgs
+    ex = capi.Extractor(400)
+    ref = oracle.Extractor(400)
+    want = [ref.extract(im) for im in imgs]
+    cap = ex.max_keypoints
+    for pinned in (False, True):
+        src = torch.from_numpy(wide).pin_memory().numpy() if pinned else wide
+        view = src[:, :, :W]                                     # strides (H*S, S, 1)
+        kps = np.zeros((n, cap, 28), np.uint8); desc = np.zeros((n, cap, 32), np.uint8); cnt = np.zeros(n, np.int32)
+        ex.extract_batch_into(view, kps, desc, cnt)
+        for f, (rk, rd) in enumerate(want):
+            assert cnt[f] == len(rk) and kps[f, :len(rk)].tobytes() == rk.tobytes() and np.array_equal(desc[f, :len(rk)], rd), (pinned, f)
+    mx = capi.MultiExtractor([0, 0, 0, 0], 400)
+    got = mx.extract_batch(imgs[:3])
+    for (k, d), (rk, rd) in zip(got, want[:3]):
+        assert k.tobytes() == rk.tobytes() and np.array_equal(d, rd)
+    mx.close(); ex.close()
