@@ -93,6 +93,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=200, help="timed frames of the single-thread cpu_baseline (+10 warm-up)")
     ap.add_argument("--no-cpu-all-cores", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true", help="do not measure roofline.traffic live (two rocprofv3 --pmc child "
+                    "runs of a 3-step bench); use the committed profiles/pmc_traffic.json instead")
     ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive host_in_host_out_fps measurement "
                     "(profiling runs: keeps every kernel launch at the benchmark's batch size)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) or gloo (CPU rehearsal of the N>1 path)")
@@ -109,7 +111,47 @@ def load_profile(name):
         return None
 
 
-def roofline_blocks(stage_ms, launch_frames, bytes_frame, extract_total_ms):
+def live_traffic(kernel, launch_frames):
+    """HBM-side bytes per launch of `kernel`, measured NOW: two child runs of this script under `rocprofv3 --pmc`
+    (FETCH_SIZE and WRITE_SIZE need separate passes; counter passes carry --kernel-trace only), 3 steps each, parsed like
+    tools/pmc_summary.py (full-batch launches only; FETCH x2, profiles/r02_fetch_calibration.json).  None on any failure."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None
+    tmp = tempfile.mkdtemp(prefix="orb_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    vals = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "run", "--",
+                   sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--pipeline", "1", "--no-cpu-baseline",
+                   "--no-host-path", "--no-live-traffic", "--frames-per-gpu", str(launch_frames)]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+            if r.returncode != 0:
+                return None
+            rows = []
+            for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
+                rows += list(csv.DictReader(open(f)))
+            name = lambda r: r["Kernel_Name"].replace("void ", "").split("(")[0].split("<")[0]
+            grid = lambda r: int(r["Grid_Size"])
+            mine = [r for r in rows if name(r) == kernel and r["Counter_Name"] == counter]
+            if not mine:
+                return None
+            big = max(grid(r) for r in mine)                       # the benchmark's launches, not the vocabulary-training batch
+            sel = [float(r["Counter_Value"]) for r in mine if grid(r) == big]
+            vals[counter] = sum(sel) / len(sel) * 1024.0
+        return int(2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"])
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def roofline_blocks(stage_ms, launch_frames, bytes_frame, extract_total_ms, live=False):
     """The contract `roofline` block (HBM, as SURVEY 8(d) defines `achieved`) for the dominant extractor kernel, plus
     `roofline_valu`: what actually binds FAST and the descriptor kernel is vector-instruction issue."""
     dom = int(np.argmax(stage_ms[:4]))
@@ -122,7 +164,15 @@ def roofline_blocks(stage_ms, launch_frames, bytes_frame, extract_total_ms):
           "binding": "valu_issue (see roofline_valu): the kernel moves ~1 MB/frame from L2, HBM is not what limits it"}
     key = STAGES[dom].split("(")[0]
     tr = load_profile("pmc_traffic.json")
-    if tr and key in tr.get("bytes_per_launch", {}):
+    lt = live_traffic(key, launch_frames) if live else None
+    if lt is not None:
+        rf["traffic"] = lt
+        rf["traffic_source"] = "measured in this run: two child runs of bench.py (3 steps) under rocprofv3 --pmc FETCH_SIZE / " \
+                               "--pmc WRITE_SIZE, per full-batch launch; FETCH x2 (gfx950: 128-byte requests tallied at 64 B, " \
+                               "profiles/r02_fetch_calibration.json)"
+        if tr and key in tr.get("bytes_per_launch", {}):
+            rf["traffic_committed_profile"] = int(tr["bytes_per_launch"][key] * launch_frames / tr["frames_per_launch"])
+    elif tr and key in tr.get("bytes_per_launch", {}):
         rf["traffic"] = int(tr["bytes_per_launch"][key] * launch_frames / tr["frames_per_launch"])
         rf["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2 per " \
                                "profiles/r02_fetch_calibration.json), scaled to this launch size"
@@ -307,7 +357,7 @@ def run_c4(args, rank, local_rank, world, dev, comm_dev, dist):
         return None
     fps = frames_done / elapsed
     bytes_frame = algorithmic_bytes_per_frame(W, H, pyr_px, mean_kp)
-    rf, rv = roofline_blocks(stage_ms, launch_frames, bytes_frame, float(stage_ms[4]))
+    rf, rv = roofline_blocks(stage_ms, launch_frames, bytes_frame, float(stage_ms[4]), live=(world == 1 and not args.no_live_traffic))
     out = {
         "metric": METRIC, "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,

@@ -31,6 +31,9 @@ def test_single_gpu_line_has_every_contract_field():
     assert d["config"]["host_in_host_out_fps"]["pinned"] > 0
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    # traffic is measured live (two rocprofv3 --pmc child runs).  At 32 frames the pyramids stay in the XCDs' L2s, so the
+    # memory-side bytes are far below the algorithmic ones; at 512 frames they are the 0.94 MB/frame the kernel must read
+    assert rf["traffic"] is not None and rf["traffic"] > 0 and "measured in this run" in rf["traffic_source"]
     if "roofline_valu" in d:
         rv = d["roofline_valu"]
         assert rv["bound"] == "valu_issue" and abs(rv["frac"] - rv["achieved"] / rv["peak"]) < 1e-3

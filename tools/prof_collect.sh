@@ -12,7 +12,7 @@ OUT=$ROOT/gpurun_out/prof_$tag
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 ARGS=("$@")
-if [ ${#ARGS[@]} -eq 0 ]; then ARGS=(--no-cpu-baseline --no-host-path --steps 6 --warmup 2 --pipeline 1); fi
+if [ ${#ARGS[@]} -eq 0 ]; then ARGS=(--no-cpu-baseline --no-host-path --no-live-traffic --steps 6 --warmup 2 --pipeline 1); fi
 
 run() {   # name, rocprofv3 options...
     local name=$1
