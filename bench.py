@@ -121,6 +121,9 @@ def live_traffic(kernel, launch_frames):
     import tempfile
     if shutil.which("rocprofv3") is None:
         return None
+    # already running under a profiler (the tool preloads itself into children): do not nest, use the committed profile
+    if any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None
     tmp = tempfile.mkdtemp(prefix="orb_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
     vals = {}
