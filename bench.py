@@ -377,6 +377,7 @@ def run_c4(args, rank, local_rank, world, dev, comm_dev, dist):
                    "single_lane_ms_per_step": round(single_ms, 4),
                    "single_lane_frames_per_s": round(B / single_ms * 1e3, 1),
                    "stage_ms_per_launch_single_lane": {n: round(float(v), 4) for n, v in zip(STAGES + ["extract_total"], stage_ms)},
+                   "extract_only_frames_per_s_single_lane": round(launch_frames / float(stage_ms[4]) * 1e3, 1),
                    "transform_plus_match_ms_single_lane": round(single_ms - float(stage_ms[4]), 4),
                    "host_in_host_out_fps": host_fps},
         "roofline": rf,
@@ -384,7 +385,11 @@ def run_c4(args, rank, local_rank, world, dev, comm_dev, dist):
     if rv:
         out["roofline_valu"] = rv
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline_c4(args, frames_sets[ln0["set"]], first, ln0, counts, cap, nm, tree, valid_np)
+        cb = cpu_baseline_c4(args, frames_sets[ln0["set"]], first, ln0, counts, cap, nm, tree, valid_np)
+        cb["gpu_over_cpu_port"] = {"extract_plus_match": round(fps / cb["value"], 1),
+                                   "extract_only": round(launch_frames / float(stage_ms[4]) * 1e3 / cb["extract_only_frames_per_s"], 1),
+                                   "note": "against this single-thread scalar port (kind 'port'), not OpenCV's SIMD build of the reference"}
+        out["cpu_baseline"] = cb
     return out
 
 
@@ -448,6 +453,8 @@ def cpu_baseline_c4(args, frames_np, first, ln0, counts, cap, nm_gpu, tree, vali
            "match_ms_per_frame_median": round(med_m * 1e3, 3),
            "extract_only_frames_per_s": round(1.0 / med_e, 3),
            "gpu_matches_oracle_on_sample": bool(parity)}
+    # north_star asks for >= 1000x the single-thread CPU ORBextractor: the ratios against THIS port (not OpenCV's SIMD paths)
+    res["gpu_over_cpu_port"] = {"extract_plus_match": None, "note": "filled by the caller"}
     if not args.no_cpu_all_cores and all_cores and len(all_cores) > 1:
         nproc = len(all_cores)
         per = 24
