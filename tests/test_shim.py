@@ -32,6 +32,47 @@ def test_shims_compile_and_link():
     assert os.path.exists(build_driver())
 
 
+TOOL = os.path.join(SUP, "orb_batch_tool")
+
+
+def build_batch_tool():
+    capi.build_library()
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(PKG, "host", "orb_batch_tool.cc"), "-L" + PKG, "-lorbhip", "-Wl,-rpath," + PKG, "-o", TOOL])
+    return TOOL
+
+
+def test_batch_tool_compiles_and_links():
+    assert os.path.exists(build_batch_tool())
+
+
+@pytest.mark.gpu
+def test_batch_tool_multi_device_cpp_host(tmp_path):
+    """host/orb_batch_tool.cc: the C++ host program of the batched-frames mode (orb_multi_* over the C ABI, pinned
+    buffers from orb_host_alloc) on 37 frames with the GPU listed three times; every frame bit-exact vs the oracle."""
+    import json
+    build_batch_tool()
+    n, W, H = 37, 400, 300
+    imgs = synth.synth_sequence(700, n, W, H)
+    raw = tmp_path / "frames.raw"
+    imgs.tofile(raw)
+    out = str(tmp_path / "o")
+    line = subprocess.check_output([TOOL, str(raw), str(W), str(H), str(n), "600", out, "0,0,0"], text=True)
+    info = json.loads(line.strip().splitlines()[-1])
+    assert info["frames"] == n and info["devices"] == 3 and info["frames_per_s"] > 0
+    counts = np.fromfile(out + ".counts", dtype=np.int32)
+    kps = np.fromfile(out + ".kps", dtype=oracle.KP_DTYPE)
+    desc = np.fromfile(out + ".desc", dtype=np.uint8).reshape(-1, 32)
+    ref = oracle.Extractor(600)
+    off = 0
+    for i in range(n):
+        rk, rd = ref.extract(imgs[i])
+        assert counts[i] == len(rk)
+        assert kps[off:off + len(rk)].tobytes() == rk.tobytes() and np.array_equal(desc[off:off + len(rk)], rd), i
+        off += len(rk)
+    assert off == len(kps) == info["keypoints"]
+
+
 def test_matcher_binding_without_editing_the_reference_source(tmp_path):
     """INTEGRATION.md section 2, the no-edit recipe: an object that defines the four replaced ORBmatcher functions itself
     (standing in for the reference's src/ORBmatcher.cc compiled unchanged) gets those four symbols weakened by
