@@ -641,7 +641,9 @@ extern "C" int orb_get_fast_overflows(orb_extractor* h, int32_t* overflowed, int
 
 extern "C" int orb_get_level_counts(orb_extractor* h, int frame, int32_t* kept, int32_t* cands)
 {
-    if (!h || frame < 0 || frame >= h->lastFrames) return ORB_ERR_INVALID;
+    if (!h) return ORB_ERR_INVALID;
+    frame -= h->frameBase;                                     // as orb_get_pyramid_level: index within the whole batch
+    if (frame < 0 || frame >= h->lastFrames) return ORB_ERR_INVALID;
     ORB_HIP_TRY(hipSetDevice(h->device));
     ORB_HIP_TRY(hipStreamSynchronize(h->stream));
     int32_t buf[ORB_MAX_LEVELS];

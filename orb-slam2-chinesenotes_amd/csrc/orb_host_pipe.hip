@@ -92,7 +92,6 @@ int orb_extract_batch_pipelined(orb_extractor* h, const uint8_t* imgs, int nFram
     }
     if (!inPinned && (rc = ensure_pinned(&P.pinIn[0], &P.pinInBytes, imgBytes * C, &P.pinIn[1])) != ORB_OK) return rc;
     if ((rc = ensure_pinned(&P.pinOut[0], &P.pinOutBytes, outB, &P.pinOut[1])) != ORB_OK) return rc;
-    const bool contiguous = rowStride == (size_t)cols && frameStride == imgBytes;
     hipStream_t cs = h->stream;
     int firstErr = ORB_OK;
 
@@ -119,7 +118,6 @@ int orb_extract_batch_pipelined(orb_extractor* h, const uint8_t* imgs, int nFram
                                                  hipMemcpyHostToDevice, P.h2d));
             }
         }
-        (void)contiguous;
         ORB_HIP_TRY(hipEventRecord(P.evIn[s], P.h2d));
         ORB_HIP_TRY(hipStreamWaitEvent(cs, P.evIn[s], 0));
         if (k >= 2) ORB_HIP_TRY(hipStreamWaitEvent(cs, P.evOut[s], 0));       // this slot's outputs of chunk k-2 have left

@@ -74,13 +74,15 @@ static int broadcast_pattern(orb_multi* m)
     for (int i = 0; i < (int)m->ex.size(); i++)
         for (int u = 0; u < nu; u++)
             if (m->devices[i] == m->uniq[u] && firstOf[u] < 0) firstOf[u] = i;
-    if (m->rccl.GroupStart() != 0) return ORB_ERR_HIP;
-    for (int u = 0; u < nu; u++) {
+    if (m->rccl.GroupStart() != 0) { orb_set_error("ncclGroupStart failed"); return ORB_ERR_HIP; }
+    int grc = ORB_OK;
+    for (int u = 0; u < nu && grc == ORB_OK; u++) {
         orb_extractor* h = m->ex[firstOf[u]];
-        ORB_HIP_TRY(hipSetDevice(h->device));
+        if (hipSetDevice(h->device) != hipSuccess) { orb_set_error("hipSetDevice(%d) failed", h->device); grc = ORB_ERR_HIP; break; }
         const int r = m->rccl.Broadcast(h->dPattern.p, h->dPattern.p, 1024, /*ncclInt8*/ 0, /*root*/ 0, m->comms[u], h->stream);
-        if (r != 0) { orb_set_error("ncclBroadcast: %s", m->rccl.GetErrorString ? m->rccl.GetErrorString(r) : "error"); return ORB_ERR_HIP; }
+        if (r != 0) { orb_set_error("ncclBroadcast: %s", m->rccl.GetErrorString ? m->rccl.GetErrorString(r) : "error"); grc = ORB_ERR_HIP; }
     }
+    if (grc != ORB_OK) { (void)m->rccl.GroupEnd(); return grc; }          // never leave the group open behind an error
     if (m->rccl.GroupEnd() != 0) { orb_set_error("ncclGroupEnd failed"); return ORB_ERR_HIP; }
     for (int u = 0; u < nu; u++) {
         orb_extractor* h = m->ex[firstOf[u]];
@@ -157,12 +159,17 @@ extern "C" int orb_multi_extract_batch(orb_multi* m, const uint8_t* imgs, int n_
         int first = 0, count = 0;
         orb_shard_range(n_frames, W, r, &first, &count);
         if (count == 0) continue;
-        th.emplace_back([=, &rcs, &errs]() {
+        auto work = [=, &rcs, &errs]() {
             rcs[r] = orb_extract_batch(m->ex[r], imgs ? imgs + frame_stride * (size_t)first : nullptr, count, rows, cols, row_stride,
                                        frame_stride, kps ? kps + (size_t)cap * first : nullptr,
                                        desc ? desc + (size_t)ORB_DESC_BYTES * cap * first : nullptr, cap, counts + first);
             if (rcs[r] != ORB_OK) errs[r] = orb_last_error();          // the error string is thread-local
-        });
+        };
+        try {
+            th.emplace_back(work);
+        } catch (...) {                                                // no thread to be had: this block runs here (no exception leaves the C ABI)
+            work();
+        }
     }
     for (std::thread& t : th) t.join();
     for (int r = 0; r < W; r++)

@@ -9,7 +9,7 @@ from orbhip import capi, synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("k,L,levelsup", [(10, 3, 1), (10, 3, 2), (5, 4, 2), (10, 2, 4), (3, 6, 4)])
+@pytest.mark.parametrize("k,L,levelsup", [(10, 3, 1), (10, 3, 2), (5, 4, 2), (10, 2, 4), (3, 6, 4), (16, 3, 1), (17, 3, 1), (40, 2, 1)])
 def test_vocab_transform_matches_oracle(k, L, levelsup):
     tree = synth.synth_vocab_tree(k, L, seed=k * 100 + L)
     rng = np.random.default_rng(L)
