@@ -72,9 +72,22 @@ __device__ __forceinline__ int hamming8(const uint32_t* a, const uint32_t* b)
     return d;
 }
 
+// A load through a pointer that is known to point to global (HBM) memory.  The BowSide pointers reach the kernel inside a
+// struct read from memory, so the compiler cannot tell their address space and would emit flat_load (which also takes an
+// LDS-aperture check and counts on both wait counters); this makes it a global_load.
+template <class T>
+__device__ __forceinline__ T gload(const T* p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return *reinterpret_cast<const __attribute__((address_space(1))) T*>(reinterpret_cast<uintptr_t>(p));
+#else
+    return *p;                                         // (host pass of the single-source compile: never executed)
+#endif
+}
+
 __device__ __forceinline__ void load_desc(const uint8_t* p, uint32_t v[8])
 {
-    const uint4 lo = reinterpret_cast<const uint4*>(p)[0], hi = reinterpret_cast<const uint4*>(p)[1];
+    const uint4 lo = gload(reinterpret_cast<const uint4*>(p)), hi = gload(reinterpret_cast<const uint4*>(p) + 1);
     v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w;
     v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
 }
@@ -89,7 +102,7 @@ __device__ __forceinline__ int rot_bin(float angA, float angB)
     return bin;
 }
 
-__device__ void three_maxima_dev(const int* counts, int& ind1, int& ind2, int& ind3)
+__device__ __forceinline__ void three_maxima_dev(const int* counts, int& ind1, int& ind2, int& ind3)
 {
     int max1 = 0, max2 = 0, max3 = 0;
     ind1 = ind2 = ind3 = -1;
@@ -167,7 +180,7 @@ __device__ void build_csr(const uint16_t* __restrict__ nodeOf, int n, int nNodes
         nd[m] = 0xFFFFu;
         slot[m] = 0;
         if (i < n) {
-            const unsigned v = nodeOf[i];
+            const unsigned v = gload(nodeOf + i);
             if (v < (unsigned)nNodes) { nd[m] = v; slot[m] = atomicAdd(&cntw[v], 1u); }
         }
     }
@@ -208,8 +221,8 @@ __device__ __forceinline__ void load_or_build_csr(const BowSide& S, int nNodes, 
                                                   uint16_t* start, uint16_t* cnt)
 {
     if (S.csrKeys) {
-        for (int i = threadIdx.x; i < S.n; i += blockDim.x) keys[i] = S.csrKeys[i];
-        for (int t = threadIdx.x; t < nNodes; t += blockDim.x) { start[t] = S.csrStart[t]; cnt[t] = S.csrCnt[t]; }
+        for (int i = threadIdx.x; i < S.n; i += blockDim.x) keys[i] = gload(S.csrKeys + i);
+        for (int t = threadIdx.x; t < nNodes; t += blockDim.x) { start[t] = gload(S.csrStart + t); cnt[t] = gload(S.csrCnt + t); }
         __syncthreads();
     } else {
         build_csr(S.nodeOf, S.n, nNodes, keys, tmp, cntw, start, cnt);
@@ -235,6 +248,131 @@ __global__ __launch_bounds__(1024) void k_build_csr(const uint16_t* __restrict__
     for (int t = threadIdx.x; t < nNodes; t += blockDim.x) {
         startOut[(size_t)f * nNodes + t] = start[t];
         cntOut[(size_t)f * nNodes + t] = cnt[t];
+    }
+}
+
+// minimum over the 16 lanes of a DPP row, in every lane of the row (row_ror 8, 4, 2, 1)
+__device__ __forceinline__ unsigned row16_umin_all(unsigned v)
+{
+    ORB_DPP_STEP_UMIN(v, 0x128, 0xf);
+    ORB_DPP_STEP_UMIN(v, 0x124, 0xf);
+    ORB_DPP_STEP_UMIN(v, 0x122, 0xf);
+    ORB_DPP_STEP_UMIN(v, 0x121, 0xf);
+    return v;
+}
+
+// A node with at most 16 NB features of the frame (the usual case: ~10 features per node and frame; NB = 2 covers the
+// nodes of up to 32): the wave works as 4 rows of 16 lanes, every row holding the node's B features (NB per lane), and
+// takes 4 A features at a time -- one per row, their distances computed side by side.  Best and second best of all four
+// rows come from one pair of row reductions (row_ror: every lane of a row ends up with its row's minimum) and every lane
+// runs the acceptance test (:625-627 / :772-775) for its own row.  The greedy "already taken" rule couples the rows only
+// when the column a row takes is the best or second-best column of a LATER row of the group (a column that is neither
+// changes neither): two ballots tell; if not -- the usual case -- all rows commit at once, else the rows are resolved one
+// after the other as the reference's loop does.
+template <bool KK, int NB>
+__device__ __forceinline__ void match_small_node(const BowSide& A, const BowSide& B, int na, int nb, int a0, int b0,
+                                                 const uint32_t* keysA, const uint32_t* keysB, const uint8_t* okALds,
+                                                 uint8_t* takenB, int16_t* res, float ratio, int lane)
+{
+    constexpr int GA = NB == 1 ? 4 : 2;                        // groups of 4 A features whose descriptors are requested together
+    const int rowI = lane >> 4, col = lane & 15;
+    uint32_t dB[NB][8];
+    int jB[NB];
+    bool taken[NB];
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+#pragma unroll
+        for (int w = 0; w < 8; w++) dB[k][w] = 0;
+        jB[k] = -1;
+        taken[k] = true;                                       // columns >= nb count as taken (distance 256)
+        if (col + 16 * k < nb) {
+            jB[k] = (int)(keysB[b0 + col + 16 * k] & 0xFFFFu);
+            load_desc(B.desc + (size_t)jB[k] * 32, dB[k]);
+            taken[k] = takenB[jB[k]] != 0;
+        }
+    }
+    auto reduce2 = [&](const uint32_t* dAg, unsigned& r1, unsigned& r2) {
+        unsigned v[NB];
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            unsigned d = 0;
+#pragma unroll
+            for (int w = 0; w < 8; w++) d += __popc(dB[k][w] ^ dAg[w]);
+            v[k] = ((taken[k] ? 256u : d) << 16) | (unsigned)(col + 16 * k);
+        }
+        const unsigned lo = NB == 1 ? v[0] : min(v[0], v[NB - 1]), hi = NB == 1 ? 0xFFFFFFFFu : max(v[0], v[NB - 1]);
+        r1 = row16_umin_all(lo);
+        r2 = row16_umin_all(lo == r1 ? hi : lo);
+    };
+    for (int abase = 0; abase < na; abase += 4 * GA) {
+        uint32_t dA[GA][8];
+        int iAg[GA];
+        bool okAg[GA];
+#pragma unroll
+        for (int g = 0; g < GA; g++) {
+            // branch-free: rows past the node's last A feature load its last one again and are masked by okAg
+            const int p = abase + 4 * g + rowI;
+            iAg[g] = (int)(keysA[a0 + min(p, na - 1)] & 0xFFFFu);
+            okAg[g] = p < na && okALds[iAg[g]] != 0;           // :590-595
+            load_desc(A.desc + (size_t)iAg[g] * 32, dA[g]);
+        }
+#pragma unroll
+        for (int g = 0; g < GA; g++) {
+            if (abase + 4 * g >= na) continue;
+            const int iA = iAg[g];
+            unsigned r1, r2;
+            reduce2(dA[g], r1, r2);
+            const int b1 = (int)(r1 >> 16), b2 = (int)(r2 >> 16);                 // 256 when nothing is left
+            const bool accept = okAg[g] && (KK ? (b1 < TH_LOW) : (b1 <= TH_LOW)) && (float)b1 < __fmul_rn(ratio, (float)b2);
+            const unsigned c1 = r1 & 31u, c2 = r2 & 31u;
+            unsigned long long winsK[NB], wins = 0;
+#pragma unroll
+            for (int k = 0; k < NB; k++) {
+                winsK[k] = __ballot(accept && c1 == (unsigned)(col + 16 * k));     // bit 16 r + lane column
+                wins |= winsK[k];
+            }
+            const unsigned long long cares = __ballot(okAg[g] && ((unsigned)col == (c1 & 15u) || (unsigned)col == (c2 & 15u)));
+            const unsigned w0 = (unsigned)wins & 0xFFFFu, w1 = (unsigned)(wins >> 16) & 0xFFFFu, w2 = (unsigned)(wins >> 32) & 0xFFFFu;
+            const unsigned i1 = (unsigned)(cares >> 16) & 0xFFFFu, i2 = (unsigned)(cares >> 32) & 0xFFFFu, i3 = (unsigned)(cares >> 48);
+            if (((w0 & (i1 | i2 | i3)) | (w1 & (i2 | i3)) | (w2 & i3)) == 0) {
+#pragma unroll
+                for (int k = 0; k < NB; k++) {
+                    if (accept && c1 == (unsigned)(col + 16 * k)) {
+                        takenB[jB[k]] = 1;
+                        const int rIdx = KK ? iA : jB[k];
+                        res[rIdx] = (int16_t)(KK ? jB[k] : iA);
+                    }
+                    const unsigned all = (unsigned)(winsK[k] | (winsK[k] >> 16) | (winsK[k] >> 32) | (winsK[k] >> 48)) & 0xFFFFu;
+                    taken[k] = taken[k] || ((all >> col) & 1u);                   // in every row: the column is gone
+                }
+                continue;
+            }
+            const unsigned long long okMask = __ballot(okAg[g]);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                if (abase + 4 * g + r >= na) continue;
+                if (!((okMask >> (16 * r)) & 1)) continue;
+                unsigned q1, q2;
+                reduce2(dA[g], q1, q2);                                           // with the flags as they are now
+                const unsigned m1 = (unsigned)__builtin_amdgcn_readlane((int)q1, 16 * r);
+                const unsigned m2 = (unsigned)__builtin_amdgcn_readlane((int)q2, 16 * r);
+                const int best1 = (int)(m1 >> 16), best2 = (int)(m2 >> 16);
+                const bool pass = KK ? (best1 < TH_LOW) : (best1 <= TH_LOW);      // :772 vs :625
+                if (pass && (float)best1 < __fmul_rn(ratio, (float)best2)) {
+                    const int win = (int)(m1 & 31u);
+#pragma unroll
+                    for (int k = 0; k < NB; k++)
+                        if (col + 16 * k == win) {
+                            taken[k] = true;
+                            if (rowI == r) {
+                                takenB[jB[k]] = 1;
+                                const int rIdx = KK ? iA : jB[k];
+                                res[rIdx] = (int16_t)(KK ? jB[k] : iA);
+                            }
+                        }
+                }
+            }
+        }
     }
 }
 
@@ -281,8 +419,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     }
     const int nRes = KK ? A.n : B.n;
     for (int i = tid; i < nRes; i += blockDim.x) { res[i] = -1; bin[i] = 0xFF; }
-    for (int i = tid; i < B.n; i += blockDim.x) takenB[i] = (KK && B.valid && !B.valid[i]) ? 1 : 0;   // :750
-    for (int i = tid; i < A.n; i += blockDim.x) okALds[i] = (A.valid && !A.valid[i]) ? 0 : 1;
+    for (int i = tid; i < B.n; i += blockDim.x) takenB[i] = (KK && B.valid && !gload(B.valid + i)) ? 1 : 0;   // :750
+    for (int i = tid; i < A.n; i += blockDim.x) okALds[i] = (A.valid && !gload(A.valid + i)) ? 0 : 1;
     if (tid < HISTO_LENGTH) hist[tid] = 0;
     if (tid == 0) { nm = 0; nextNode = 0; }
     load_or_build_csr(A, nNodes, keysA, tmp, cntw, startA, cntA);
@@ -299,79 +437,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
         if (na == 0 || nb == 0) continue;
         const int a0 = startA[node], b0 = startB[node];
         if (nb <= 16) {
-            // ---- small node (the usual case: ~10 features per node and frame): the wave works as 4 rows of 16
-            // lanes, every row holding the node's B features, and takes 4 A features at a time -- their distances
-            // are computed side by side, then the rows are resolved in order because the greedy "already taken"
-            // rule couples them.  Row minima are 4-step DPP reductions (row_shr), broadcast with v_readlane.
-            const int rowI = lane >> 4, col = lane & 15;
-            uint32_t dB[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            int jB = -1;
-            bool taken = true;                                     // columns >= nb count as taken (distance 256)
-            if (col < nb) {
-                jB = (int)(keysB[b0 + col] & 0xFFFFu);
-                load_desc(B.desc + (size_t)jB * 32, dB);
-                taken = takenB[jB] != 0;
-            }
-            // A features are taken 16 at a time: row r of group g holds A feature abase + 4 g + r, and the descriptors of
-            // all four groups are requested before any is used -- the loop used to pay one global round trip per group
-            for (int abase = 0; abase < na; abase += 16) {
-                uint32_t dA[4][8];
-                int iAg[4];
-                bool okAg[4];
-#pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    const int p = abase + 4 * g + rowI;
-#pragma unroll
-                    for (int w = 0; w < 8; w++) dA[g][w] = 0;
-                    iAg[g] = -1;
-                    okAg[g] = false;
-                    if (p < na) {
-                        iAg[g] = (int)(keysA[a0 + p] & 0xFFFFu);
-                        okAg[g] = okALds[iAg[g]] != 0;                // :590-595
-                        if (okAg[g]) load_desc(A.desc + (size_t)iAg[g] * 32, dA[g]);
-                    }
-                }
-#pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    if (abase + 4 * g >= na) continue;
-                    const int iA = iAg[g];
-                    unsigned d = 0;
-#pragma unroll
-                    for (int w = 0; w < 8; w++) d += __popc(dB[w] ^ dA[g][w]);
-                    const unsigned long long okMask = __ballot(okAg[g]);
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        if (abase + 4 * g + r >= na) continue;
-                        if (!((okMask >> (16 * r)) & 1)) continue;
-                        const unsigned mine = ((taken ? 256u : d) << 16) | (unsigned)col;
-                        unsigned v1 = mine;
-                        ORB_DPP_STEP_UMIN(v1, 0x111, 0xf);
-                        ORB_DPP_STEP_UMIN(v1, 0x112, 0xf);
-                        ORB_DPP_STEP_UMIN(v1, 0x114, 0xf);
-                        ORB_DPP_STEP_UMIN(v1, 0x118, 0xf);
-                        const unsigned m1 = (unsigned)__builtin_amdgcn_readlane((int)v1, 16 * r + 15);
-                        unsigned v2 = mine == m1 ? 0xFFFFFFFFu : mine;
-                        ORB_DPP_STEP_UMIN(v2, 0x111, 0xf);
-                        ORB_DPP_STEP_UMIN(v2, 0x112, 0xf);
-                        ORB_DPP_STEP_UMIN(v2, 0x114, 0xf);
-                        ORB_DPP_STEP_UMIN(v2, 0x118, 0xf);
-                        const unsigned m2 = (unsigned)__builtin_amdgcn_readlane((int)v2, 16 * r + 15);
-                        const int best1 = (int)(m1 >> 16), best2 = (int)(m2 >> 16);      // 256 when nothing is left
-                        const bool pass = KK ? (best1 < TH_LOW) : (best1 <= TH_LOW);      // :772 vs :625
-                        if (pass && (float)best1 < __fmul_rn(ratio, (float)best2)) {
-                            const int win = (int)(m1 & 0xFFFFu);
-                            if (col == win) {
-                                taken = true;                          // in every row: the column is gone
-                                if (rowI == r) {
-                                    takenB[jB] = 1;
-                                    const int rIdx = KK ? iA : jB;
-                                    res[rIdx] = (int16_t)(KK ? jB : iA);
-                                }
-                            }
-                        }
-                    }
-                }
-            }
+            match_small_node<KK, 1>(A, B, na, nb, a0, b0, keysA, keysB, okALds, takenB, res, ratio, lane);
+        } else if (nb <= 32) {
+            match_small_node<KK, 2>(A, B, na, nb, a0, b0, keysA, keysB, okALds, takenB, res, ratio, lane);
         } else if (nb <= 2 * WAVE) {
             // ---- medium node: the node's B features fit the wave's registers, one or two per lane (positions lane and
             // lane + 64); nothing in the serial A loop touches memory
@@ -487,7 +555,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
             local++;
             if (checkOri) {
                 const int iA = KK ? i : res[i], jB = KK ? res[i] : i;
-                const int bb = rot_bin(A.angle[(size_t)iA * A.angleStride], B.angle[(size_t)jB * B.angleStride]);
+                const int bb = rot_bin(gload(A.angle + (size_t)iA * A.angleStride), gload(B.angle + (size_t)jB * B.angleStride));
                 bin[i] = (uint8_t)bb;
                 atomicAdd(&hist[bb], 1);
             }
