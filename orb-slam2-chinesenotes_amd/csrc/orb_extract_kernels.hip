@@ -21,8 +21,14 @@
 __global__ __launch_bounds__(256) void k_copy_level0(const uint8_t* __restrict__ src, size_t rowStride,
                                                      size_t frameStride, uint8_t* __restrict__ pyr,
                                                      size_t pyrSlab, int w, int h, int pitch, int vec16, int x16n,
-                                                     unsigned invx)
+                                                     unsigned invx, int* __restrict__ clr, int clrInts)
 {
+    // the first kernel of the chain also clears the batch's status words (error flags, candidate / keypoint counters,
+    // overflow list head): one launch less than a memset node in front of it (5 us of a single frame's chain)
+    {
+        const unsigned g = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+        if (g < (unsigned)clrInts) clr[g] = 0;
+    }
     // flattened (row, 16-byte column) index: every lane of every wave has work (a 640-px row is only 40 columns)
     const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int f = blockIdx.y;
@@ -273,14 +279,14 @@ __global__ __launch_bounds__(256) void k_resize_pair(uint8_t* __restrict__ pyr, 
 static unsigned inv32(int d) { return d <= 1 ? 0u : (unsigned)(((1ull << 32) + d - 1) / d); }
 
 void orb_launch_copy_level0(hipStream_t st, const uint8_t* src, size_t rowStride, size_t frameStride,
-                            uint8_t* pyr, size_t pyrSlab, int w, int h, int pitch, int nFrames)
+                            uint8_t* pyr, size_t pyrSlab, int w, int h, int pitch, int nFrames, int* clr, int clrInts)
 {
     const int vec16 = ((reinterpret_cast<uintptr_t>(src) | rowStride | frameStride) & 15) == 0;
     const int x16 = (w + 15) / 16;
     const int total = x16 * h;
     dim3 grid((total + 255) / 256, nFrames);
     hipLaunchKernelGGL(k_copy_level0, grid, dim3(256), 0, st, src, rowStride, frameStride, pyr, pyrSlab, w, h, pitch, vec16,
-                       x16, inv32(x16));
+                       x16, inv32(x16), clr, clrInts);
 }
 
 void orb_launch_resize(hipStream_t st, uint8_t* pyr, size_t pyrSlab, const OrbLevelGeom& src,

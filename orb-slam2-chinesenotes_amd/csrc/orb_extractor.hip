@@ -336,9 +336,10 @@ extern "C" int orb_extract_batch_device(orb_extractor* h, const uint8_t* d_imgs,
     uint32_t* skpl = (uint32_t*)h->dKpl.p;
     const bool prof = h->profiling;
     hipEvent_t* pe = h->ev[h->profCount % orb_extractor::kProfSlots];
-    ORB_HIP_TRY(hipMemsetAsync(h->errP(), 0, orb_extractor::batchInts(n) * 4, st));
     if (prof) ORB_HIP_TRY(hipEventRecord(pe[0], st));
-    orb_launch_copy_level0(st, d_imgs, rowStride, frameStride, pyr, h->pyrSlab, G.L[0].w, G.L[0].h, G.L[0].pitch, n);
+    // (also clears the status block behind the sticky word: error flags, counters, overflow list head)
+    orb_launch_copy_level0(st, d_imgs, rowStride, frameStride, pyr, h->pyrSlab, G.L[0].w, G.L[0].h, G.L[0].pitch, n, h->errP(),
+                           (int)orb_extractor::batchInts(n));
     {
         auto xq_of = [&](int l) { return h->xqOff[l] >= 0 ? (const uint4*)h->dXq.p + h->xqOff[l] : (const uint4*)nullptr; };
         auto ytab_of = [&](int l) { return (const int2*)h->dYtab.p + h->ytabOff[l]; };

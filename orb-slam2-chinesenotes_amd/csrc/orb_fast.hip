@@ -568,7 +568,9 @@ void orb_launch_fast_strips(hipStream_t st, const OrbGeom& G, const uint8_t* pyr
                        orb_fast_lds_bytes(pdw, rowsMax, candCap), st, G, pyr, pyrSlab, strips, pathTab, cand, candSlab,
                        candCount, errFlags, ovfCount, ovfList, iniTh, minTh, pdw, rowsMax, candCap, nStrips, nFrames, inv);
     const long long all = (long long)nStrips * nFrames;
-    hipLaunchKernelGGL(k_fast_strips_dense, dim3((unsigned)std::min<long long>(all, 2048)), dim3(WAVE),
+    // (the list is almost always empty: a small grid keeps this launch short in a single frame's chain; the kernel
+    // strides over the list whatever its length)
+    hipLaunchKernelGGL(k_fast_strips_dense, dim3((unsigned)std::max<long long>(16, std::min<long long>(all / 16, 2048))), dim3(WAVE),
                        orb_fast_dense_lds_bytes(pdw, rowsMax, sdw), st, G, pyr, pyrSlab, strips, pathTab, cand, candSlab,
                        candCount, errFlags, ovfCount, ovfList, iniTh, minTh, pdw, rowsMax, sdw);
 }

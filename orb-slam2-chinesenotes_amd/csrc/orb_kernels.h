@@ -3,7 +3,7 @@
 #include "orb_common.h"
 
 void orb_launch_copy_level0(hipStream_t st, const uint8_t* src, size_t rowStride, size_t frameStride,
-                            uint8_t* pyr, size_t pyrSlab, int w, int h, int pitch, int nFrames);
+                            uint8_t* pyr, size_t pyrSlab, int w, int h, int pitch, int nFrames, int* clr, int clrInts);
 bool orb_launch_resize_pair(hipStream_t st, uint8_t* pyr, size_t pyrSlab, const OrbLevelGeom& S, const OrbLevelGeom& M,
                             const OrbLevelGeom& D, const uint4* xqM, const int2* ytabM, const uint4* xqD, const int2* ytabD,
                             int nFrames);
