@@ -28,27 +28,29 @@ __device__ __forceinline__ unsigned qt_digit(unsigned long long k, int depth)
     return (unsigned)(k >> (ORB_KEY_PATH_SHIFT + 2 * (ORB_KEY_PATH_LEVELS - 1 - depth))) & 3u;
 }
 
-// first index in [lo,hi) whose digit at `depth` is >= q
-__device__ __forceinline__ int qt_lower(const unsigned long long* keys, int lo, int hi, int depth, unsigned q)
-{
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (qt_digit(keys[mid], depth) < q) lo = mid + 1; else hi = mid;
-    }
-    return lo;
-}
-
-// DivideNode: the three interior cut points of a node's key range
+// DivideNode: the three interior cut points of a node's key range.  The three searches (first key whose digit is >= 1,
+// >= 2, >= 3) run side by side over the whole range: three independent LDS reads in flight per step instead of a chain
+// of three dependent searches (the division passes are chains of dependent LDS round trips, nothing else).
 __device__ __forceinline__ int3 qt_cuts(const unsigned long long* keys, const QtNode nd)
 {
     int3 c;
     if (nd.depth >= ORB_KEY_PATH_LEVELS) {            // unreachable inside the supported image envelope
         c.x = c.y = c.z = nd.hi;
-    } else {
-        c.y = qt_lower(keys, nd.lo, nd.hi, nd.depth, 2);
-        c.x = qt_lower(keys, nd.lo, c.y, nd.depth, 1);
-        c.z = qt_lower(keys, c.y, nd.hi, nd.depth, 3);
+        return c;
     }
+    const int sh = ORB_KEY_PATH_SHIFT + 2 * (ORB_KEY_PATH_LEVELS - 1 - nd.depth);
+    int l1 = nd.lo, h1 = nd.hi, l2 = nd.lo, h2 = nd.hi, l3 = nd.lo, h3 = nd.hi;
+    while (l1 < h1 || l2 < h2 || l3 < h3) {
+        const int m1 = (l1 + h1) >> 1, m2 = (l2 + h2) >> 1, m3 = (l3 + h3) >> 1;
+        // (a finished search has l == h: its probe index may be nd.hi, one past the node -- clamp, the result is unused)
+        const unsigned d1 = (unsigned)(keys[min(m1, nd.hi - 1)] >> sh) & 3u;
+        const unsigned d2 = (unsigned)(keys[min(m2, nd.hi - 1)] >> sh) & 3u;
+        const unsigned d3 = (unsigned)(keys[min(m3, nd.hi - 1)] >> sh) & 3u;
+        if (l1 < h1) { if (d1 < 1u) l1 = m1 + 1; else h1 = m1; }
+        if (l2 < h2) { if (d2 < 2u) l2 = m2 + 1; else h2 = m2; }
+        if (l3 < h3) { if (d3 < 3u) l3 = m3 + 1; else h3 = m3; }
+    }
+    c.x = l1; c.y = l2; c.z = l3;
     return c;
 }
 
@@ -86,8 +88,12 @@ __device__ __forceinline__ void qt_body(unsigned long long* keys, int n, const O
                                         int3* cuts, int* va, int* vb, int* part, uint32_t* __restrict__ kpl,
                                         int* outCount, int* __restrict__ errFlags, int* sh)
 {
-    int& sh_size = sh[0]; int& sh_prevCount = sh[1]; int& sh_state = sh[2]; int& sh_inB = sh[3];
-    int& sh_prevInB = sh[4]; int& sh_tstar = sh[5];
+    // shared words: sh[0] number of roots, sh[1] / sh[2] the two "expandable children" counters (passes alternate between
+    // them: the one a pass does not count into is cleared for the next pass), sh[3] t* of the careful phase.
+    // The loop state itself (phase, list size, which buffers hold the lists) is kept in registers, computed redundantly by
+    // every thread from values all of them read after the same barrier: no thread-0 update + barrier at the end of a pass
+    // and none at its start (a pass is a chain of barrier-separated steps; two of seven were only that bookkeeping).
+    int& sh_tstar = sh[3];
     const int tid = threadIdx.x, T = blockDim.x;
     __syncthreads();
     orb_block_sort(keys, n);
@@ -105,29 +111,22 @@ __device__ __forceinline__ void qt_body(unsigned long long* keys, int n, const O
             if (a > lo) { QtNode nd; nd.lo = lo; nd.hi = a; nd.depth = 0; A[cnt++] = nd; }
             lo = a;
         }
-        sh_size = cnt;
-        sh_state = 0;
-        sh_inB = 0;
-        sh_prevInB = 0;
-        sh_prevCount = 0;
+        sh[0] = cnt;
+        sh[1] = 0;
+        sh[2] = 0;
     }
     __syncthreads();
 
-    while (true) {
-        const int state = sh_state;
-        const int size0 = sh_size;
-        const int pc = sh_prevCount;
-        QtNode* cur = sh_inB ? B : A;
-        QtNode* nxt = sh_inB ? A : B;
-        unsigned long long* prev = sh_prevInB ? prevB : prevA;
-        unsigned long long* prevNew = sh_prevInB ? prevA : prevB;
-        __syncthreads();                               // everyone holds the loop state before it is rewritten
-        if (state == 2) break;
-        if (state == 1 && pc == 0) {                   // nothing left to expand: size cannot change (:762)
-            if (tid == 0) sh_state = 2;
-            __syncthreads();
-            continue;
-        }
+    int state = 0;                                     // 0 full passes, 1 careful phase, 2 done
+    int size0 = sh[0], pc = 0, inB = 0, prevInB = 0, par = 0;
+    while (state != 2) {
+        if (state == 1 && pc == 0) break;              // nothing left to expand: size cannot change (:762)
+        QtNode* cur = inB ? B : A;
+        QtNode* nxt = inB ? A : B;
+        unsigned long long* prev = prevInB ? prevB : prevA;
+        unsigned long long* prevNew = prevInB ? prevA : prevB;
+        int* cntNow = &sh[1 + par];                    // this pass counts the expandable children here ...
+        int* cntNext = &sh[1 + (par ^ 1)];             // ... and clears the counter of the next pass
 
         if (state == 0) {
             // ---------------- one full pass over the list (:631-691), all nodes at once
@@ -141,8 +140,8 @@ __device__ __forceinline__ void qt_body(unsigned long long* keys, int n, const O
                     va[i] = (c.x > nd.lo) + (c.y > c.x) + (c.z > c.y) + (nd.hi > c.z);
                 }
             }
-            if (tid == 0) sh_prevCount = 0;
             __syncthreads();
+            if (tid == 0) *cntNext = 0;                // every thread has read it (before this barrier) in the pass before
             const int tot = qt_scan(va, size0, part);
             const int sTot = tot & 0xFFFF, kTot = tot >> 16;
             for (int i = tid; i < size0; i += T) {
@@ -162,7 +161,7 @@ __device__ __forceinline__ void qt_body(unsigned long long* keys, int n, const O
                             QtNode ch; ch.lo = a; ch.hi = b; ch.depth = nd.depth + 1;
                             nxt[pos] = ch;
                             if (b - a > 1) {
-                                const int slot = atomicAdd(&sh_prevCount, 1);
+                                const int slot = atomicAdd(cntNow, 1);
                                 prev[slot] = ((unsigned long long)(b - a) << 48) | ((unsigned long long)j << 24) |
                                              (unsigned long long)pos;
                             }
@@ -172,14 +171,13 @@ __device__ __forceinline__ void qt_body(unsigned long long* keys, int n, const O
                 }
             }
             __syncthreads();
-            if (tid == 0) {
-                const int size = sTot + kTot;
-                sh_size = size;
-                sh_inB ^= 1;
-                if (size >= N || size == size0) sh_state = 2;                 // :695
-                else if (size + 3 * sh_prevCount > N) sh_state = 1;           // :701
-            }
-            __syncthreads();
+            const int size = sTot + kTot;
+            pc = *cntNow;
+            inB ^= 1;
+            par ^= 1;
+            if (size >= N || size == size0) state = 2;                        // :695
+            else if (size + 3 * pc > N) state = 1;                            // :701
+            size0 = size;
         } else {
             // ---------------- careful phase (:703-765): largest first, stop as soon as size >= N
             orb_block_sort(prev, pc);                    // ascending (size, seq); processed from the back (:711-713)
@@ -191,10 +189,9 @@ __device__ __forceinline__ void qt_body(unsigned long long* keys, int n, const O
                 va[t] = (c.x > nd.lo) + (c.y > c.x) + (c.z > c.y) + (nd.hi > c.z);   // children of candidate t
             }
             for (int i = tid; i < size0; i += T) vb[i] = 1;                   // alive flags of the current list
-            if (tid == 0) sh_tstar = pc;
+            if (tid == 0) { sh_tstar = pc; *cntNext = 0; }
             __syncthreads();
-            const int sAll = qt_scan(va, pc, part);    // va[t] = children created before candidate t
-            (void)sAll;
+            (void)qt_scan(va, pc, part);               // va[t] = children created before candidate t
             // size after candidate t has been divided = size0 + (va[t] + children(t)) - (t + 1)
             for (int t = tid; t < pc; t += T) {
                 const int idx = (int)(prev[pc - 1 - t] & 0xFFFFFF);
@@ -205,10 +202,7 @@ __device__ __forceinline__ void qt_body(unsigned long long* keys, int n, const O
             }
             __syncthreads();
             const int P = min(pc, sh_tstar + 1);       // candidates actually divided before the break (:758)
-            __syncthreads();
             for (int t = tid; t < P; t += T) vb[(int)(prev[pc - 1 - t] & 0xFFFFFF)] = 0;     // erased parents
-            if (tid == 0) sh_prevCount = 0;
-            __syncthreads();
             // children of the first P candidates
             int sTot;
             {
@@ -217,6 +211,7 @@ __device__ __forceinline__ void qt_body(unsigned long long* keys, int n, const O
                 const int3 c = cuts[P - 1];
                 sTot = va[P - 1] + (c.x > nd.lo) + (c.y > c.x) + (c.z > c.y) + (nd.hi > c.z);
             }
+            __syncthreads();
             const int kTot = qt_scan(vb, size0, part); // vb[i] = position of alive node i among the alive ones
             for (int t = tid; t < P; t += T) {
                 const int idx = (int)(prev[pc - 1 - t] & 0xFFFFFF);
@@ -232,7 +227,7 @@ __device__ __forceinline__ void qt_body(unsigned long long* keys, int n, const O
                         QtNode ch; ch.lo = a; ch.hi = b; ch.depth = nd.depth + 1;
                         nxt[pos] = ch;
                         if (b - a > 1) {
-                            const int slot = atomicAdd(&sh_prevCount, 1);
+                            const int slot = atomicAdd(cntNow, 1);
                             const unsigned long long e = ((unsigned long long)(b - a) << 48) |
                                                          ((unsigned long long)j << 24) | (unsigned long long)pos;
                             prevNew[slot] = e;
@@ -249,20 +244,19 @@ __device__ __forceinline__ void qt_body(unsigned long long* keys, int n, const O
                 if (next != here) nxt[sTot + here] = nd;
             }
             __syncthreads();
-            if (tid == 0) {
-                const int size = sTot + kTot;
-                sh_size = size;
-                sh_inB ^= 1;
-                sh_prevInB ^= 1;
-                if (size >= N || size == size0) sh_state = 2;                 // :762
-            }
-            __syncthreads();
+            const int size = sTot + kTot;
+            pc = *cntNow;
+            inB ^= 1;
+            prevInB ^= 1;
+            par ^= 1;
+            if (size >= N || size == size0) state = 2;                        // :762
+            size0 = size;
         }
     }
 
     // ---- keep the best key of every node, in list order (:770-789)
-    const QtNode* fin = sh_inB ? B : A;
-    const int size = sh_size;
+    const QtNode* fin = inB ? B : A;
+    const int size = size0;
     if (size > L.kpCap) {
         if (tid == 0) { orb_flag_error(errFlags, f, 2); *outCount = 0; }
         return;
@@ -303,7 +297,7 @@ __global__ __launch_bounds__(256) void k_quadtree(const OrbGeom G, unsigned long
     int* va = reinterpret_cast<int*>(cuts + nodeCap);
     int* vb = va + nodeCap;
     int* part = vb + nodeCap;
-    __shared__ int sh[8];                              // size, prevCount, state (0 full pass, 1 careful, 2 done), inB, prevInB, tstar
+    __shared__ int sh[4];                              // root count, two child counters, t* (see qt_body)
 
     // grid = (frames, levels): workgroups are dealt round-robin over the 8 XCDs in linear order, so with the frame
     // index fastest every XCD gets the same mix of levels (level fastest would send ALL level-0 workgroups, the
