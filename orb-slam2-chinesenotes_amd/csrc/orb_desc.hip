@@ -36,16 +36,12 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
     const float p5 = __uint_as_float(0x410e9fbfu), p7 = __uint_as_float(0xc0228ad9u);
     const float eps = 2.2204460492503131e-16f;
     const float ax = fabsf(x), ay = fabsf(y);
-    float a, c, c2;
-    if (ax >= ay) {
-        c = __fdiv_rn(ay, __fadd_rn(ax, eps));
-        c2 = __fmul_rn(c, c);
-        a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
-    } else {
-        c = __fdiv_rn(ax, __fadd_rn(ay, eps));
-        c2 = __fmul_rn(c, c);
-        a = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
-    }
+    // one division for both octant halves: c = min(ax, ay) / (max(ax, ay) + eps), picked as the reference picks them
+    const bool xGe = ax >= ay;
+    const float c = __fdiv_rn(xGe ? ay : ax, __fadd_rn(xGe ? ax : ay, eps));
+    const float c2 = __fmul_rn(c, c);
+    float a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+    if (!xGe) a = __fsub_rn(90.f, a);
     if (x < 0) a = __fsub_rn(180.f, a);
     if (y < 0) a = __fsub_rn(360.f, a);
     return a;
@@ -69,7 +65,7 @@ __device__ __forceinline__ void hblur4(unsigned d0, unsigned d1, unsigned d2, un
 __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_orient_desc(const OrbGeom G, const uint8_t* __restrict__ pyr,
                                                       size_t pyrSlab, const uint32_t* __restrict__ kpl,
                                                       const int* __restrict__ kpCount,
-                                                      const int8_t* __restrict__ pattern,
+                                                      const float4* __restrict__ patF,
                                                       const uint4* __restrict__ angTab,
                                                       orb_keypoint* __restrict__ kpsOut,
                                                       uint8_t* __restrict__ descOut, int cap,
@@ -111,8 +107,8 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     const uint32_t packed = kpl[(size_t)f * G.kpSlab + slot];
     // constant-table loads are issued here, long before their use, so that their latency hides behind the patch
     // staging (one wave per workgroup: nothing else would cover it)
-    const char4* pat4 = reinterpret_cast<const char4*>(pattern);
-    const char4 q0 = pat4[lane], q1 = pat4[64 + lane], q2 = pat4[128 + lane], q3 = pat4[192 + lane];
+    // (the pattern as floats: k_copy_level0 spreads the int8 pairs once per batch, 16 conversions per lane saved here)
+    const float4 q0 = patF[lane], q1 = patF[64 + lane], q2 = patF[128 + lane], q3 = patF[192 + lane];
     const int angV = (min(lane, 61) >> 1) - 15, angH = lane & 1;
     const uint4* angT = angTab + ((angV < 0 ? -angV : angV) * 2 + angH) * 2;
     const uint4 mk = angT[0], wt = angT[1];
@@ -205,8 +201,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     const unsigned kBias = 0x4B400000u;
     // row index through a 24-bit multiply-add: the low 24 bits of the biased row are 0x400000 + ir
     const unsigned idxC = (unsigned)((PR - 3) * HP + xoff + PR) - 0x400000u * (unsigned)HP - kBias;
-    auto sample = [&](int pxi, int pyi) -> int {
-        const float px = (float)pxi, py = (float)pyi;
+    auto sample = [&](float px, float py) -> int {
         const float fr = __fadd_rn(__fmul_rn(px, b), __fmul_rn(py, a));
         const float fc = __fsub_rn(__fmul_rn(px, a), __fmul_rn(py, b));
         const unsigned br = __float_as_uint(__fadd_rn(fr, 12582912.f)), bc = __float_as_uint(__fadd_rn(fc, 12582912.f));
@@ -241,16 +236,16 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
 }
 
 void orb_launch_orient_desc(hipStream_t st, const OrbGeom& G, const uint8_t* pyr, size_t pyrSlab,
-                            const uint32_t* kpl, const int* kpCount, const int8_t* pattern, const uint4* angTab,
+                            const uint32_t* kpl, const int* kpCount, const float* patternF, const uint4* angTab,
                             orb_keypoint* kps, uint8_t* desc, int cap, int32_t* counts, int* errFlags,
                             int nFrames)
 {
     unsigned inv = 0;
     const unsigned wgs = orb_xcd_grid((unsigned)G.kpSlab, nFrames, &inv);
     if (wgs)
-        hipLaunchKernelGGL(k_orient_desc, dim3(wgs), dim3(WAVE), 0, st, G, pyr, pyrSlab, kpl, kpCount, pattern, angTab, kps,
+        hipLaunchKernelGGL(k_orient_desc, dim3(wgs), dim3(WAVE), 0, st, G, pyr, pyrSlab, kpl, kpCount, reinterpret_cast<const float4*>(patternF), angTab, kps,
                            desc, cap, counts, errFlags, nFrames, inv);
     else
         hipLaunchKernelGGL(k_orient_desc, dim3(G.kpSlab, nFrames), dim3(WAVE), 0, st, G, pyr, pyrSlab, kpl, kpCount,
-                           pattern, angTab, kps, desc, cap, counts, errFlags, nFrames, 0u);
+                           reinterpret_cast<const float4*>(patternF), angTab, kps, desc, cap, counts, errFlags, nFrames, 0u);
 }

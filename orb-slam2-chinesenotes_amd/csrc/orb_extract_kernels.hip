@@ -21,13 +21,20 @@
 __global__ __launch_bounds__(256) void k_copy_level0(const uint8_t* __restrict__ src, size_t rowStride,
                                                      size_t frameStride, uint8_t* __restrict__ pyr,
                                                      size_t pyrSlab, int w, int h, int pitch, int vec16, int x16n,
-                                                     unsigned invx, int* __restrict__ clr, int clrInts)
+                                                     unsigned invx, int* __restrict__ clr, int clrInts,
+                                                     const char4* __restrict__ pat8, float4* __restrict__ patF)
 {
     // the first kernel of the chain also clears the batch's status words (error flags, candidate / keypoint counters,
     // overflow list head): one launch less than a memset node in front of it (5 us of a single frame's chain)
     {
         const unsigned g = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
         if (g < (unsigned)clrInts) clr[g] = 0;
+        // ... and spreads the 256 BRIEF pairs (int8 x0,y0,x1,y1) into the float4 table k_orient_desc reads: done per
+        // batch, so whoever wrote the int8 pattern (orb_extractor_set_pattern*, an RCCL broadcast) needs no hook
+        if (g < 256u) {
+            const char4 q = pat8[g];
+            patF[g] = make_float4((float)q.x, (float)q.y, (float)q.z, (float)q.w);
+        }
     }
     // flattened (row, 16-byte column) index: every lane of every wave has work (a 640-px row is only 40 columns)
     const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -279,14 +286,15 @@ __global__ __launch_bounds__(256) void k_resize_pair(uint8_t* __restrict__ pyr, 
 static unsigned inv32(int d) { return d <= 1 ? 0u : (unsigned)(((1ull << 32) + d - 1) / d); }
 
 void orb_launch_copy_level0(hipStream_t st, const uint8_t* src, size_t rowStride, size_t frameStride,
-                            uint8_t* pyr, size_t pyrSlab, int w, int h, int pitch, int nFrames, int* clr, int clrInts)
+                            uint8_t* pyr, size_t pyrSlab, int w, int h, int pitch, int nFrames, int* clr, int clrInts,
+                            const int8_t* pat8, float* patF)
 {
     const int vec16 = ((reinterpret_cast<uintptr_t>(src) | rowStride | frameStride) & 15) == 0;
     const int x16 = (w + 15) / 16;
     const int total = x16 * h;
     dim3 grid((total + 255) / 256, nFrames);
     hipLaunchKernelGGL(k_copy_level0, grid, dim3(256), 0, st, src, rowStride, frameStride, pyr, pyrSlab, w, h, pitch, vec16,
-                       x16, inv32(x16), clr, clrInts);
+                       x16, inv32(x16), clr, clrInts, reinterpret_cast<const char4*>(pat8), reinterpret_cast<float4*>(patF));
 }
 
 void orb_launch_resize(hipStream_t st, uint8_t* pyr, size_t pyrSlab, const OrbLevelGeom& src,

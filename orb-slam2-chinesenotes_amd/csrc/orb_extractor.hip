@@ -172,6 +172,7 @@ extern "C" int orb_extractor_create(const orb_extractor_params* p, int device_id
     if (rc == ORB_OK) {
         if (hipMemcpy(h->dPattern.p, ORB_BRIEF_PATTERN_XY, 1024, hipMemcpyHostToDevice) != hipSuccess) rc = ORB_ERR_HIP;
     }
+    if (rc == ORB_OK) rc = h->dPatternF.ensure(256 * 16);
     if (rc == ORB_OK) rc = h->dAngTab.ensure(16 * 2 * 32);
     if (rc == ORB_OK) {
         // IC_Angle tables (k_orient_desc): per (|v|, half row) 16 mask bytes (1 inside |u| <= umax[|v|]) and
@@ -198,7 +199,7 @@ extern "C" void orb_extractor_destroy(orb_extractor* h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    DevBuf* bufs[] = {&h->dPattern, &h->dAngTab, &h->dCells, &h->dXtab, &h->dYtab, &h->dXq, &h->dPath, &h->dPyr, &h->dCand, &h->dKpl, &h->dOvf,
+    DevBuf* bufs[] = {&h->dPattern, &h->dPatternF, &h->dAngTab, &h->dCells, &h->dXtab, &h->dYtab, &h->dXq, &h->dPath, &h->dPyr, &h->dCand, &h->dKpl, &h->dOvf,
                       &h->dStat, &h->dImgs, &h->dKps, &h->dDesc, &h->dCounts,
                       &h->dStereo, &h->dStereoIn};
     for (DevBuf* b : bufs) b->release();
@@ -337,9 +338,10 @@ extern "C" int orb_extract_batch_device(orb_extractor* h, const uint8_t* d_imgs,
     const bool prof = h->profiling;
     hipEvent_t* pe = h->ev[h->profCount % orb_extractor::kProfSlots];
     if (prof) ORB_HIP_TRY(hipEventRecord(pe[0], st));
-    // (also clears the status block behind the sticky word: error flags, counters, overflow list head)
+    // (also clears the status block behind the sticky word -- error flags, counters, overflow list head -- and spreads the
+    // int8 BRIEF pattern into the float table the descriptor kernel reads)
     orb_launch_copy_level0(st, d_imgs, rowStride, frameStride, pyr, h->pyrSlab, G.L[0].w, G.L[0].h, G.L[0].pitch, n, h->errP(),
-                           (int)orb_extractor::batchInts(n));
+                           (int)orb_extractor::batchInts(n), h->patternPtr, (float*)h->dPatternF.p);
     {
         auto xq_of = [&](int l) { return h->xqOff[l] >= 0 ? (const uint4*)h->dXq.p + h->xqOff[l] : (const uint4*)nullptr; };
         auto ytab_of = [&](int l) { return (const int2*)h->dYtab.p + h->ytabOff[l]; };
@@ -362,7 +364,7 @@ extern "C" int orb_extract_batch_device(orb_extractor* h, const uint8_t* d_imgs,
     if (prof) ORB_HIP_TRY(hipEventRecord(pe[2], st));
     orb_launch_quadtree(st, G, scand, h->candSlab, scc, skpl, skc, serr, h->sortCap, h->nodeCap, n);
     if (prof) ORB_HIP_TRY(hipEventRecord(pe[3], st));
-    orb_launch_orient_desc(st, G, pyr, h->pyrSlab, skpl, skc, h->patternPtr, (const uint4*)h->dAngTab.p, d_kps, d_desc, cap,
+    orb_launch_orient_desc(st, G, pyr, h->pyrSlab, skpl, skc, (const float*)h->dPatternF.p, (const uint4*)h->dAngTab.p, d_kps, d_desc, cap,
                            d_counts, serr, n);
     if (prof) {
         ORB_HIP_TRY(hipEventRecord(pe[4], st));

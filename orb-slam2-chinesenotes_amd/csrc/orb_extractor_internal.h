@@ -60,7 +60,7 @@ struct orb_extractor {
     bool geomDirty = false;                 // strip lengths changed: rebuild the geometry on the next call
 
     // device memory
-    DevBuf dPattern, dAngTab, dCells, dXtab, dYtab, dXq, dPath;   // constants
+    DevBuf dPattern, dPatternF, dAngTab, dCells, dXtab, dYtab, dXq, dPath;   // constants
     std::vector<size_t> xtabOff, ytabOff;       // per level offsets (in int2 units)
     std::vector<long long> xqOff;               // per level offset into dXq (uint4 units), -1 = level not eligible
     DevBuf dPyr, dCand, dKpl, dOvf;             // per-batch scratch (dOvf: FAST strips to redo densely)

@@ -3,7 +3,7 @@
 #include "orb_common.h"
 
 void orb_launch_copy_level0(hipStream_t st, const uint8_t* src, size_t rowStride, size_t frameStride,
-                            uint8_t* pyr, size_t pyrSlab, int w, int h, int pitch, int nFrames, int* clr, int clrInts);
+                            uint8_t* pyr, size_t pyrSlab, int w, int h, int pitch, int nFrames, int* clr, int clrInts, const int8_t* pat8, float* patF);
 bool orb_launch_resize_pair(hipStream_t st, uint8_t* pyr, size_t pyrSlab, const OrbLevelGeom& S, const OrbLevelGeom& M,
                             const OrbLevelGeom& D, const uint4* xqM, const int2* ytabM, const uint4* xqD, const int2* ytabD,
                             int nFrames);
@@ -20,6 +20,6 @@ void orb_launch_quadtree(hipStream_t st, const OrbGeom& G, unsigned long long* c
                          const int* candCount, uint32_t* kpl, int* kpCount, int* errFlags, int sortCap,
                          int nodeCap, int nFrames);
 void orb_launch_orient_desc(hipStream_t st, const OrbGeom& G, const uint8_t* pyr, size_t pyrSlab,
-                            const uint32_t* kpl, const int* kpCount, const int8_t* pattern, const uint4* angTab,
+                            const uint32_t* kpl, const int* kpCount, const float* patternF, const uint4* angTab,
                             orb_keypoint* kps, uint8_t* desc, int cap, int32_t* counts, int* errFlags,
                             int nFrames);
