@@ -144,12 +144,13 @@ __global__ __launch_bounds__(256) void k_resize_level4(uint8_t* __restrict__ pyr
 // (p0*a0 + p1*a1), and all products fit 24-bit multiplies.  Valid while o_i + 1 <= 7, i.e. scale <= 3.
 typedef unsigned short orb_u16x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ unsigned resize_px(uint2 wa, uint2 wb, unsigned sel, unsigned co, unsigned b0, unsigned b1)
+// bs0 / bs1: the row coefficients b0 / b1 (0..2048) shifted left by 16, so that (x * b) >> 16 is ONE v_mul_hi_u32
+__device__ __forceinline__ unsigned resize_px(uint2 wa, uint2 wb, unsigned sel, unsigned co, unsigned bs0, unsigned bs1)
 {
     const unsigned pa = __builtin_amdgcn_perm(wa.y, wa.x, sel), pb = __builtin_amdgcn_perm(wb.y, wb.x, sel);
     const unsigned h0 = __builtin_amdgcn_udot2(__builtin_bit_cast(orb_u16x2, pa), __builtin_bit_cast(orb_u16x2, co), 0u, false);
     const unsigned h1 = __builtin_amdgcn_udot2(__builtin_bit_cast(orb_u16x2, pb), __builtin_bit_cast(orb_u16x2, co), 0u, false);
-    return ((__umul24(h0 >> 4, b0) >> 16) + (__umul24(h1 >> 4, b1) >> 16) + 2) >> 2;        // <= 255
+    return (__umulhi(h0 >> 4, bs0) + __umulhi(h1 >> 4, bs1) + 2) >> 2;                        // <= 255
 }
 
 #define RESIZE_ROWS 4      // output rows per thread: the 40-byte column entry and the index decode are paid once
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(256) void k_resize_level4p(uint8_t* __restrict__ py
 #pragma unroll
     for (int r = 0; r < RESIZE_ROWS; r++) {
         const unsigned y = y0 + r;
-        const unsigned b0 = (unsigned)ty[r].y & 0xffffu, b1 = (unsigned)ty[r].y >> 16;
+        const unsigned b0 = (unsigned)ty[r].y << 16, b1 = (unsigned)ty[r].y & 0xffff0000u;   // pre-shifted, see resize_px
         const unsigned v0 = resize_px(wA0[r], wB0[r], q0.z, q1.z, b0, b1);
         const unsigned v1 = resize_px(wA0[r], wB0[r], q0.w, q1.w, b0, b1);
         const unsigned v2 = resize_px(wA1[r], wB1[r], q1.x, q2.x, b0, b1);
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(256) void k_resize_pair(uint8_t* __restrict__ pyr, 
 #pragma unroll
         for (int r = 0; r < RESIZE_ROWS; r++) {
             const unsigned lr = g * RESIZE_ROWS + r;
-            const unsigned b0 = (unsigned)ty[r].y & 0xffffu, b1 = (unsigned)ty[r].y >> 16;
+            const unsigned b0 = (unsigned)ty[r].y << 16, b1 = (unsigned)ty[r].y & 0xffff0000u;   // pre-shifted, see resize_px
             const unsigned out = resize_px(wA0[r], wB0[r], q0.z, q1.z, b0, b1) | (resize_px(wA0[r], wB0[r], q0.w, q1.w, b0, b1) << 8) |
                                  (resize_px(wA1[r], wB1[r], q1.x, q2.x, b0, b1) << 16) | (resize_px(wA1[r], wB1[r], q1.y, q2.y, b0, b1) << 24);
             if ((int)lr < nM) {
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(256) void k_resize_pair(uint8_t* __restrict__ pyr, 
         for (int r = 0; r < RESIZE_ROWS; r++) {
             const int lr = (int)g * RESIZE_ROWS + r;
             const int2 ty = ytabD[min(R0 + lr, R1 - 1)];
-            const unsigned b0 = (unsigned)ty.y & 0xffffu, b1 = (unsigned)ty.y >> 16;
+            const unsigned b0 = (unsigned)ty.y << 16, b1 = (unsigned)ty.y & 0xffff0000u;         // pre-shifted, see resize_px
             const uint32_t* rowA = band + (unsigned)(((int)((unsigned)ty.x & 0xffffu) - m0) * ldsPitchDw);
             const uint32_t* rowB = band + (unsigned)((min((int)((unsigned)ty.x >> 16), m1) - m0) * ldsPitchDw);
             const uint2 wA0 = make_uint2(rowA[ia], rowA[ia + 1]), wA1 = make_uint2(rowA[ib], rowA[ib + 1]);
