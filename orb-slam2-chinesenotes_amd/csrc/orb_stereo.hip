@@ -29,6 +29,39 @@ __device__ __forceinline__ unsigned st_umin_dpp(unsigned v)
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// Right-image side of the coarse search, once per pair instead of once per LEFT keypoint: per right keypoint its row
+// band (:528-540: r = 2 * scale[octave], rows floor(y - r) .. ceil(y + r)), octave and x as one 16-byte record, and --
+// the extractor emits keypoints level after level -- the index at which every level starts, so that a left keypoint of
+// level l scans only levels l-1 .. l+1 (:583).  Keypoints in any other order (a caller's own arrays) raise `unsorted`
+// and are scanned in full.  lv = [nPairs][ORB_MAX_LEVELS + 1].
+__global__ __launch_bounds__(256) void k_stereo_prep(const OrbGeom G, const orb_keypoint* __restrict__ kR0, int nR,
+                                                     const int32_t* __restrict__ countsR, size_t stride,
+                                                     uint4* __restrict__ rec0, size_t recStride, int* __restrict__ lv0,
+                                                     int* __restrict__ unsorted0)
+{
+    const int pr = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int Nr = countsR ? min(countsR[pr], (int)stride) : nR;
+    int* lv = lv0 + (size_t)pr * (ORB_MAX_LEVELS + 1);
+    const int nl = G.nlevels;
+    if (Nr <= 0) {
+        if (i == 0)
+            for (int o = 0; o <= nl; o++) lv[o] = 0;
+        return;
+    }
+    if (i >= Nr) return;
+    const orb_keypoint* kR = kR0 + stride * pr;
+    const orb_keypoint kp = kR[i];
+    const int oc = min(max(kp.octave, 0), nl - 1);
+    const float r = __fmul_rn(2.0f, G.L[oc].scale);                          // :531
+    const int maxr = (int)ceilf(__fadd_rn(kp.y, r)), minr = (int)floorf(__fsub_rn(kp.y, r));
+    rec0[recStride * pr + i] = make_uint4((unsigned)minr, (unsigned)maxr, (unsigned)kp.octave, __float_as_uint(kp.x));
+    const int prevOc = i > 0 ? min(max(kR[i - 1].octave, 0), nl - 1) : -1;
+    if (oc < prevOc) unsorted0[pr] = 1;
+    for (int o = prevOc + 1; o <= oc; o++) lv[o] = i;
+    if (i == Nr - 1)
+        for (int o = oc + 1; o <= nl; o++) lv[o] = Nr;
+}
+
 // grid (left keypoint, pair): pair p uses frames frame0 + p of the two pyramids and rows [p * stride, ...) of the
 // keypoint / descriptor / result arrays; the keypoint counts come from the host (single pair) or from device arrays
 // (batch: the extractors' d_counts, no host round trip between extraction and search).
@@ -43,7 +76,9 @@ __global__ __launch_bounds__(WAVE) void k_stereo_match(const OrbGeom G, const ui
                                                        float mbf, float* __restrict__ uRight0,
                                                        float* __restrict__ depth0,
                                                        unsigned long long* __restrict__ pairs0,
-                                                       int* __restrict__ pairCount0)
+                                                       const uint4* __restrict__ rec0,
+                                                       size_t recStride, const int* __restrict__ lv0,
+                                                       const int* __restrict__ unsorted0)
 {
     __shared__ int IL[11][11];
     __shared__ int IR[11][21];
@@ -59,9 +94,10 @@ __global__ __launch_bounds__(WAVE) void k_stereo_match(const OrbGeom G, const ui
     float* uRight = uRight0 + stride * pr;
     float* depth = depth0 + stride * pr;
     unsigned long long* pairs = pairs0 + stride * pr;
-    int* pairCount = pairCount0 + pr;
     if (iL >= N) return;
-    if (lane == 0) { uRight[iL] = -1.0f; depth[iL] = -1.0f; }
+    // (every left keypoint owns slot iL of `pairs`: ~0 = no match.  One atomic slot counter per pair used to serialise all
+    // the waves of a batch on ONE cache line of the L2: 64 k returning atomics took longer than the search itself)
+    if (lane == 0) { uRight[iL] = -1.0f; depth[iL] = -1.0f; pairs[iL] = ~0ull; }
     const orb_keypoint kpL = kL[iL];
     const int levelL = kpL.octave;
     const float vL = kpL.y, uL = kpL.x;
@@ -77,24 +113,47 @@ __global__ __launch_bounds__(WAVE) void k_stereo_match(const OrbGeom G, const ui
         const uint4 lo = reinterpret_cast<const uint4*>(dL + (size_t)iL * 32)[0], hi = reinterpret_cast<const uint4*>(dL + (size_t)iL * 32)[1];
         dl[0] = lo.x; dl[1] = lo.y; dl[2] = lo.z; dl[3] = lo.w; dl[4] = hi.x; dl[5] = hi.y; dl[6] = hi.z; dl[7] = hi.w;
     }
-    unsigned best = 0xFFFFFFFFu;
-    for (int base = 0; base < Nr; base += WAVE) {
-        const int iR = base + lane;
-        unsigned mine = 0xFFFFFFFFu;
-        if (iR < Nr) {
-            const orb_keypoint kp = kR[iR];
-            const float r = __fmul_rn(2.0f, G.L[kp.octave].scale);            // :531
-            const int maxr = (int)ceilf(__fadd_rn(kp.y, r)), minr = (int)floorf(__fsub_rn(kp.y, r));
-            if (row >= minr && row <= maxr && kp.octave >= levelL - 1 && kp.octave <= levelL + 1 && kp.x >= minU &&
-                kp.x <= maxU) {
-                const uint4 lo = reinterpret_cast<const uint4*>(dR + (size_t)iR * 32)[0], hi = reinterpret_cast<const uint4*>(dR + (size_t)iR * 32)[1];
-                const int dist = __popc(dl[0] ^ lo.x) + __popc(dl[1] ^ lo.y) + __popc(dl[2] ^ lo.z) + __popc(dl[3] ^ lo.w) +
-                                 __popc(dl[4] ^ hi.x) + __popc(dl[5] ^ hi.y) + __popc(dl[6] ^ hi.z) + __popc(dl[7] ^ hi.w);
-                mine = ((unsigned)dist << 16) | (unsigned)iR;
-            }
-        }
-        best = min(best, st_umin_dpp(mine));
+    // candidates come from the per-pair records of k_stereo_prep; only the levels levelL-1 .. levelL+1 are scanned (when
+    // the right keypoints are in level order).  A wave is a chain of dependent global round trips and nothing else, so the
+    // scan is arranged for FEW of them: every lane keeps its own best over the records lane, lane + 64, ... (one wave
+    // reduction at the end: the minimum of (distance << 16 | index) IS "first minimum wins"), four chunks of 64 records
+    // are requested at once, then the descriptors of their candidates, then the distances.
+    const uint4* recs = rec0 + recStride * pr;
+    int scanLo = 0, scanHi = Nr;
+    if (!unsorted0[pr]) {
+        const int* lv = lv0 + (size_t)pr * (ORB_MAX_LEVELS + 1);
+        scanLo = lv[min(max(levelL - 1, 0), G.nlevels)];
+        scanHi = lv[min(max(levelL + 2, 0), G.nlevels)];
     }
+    unsigned best = 0xFFFFFFFFu;
+    for (int base = scanLo & ~(WAVE - 1); base < scanHi; base += 4 * WAVE) {
+        uint4 rc[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) rc[k] = recs[min(base + k * WAVE + lane, Nr - 1)];
+        bool cand[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int oct = (int)rc[k].z;
+            const float x = __uint_as_float(rc[k].w);
+            cand[k] = base + k * WAVE + lane < scanHi && row >= (int)rc[k].x && row <= (int)rc[k].y && oct >= levelL - 1 &&
+                      oct <= levelL + 1 && x >= minU && x <= maxU;
+        }
+        uint4 lo[4], hi[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (cand[k]) {
+                const uint4* d = reinterpret_cast<const uint4*>(dR + (size_t)(base + k * WAVE + lane) * 32);
+                lo[k] = d[0]; hi[k] = d[1];
+            }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (cand[k]) {
+                const int dist = __popc(dl[0] ^ lo[k].x) + __popc(dl[1] ^ lo[k].y) + __popc(dl[2] ^ lo[k].z) + __popc(dl[3] ^ lo[k].w) +
+                                 __popc(dl[4] ^ hi[k].x) + __popc(dl[5] ^ hi[k].y) + __popc(dl[6] ^ hi[k].z) + __popc(dl[7] ^ hi[k].w);
+                best = min(best, ((unsigned)dist << 16) | (unsigned)(base + k * WAVE + lane));
+            }
+    }
+    best = st_umin_dpp(best);
     const int bestDist = (best == 0xFFFFFFFFu) ? 100 : min(100, (int)(best >> 16));   // init TH_HIGH, strict <
     if (!(bestDist < 75) || best == 0xFFFFFFFFu) return;                              // thOrbDist (:518, :599)
     const int bestIdxR = (int)(best & 0xFFFFu);
@@ -153,37 +212,39 @@ __global__ __launch_bounds__(WAVE) void k_stereo_match(const OrbGeom G, const ui
         }
         depth[iL] = __fdiv_rn(mbf, disparity);
         uRight[iL] = bestuR;
-        const int slot = atomicAdd(pairCount, 1);
-        pairs[slot] = ((unsigned long long)(unsigned)bestSad << 32) | (unsigned)iL;
+        pairs[iL] = ((unsigned long long)(unsigned)bestSad << 32) | (unsigned)iL;
     }
 }
 
-// one workgroup per pair: sort (SAD, index), median, cut >= 1.5 * 1.4 * median (:685-698).  The pairs are sorted in LDS
-// (orb_block_sort) when they fit ldsCap entries, in global memory otherwise.
-__global__ __launch_bounds__(1024) void k_stereo_outliers(unsigned long long* __restrict__ pairs0, size_t stride,
-                                                          const int* __restrict__ pairCount0,
+// one workgroup per pair: sort the left keypoints' (SAD, index) slots (unmatched ones are ~0 and end up behind), median
+// of the matched ones, cut >= 1.5 * 1.4 * median (:685-698).  Sorted in LDS (orb_block_sort) when the slots fit ldsCap
+// entries, in global memory otherwise.
+__global__ __launch_bounds__(1024) void k_stereo_outliers(unsigned long long* __restrict__ pairs0, size_t stride, int nL,
+                                                          const int32_t* __restrict__ countsL,
                                                           float* __restrict__ uRight0, float* __restrict__ depth0, int ldsCap)
 {
     extern __shared__ unsigned long long spairs[];
+    __shared__ int nValid;
     const int pr = blockIdx.x;
     unsigned long long* gp = pairs0 + stride * pr;
     float* uRight = uRight0 + stride * pr;
     float* depth = depth0 + stride * pr;
-    const int n = pairCount0[pr];
-    if (n == 0) return;                                            // reference: UB on the empty vector (:686)
+    const int nAll = countsL ? min(countsL[pr], (int)stride) : nL;
+    if (nAll <= 0) return;
     unsigned long long* pairs = gp;
-    if (n <= ldsCap) {
-        for (int i = threadIdx.x; i < n; i += blockDim.x) spairs[i] = gp[i];
+    if (nAll <= ldsCap) {
+        for (int i = threadIdx.x; i < nAll; i += blockDim.x) spairs[i] = gp[i];
         __syncthreads();
-        orb_block_sort(spairs, n);
+        orb_block_sort(spairs, nAll);
         pairs = spairs;
     } else {
         int np2 = 1;
-        while (np2 < n) np2 <<= 1;
+        while (np2 < nAll) np2 <<= 1;
+        __syncthreads();
         for (int k = 2; k <= np2; k <<= 1) {
             for (int i = threadIdx.x; i < np2; i += blockDim.x) {
                 const int p = i ^ (k - 1);
-                if (p > i && p < n) {
+                if (p > i && p < nAll) {
                     const unsigned long long x = gp[i], y = gp[p];
                     if (x > y) { gp[i] = y; gp[p] = x; }
                 }
@@ -192,7 +253,7 @@ __global__ __launch_bounds__(1024) void k_stereo_outliers(unsigned long long* __
             for (int j = k >> 2; j > 0; j >>= 1) {
                 for (int i = threadIdx.x; i < np2; i += blockDim.x) {
                     const int p = i ^ j;
-                    if (p > i && p < n) {
+                    if (p > i && p < nAll) {
                         const unsigned long long x = gp[i], y = gp[p];
                         if (x > y) { gp[i] = y; gp[p] = x; }
                     }
@@ -201,6 +262,17 @@ __global__ __launch_bounds__(1024) void k_stereo_outliers(unsigned long long* __
             }
         }
     }
+    if (threadIdx.x == 0) {                                        // number of matched keypoints: first ~0 in the sorted slots
+        int a = 0, b = nAll;
+        while (a < b) {
+            const int mid = (a + b) >> 1;
+            if (pairs[mid] != ~0ull) a = mid + 1; else b = mid;
+        }
+        nValid = a;
+    }
+    __syncthreads();
+    const int n = nValid;
+    if (n == 0) return;                                            // reference: UB on the empty vector (:686)
     const float median = (float)(int)(pairs[n / 2] >> 32);
     const float thDist = __fmul_rn(1.5f * 1.4f, median);
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
@@ -232,21 +304,31 @@ static int stereo_launch(orb_extractor* left, orb_extractor* right, int frameL, 
     ORB_HIP_TRY(hipSetDevice(left->device));
     int rc;
     const size_t perPair = stride;                                  // (SAD, index) slots per pair
-    if ((rc = left->dStereo.ensure((size_t)8 * perPair * nPairs + (size_t)4 * nPairs + 16)) != ORB_OK) return rc;
+    // scratch: pairs[perPair * nPairs] (u64, slot iL of pair p = left keypoint iL) | rec[recStride * nPairs] (uint4)
+    //          | unsorted[nPairs] (cleared) | lv[nPairs][ORB_MAX_LEVELS + 1]
+    const size_t nSlots = perPair * nPairs;
+    const size_t recStride = std::max<size_t>(stride, (size_t)(cR ? 0 : nR));       // single pair: stride is the LEFT count
+    const size_t nRecs = recStride * nPairs;
+    if ((rc = left->dStereo.ensure((size_t)8 * (nSlots + 1) + (size_t)16 * nRecs + (size_t)4 * nPairs * (2 + ORB_MAX_LEVELS + 1) + 16)) != ORB_OK)
+        return rc;
     hipStream_t st = left->stream;
     ORB_HIP_TRY(hipEventRecord(left->waitEv, right->stream));      // the right pyramid must be complete
     ORB_HIP_TRY(hipStreamWaitEvent(st, left->waitEv, 0));
     unsigned long long* pairs = (unsigned long long*)left->dStereo.p;
-    int* pairCount = (int*)(pairs + perPair * nPairs);
-    ORB_HIP_TRY(hipMemsetAsync(pairCount, 0, (size_t)4 * nPairs, st));
+    uint4* rec = (uint4*)(pairs + ((nSlots + 1) & ~(size_t)1));           // 16-byte aligned
+    int* unsorted = (int*)(rec + nRecs);
+    int* lv = unsorted + nPairs;
+    ORB_HIP_TRY(hipMemsetAsync(unsorted, 0, (size_t)4 * nPairs, st));
     const float maxD = mbf / mb;                                   // :546
     const int gridX = cL ? (int)stride : nL;
+    const int gridR = cR ? (int)stride : std::max(nR, 1);
+    hipLaunchKernelGGL(k_stereo_prep, dim3((gridR + 255) / 256, nPairs), dim3(256), 0, st, left->G, kR, nR, cR, stride, rec, recStride, lv, unsorted);
     hipLaunchKernelGGL(k_stereo_match, dim3(gridX, nPairs), dim3(WAVE), 0, st, left->G,
                        (const uint8_t*)left->dPyr.p + left->pyrSlab * frameL, left->pyrSlab,
                        (const uint8_t*)right->dPyr.p + right->pyrSlab * frameR, right->pyrSlab, kL, dL, nL, cL, kR, dR, nR, cR,
-                       stride, maxD, mbf, uR, dep, pairs, pairCount);
+                       stride, maxD, mbf, uR, dep, pairs, rec, recStride, lv, unsorted);
     const int ldsCap = (int)std::min<size_t>(stride, 4096);         // <= 32 KB of (SAD, index) pairs
-    hipLaunchKernelGGL(k_stereo_outliers, dim3(nPairs), dim3(1024), (size_t)8 * ldsCap, st, pairs, perPair, pairCount, uR, dep, ldsCap);
+    hipLaunchKernelGGL(k_stereo_outliers, dim3(nPairs), dim3(1024), (size_t)8 * ldsCap, st, pairs, perPair, nL, cL, uR, dep, ldsCap);
     ORB_HIP_TRY(hipGetLastError());
     return ORB_OK;
 }

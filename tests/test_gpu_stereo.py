@@ -69,6 +69,27 @@ def test_stereo_other_sizes_and_feature_counts(idx, w, h, nf):
         assert got_u.tobytes() == want_u.tobytes() and got_z.tobytes() == want_z.tobytes(), (nl, nr)
 
 
+def test_stereo_right_keypoints_in_any_order_and_more_right_than_left():
+    """The coarse search scans only the neighbouring pyramid levels when the right keypoints come level after level (the
+    extractor's order); a caller's own order (shuffled here: "first minimum wins" then follows THAT order) and a right
+    side larger than the left one go through the full scan -- both identical to the oracle on the same arrays."""
+    (exl, exr, kl, dl, kr, dr), (rl, rr) = _pair(310, 752, 480, 1200)
+    rng = np.random.default_rng(5)
+    perm = rng.permutation(len(kr))
+    krs, drs = kr[perm].copy(), np.ascontiguousarray(dr[perm])
+    want_u, want_z = oracle.stereo_matches(rl, rr, kl, dl, krs, drs, MB, MBF)
+    got_u, got_z = capi.stereo_match(exl, exr, kl, dl, krs, drs, MB, MBF)
+    assert (want_u >= 0).sum() > 0.2 * len(kl)
+    assert got_u.tobytes() == want_u.tobytes() and got_z.tobytes() == want_z.tobytes()
+    # 100 left keypoints (a slice keeps them level-ordered) against all right ones, ordered and shuffled
+    sl = np.sort(rng.permutation(len(kl))[:100])
+    for k2, d2 in ((kr, dr), (krs, drs)):
+        a = (kl[sl].copy(), np.ascontiguousarray(dl[sl]), k2, d2)
+        want_u, want_z = oracle.stereo_matches(rl, rr, *a, MB, MBF)
+        got_u, got_z = capi.stereo_match(exl, exr, *a, MB, MBF)
+        assert got_u.tobytes() == want_u.tobytes() and got_z.tobytes() == want_z.tobytes()
+
+
 def test_stereo_batch_of_pairs_in_one_launch():
     """orb_stereo_match_batch_device: 5 KITTI-sized pairs extracted as two device batches, the stereo search of all of
     them in ONE launch with the keypoint counts read on the device; every pair bit-exact against the oracle (which
