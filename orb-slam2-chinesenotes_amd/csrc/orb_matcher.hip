@@ -102,18 +102,24 @@ __device__ __forceinline__ int rot_bin(float angA, float angB)
     return bin;
 }
 
-__device__ __forceinline__ void three_maxima_dev(const int* counts, int& ind1, int& ind2, int& ind3)
+// ComputeThreeMaxima (:1663-1707) by one wave: the reference's sequential scan with strict > keeps, among equal counts,
+// the lower bin first, i.e. it selects by (count descending, bin ascending) -- three wave maxima of (count << 8 | 63 - bin),
+// empty bins (the scan never takes a count of 0) excluded.  (A serial 30-step loop by one thread, unrolled by the compiler
+// under this kernel's 64-VGPR limit, spilled ~150 scratch accesses into the tail of every pair.)
+__device__ __forceinline__ void three_maxima_wave(const int* hist, int* keep, int lane)
 {
-    int max1 = 0, max2 = 0, max3 = 0;
-    ind1 = ind2 = ind3 = -1;
-    for (int i = 0; i < HISTO_LENGTH; i++) {
-        const int s = counts[i];
-        if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
-        else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
-        else if (s > max3) { max3 = s; ind3 = i; }
-    }
-    if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { ind2 = -1; ind3 = -1; }
-    else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { ind3 = -1; }
+    const int cnt = lane < HISTO_LENGTH ? hist[lane] : 0;
+    const unsigned key = cnt > 0 ? ((unsigned)cnt << 8) | (unsigned)(63 - lane) : 0u;
+    const unsigned k1 = ~orb_wave_umin(~key);
+    const unsigned key2 = key == k1 ? 0u : key;
+    const unsigned k2 = ~orb_wave_umin(~key2);
+    const unsigned key3 = key2 == k2 ? 0u : key2;
+    const unsigned k3 = ~orb_wave_umin(~key3);
+    int ind1 = k1 ? 63 - (int)(k1 & 0xFFu) : -1, ind2 = k2 ? 63 - (int)(k2 & 0xFFu) : -1, ind3 = k3 ? 63 - (int)(k3 & 0xFFu) : -1;
+    const float max1 = (float)(k1 >> 8), max2 = (float)(k2 >> 8), max3 = (float)(k3 >> 8);
+    if (max2 < __fmul_rn(0.1f, max1)) { ind2 = -1; ind3 = -1; }
+    else if (max3 < __fmul_rn(0.1f, max1)) { ind3 = -1; }
+    if (lane == 0) { keep[0] = ind1; keep[1] = ind2; keep[2] = ind3; }
 }
 
 // ------------------------------------------------------------------ vocabulary stand-in
@@ -563,11 +569,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     if (local) atomicAdd(&nm, local);
     __syncthreads();
     if (checkOri) {
-        if (tid == 0) {
-            int i1, i2, i3;
-            three_maxima_dev(hist, i1, i2, i3);
-            keepBins[0] = i1; keepBins[1] = i2; keepBins[2] = i3;
-        }
+        if (tid < WAVE) three_maxima_wave(hist, keepBins, tid);
         __syncthreads();
         int dropped = 0;
         for (int i = tid; i < nRes; i += blockDim.x)
