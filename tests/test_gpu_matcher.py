@@ -436,6 +436,33 @@ def test_search_by_bow_randomized_sizes():
     assert checked > 500                                           # the planted duplicates do get matched
 
 
+def test_search_by_bow_rotation_histogram_ties():
+    """ComputeThreeMaxima on the device (three wave maxima) against the reference's sequential scan: planted matches whose
+    rotation differences fall into a few bins with EQUAL counts (ties go to the lower bin), with one dominant bin (the
+    0.1 rule drops the others) and with fewer than three occupied bins."""
+    rng = np.random.default_rng(99)
+    for t, (rots, per_bin) in enumerate([((0, 36, 72, 108), (20, 20, 20, 20)), ((0, 36, 72, 108, 144), (7, 7, 9, 7, 9)),
+                                         ((0, 72), (40, 3)), ((36,), (25,)), ((0, 36, 72), (30, 3, 2)), ((0, 36, 72, 108), (5, 5, 5, 4))]):
+        n = sum(per_bin)
+        da = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        db = da.copy()
+        db[:, 0] ^= 1                                              # distance 1: every planted pair matches
+        aa = rng.uniform(100, 200, n).astype(np.float32)
+        rot = np.concatenate([np.full(c, r, np.float32) for r, c in zip(rots, per_bin)])
+        ab = ((aa - rot - np.float32(3.0)) % np.float32(360.0)).astype(np.float32)     # rot = angA - angB lands mid-bin
+        fva, ta = _fv(da)
+        fvb, tb = _fv(db)
+        va = np.ones(n, np.uint8)
+        m = capi.Matcher(0.9, True)
+        wn, w = oracle.search_by_bow(da, aa, va, fva, db, ab, fvb, 0.9, True)
+        gn, g = m.search_by_bow(da, aa, va, ta, db, ab, tb)
+        assert gn == wn and np.array_equal(g, w), t
+        wn2, w2 = oracle.search_by_bow_kk(da, aa, va, fva, db, ab, va, fvb, 0.9, True)
+        gn2, g2 = m.search_by_bow_kk(da, aa, va, ta, db, ab, va, tb)
+        assert gn2 == wn2 and np.array_equal(g2, w2), t
+        assert 0 < wn <= n and (len(rots) <= 3 or wn < n)          # something is kept, and a 4th bin is dropped
+
+
 def _rand_keypoints(rng, n, w=640, h=480, level0_frac=0.5):
     k = np.zeros(n, oracle.KP_DTYPE if hasattr(oracle, "KP_DTYPE") else capi.KP_DTYPE)
     k["x"] = rng.uniform(16, w - 16, n).astype(np.float32)
