@@ -16,11 +16,14 @@
 #include "../../include/orb_sincos.h"
 
 #define WAVE 64
+typedef unsigned short orb_u16x2 __attribute__((ext_vector_type(2)));
 #define PR 21                  // patch radius
 #define PW 43                  // patch rows / useful columns
 #define PB 48                  // LDS row pitch in bytes (12 aligned dwords cover xoff + 43 <= 46 bytes)
 #define PDW (PB / 4)
-#define HP 48                  // pitch of the row-blurred patch (u16), indexed by LDS byte position
+#define HT_RP 50               // the row-blurred patch is kept TRANSPOSED: u16 per column (25 dwords: an odd dword pitch
+                               // spreads the columns over the LDS banks); rows 0..47, of which 0..42 exist
+#define HT_COLS 40             // columns = the 10 quads of LDS bytes that the pattern can reach
 
 __device__ __forceinline__ int reflect101(int i, int n)
 {
@@ -75,10 +78,9 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     // ONE LDS region: first the raw patch (2 KB, dword rows with one dword of slack on both sides), later the
     // row-blurred patch H (4 KB, u16) written over it once every lane holds its blur outputs in registers.
     // 4.1 KB per workgroup instead of 6.2 KB lets the wave-slot limit (32 per CU), not LDS, set the occupancy.
-    __shared__ uint32_t ldsBuf[(PW * HP * 2) / 4];
-    static_assert(PW * HP * 2 >= (1 + PW * PDW + 1) * 4, "H must cover the raw patch");
+    __shared__ uint32_t ldsBuf[1032];
+    static_assert(1032 >= 1 + 48 * PDW + 2 && 1032 * 4 >= HT_COLS * HT_RP * 2, "raw patch rows 0..47 (43..47: slack that is read, never used) and H");
     uint32_t* Pdw = ldsBuf + 1;
-    uint16_t* H = reinterpret_cast<uint16_t*>(ldsBuf);
     const int lane = threadIdx.x;
     int slot, f;
     if (invPerFrame) {                                 // 1-D XCD-aware grid: a frame's keypoints share one L2
@@ -162,30 +164,34 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     const float angle = fast_atan2_deg((float)m01, (float)m10);
 
     // ---- horizontal 7-tap pass.  The rotated pattern stays within 18 px of the keypoint (|x|,|y| <= 13), so only
-    // LDS bytes xoff+3 .. xoff+39 are ever sampled: 10 quads starting at q0 = (xoff+3)/4.  Static mapping lane ->
-    // (row phase rp of 6, quad): rows rp, rp+6, ... in 8 unrolled steps whose LDS addresses are base + constant
-    // (no index arithmetic; this kernel is VALU-issue bound).
+    // LDS bytes xoff+3 .. xoff+39 are ever sampled: 10 quads starting at qFirst = (xoff+3)/4.  Static mapping lane ->
+    // (row phase rp of 6, quad): row PAIRS 12 i + 2 rp, + 1 for i = 0..3 (LDS addresses are base + constant: no index
+    // arithmetic), written TRANSPOSED -- H[column][row], a dword = two vertically adjacent rows of one column -- so that
+    // the 7 vertical taps of a sample are 4 consecutive dwords.  The kernel is bound by the LDS pipe (r02 counters: 89 %
+    // busy, 2/3 of it the 56 conflict-ridden u16 reads per lane of the row-major layout); this way a sample is two
+    // ds_read2_b32 + 4 v_alignbit + 4 v_dot2_u32_u16.
+    const int qFirst = (xoff + 3) >> 2;
     {
-        const int rp = lane / 10, q = ((xoff + 3) >> 2) + (lane - rp * 10);     // 6 row phases x 10 quads = 60 lanes
-        uint2 hv[8];
+        const int rp = lane / 10, ql = lane - rp * 10;         // 6 row phases x 10 quads = 60 lanes
+        uint32_t hv[4][4];                                     // [row pair][column of the quad]
         if (rp < 6) {
-            const uint32_t* p = Pdw + rp * PDW + q - 1;
+            const uint32_t* p = Pdw + 2 * rp * PDW + qFirst + ql - 1;
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                if (i < 7 || rp < PW - 42) {                      // row 42 exists for phase 0 only
-                    unsigned o[4];
-                    hblur4(p[i * 6 * PDW], p[i * 6 * PDW + 1], p[i * 6 * PDW + 2], o);
-                    hv[i].x = o[0] | (o[1] << 16);
-                    hv[i].y = o[2] | (o[3] << 16);
-                }
+            for (int i = 0; i < 4; i++) {
+                unsigned o0[4], o1[4];
+                hblur4(p[12 * i * PDW], p[12 * i * PDW + 1], p[12 * i * PDW + 2], o0);
+                hblur4(p[(12 * i + 1) * PDW], p[(12 * i + 1) * PDW + 1], p[(12 * i + 1) * PDW + 2], o1);
+#pragma unroll
+                for (int j = 0; j < 4; j++) hv[i][j] = o0[j] | (o1[j] << 16);
             }
         }
         __syncthreads();                                       // every read of the raw patch is done: H may overwrite it
         if (rp < 6) {
-            uint16_t* hrow = &H[rp * HP + 4 * q];
+            uint32_t* col = ldsBuf + 4 * ql * (HT_RP / 2) + rp;  // dword (column 4 ql, rows 2 rp / 2 rp + 1)
 #pragma unroll
-            for (int i = 0; i < 8; i++)
-                if (i < 7 || rp < PW - 42) *reinterpret_cast<uint2*>(hrow + i * 6 * HP) = hv[i];
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) col[j * (HT_RP / 2) + 6 * i] = hv[i][j];
         }
     }
     __syncthreads();
@@ -199,15 +205,26 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     // bits of the sum ARE the integer (biased by 0x4B400000), so rounding costs one v_add_f32 per coordinate and the
     // biases fold into one wave-uniform constant of the LDS index (all arithmetic mod 2^32).
     const unsigned kBias = 0x4B400000u;
-    // row index through a 24-bit multiply-add: the low 24 bits of the biased row are 0x400000 + ir
-    const unsigned idxC = (unsigned)((PR - 3) * HP + xoff + PR) - 0x400000u * (unsigned)HP - kBias;
+    // column index through a 24-bit multiply-add: the low 24 bits of the biased column are 0x400000 + ic
+    const unsigned eC = (unsigned)((xoff + PR - 4 * qFirst) * HT_RP + (PR - 3)) - 0x400000u * (unsigned)HT_RP - kBias;
+    const unsigned K0 = 18u | (34u << 16), K1 = 49u | (55u << 16), K2 = 49u | (34u << 16), K3 = 18u;   // taps, two per dot2
     auto sample = [&](float px, float py) -> int {
         const float fr = __fadd_rn(__fmul_rn(px, b), __fmul_rn(py, a));
         const float fc = __fsub_rn(__fmul_rn(px, a), __fmul_rn(py, b));
         const unsigned br = __float_as_uint(__fadd_rn(fr, 12582912.f)), bc = __float_as_uint(__fadd_rn(fc, 12582912.f));
-        const uint16_t* h = H + (int)(__umul24(br, (unsigned)HP) + (bc + idxC));   // = H[(21 + ir - 3) * HP + xoff + 21 + ic]
-        const int acc = 18 * (h[0] + h[6 * HP]) + 34 * (h[HP] + h[5 * HP]) + 49 * (h[2 * HP] + h[4 * HP]) + 55 * h[3 * HP];
-        return min(255, (acc + 32768) >> 16);
+        // u16 index of the topmost tap: H[xoff + 21 + ic - 4 qFirst][21 + ir - 3]; its 7 rows lie in 4 consecutive dwords,
+        // starting in the low (even index) or the high half of the first
+        const unsigned e = __umul24(bc, (unsigned)HT_RP) + br + eC;
+        const uint32_t* hw = ldsBuf + (e >> 1);
+        const unsigned d0 = hw[0], d1 = hw[1], d2 = hw[2], d3 = hw[3];
+        const unsigned sh = e << 4;                            // v_alignbit uses the low 5 bits: 0 or 16
+        const unsigned p0 = __builtin_amdgcn_alignbit(d1, d0, sh), p1 = __builtin_amdgcn_alignbit(d2, d1, sh);
+        const unsigned p2 = __builtin_amdgcn_alignbit(d3, d2, sh), p3 = __builtin_amdgcn_alignbit(d3, d3, sh);   // (high half x tap 0)
+        unsigned acc = __builtin_amdgcn_udot2(__builtin_bit_cast(orb_u16x2, p3), __builtin_bit_cast(orb_u16x2, K3), 32768u, false);
+        acc = __builtin_amdgcn_udot2(__builtin_bit_cast(orb_u16x2, p2), __builtin_bit_cast(orb_u16x2, K2), acc, false);
+        acc = __builtin_amdgcn_udot2(__builtin_bit_cast(orb_u16x2, p1), __builtin_bit_cast(orb_u16x2, K1), acc, false);
+        acc = __builtin_amdgcn_udot2(__builtin_bit_cast(orb_u16x2, p0), __builtin_bit_cast(orb_u16x2, K0), acc, false);
+        return (int)min(255u, acc >> 16);
     };
     const unsigned long long w0 = __ballot(sample(q0.x, q0.y) < sample(q0.z, q0.w));
     const unsigned long long w1 = __ballot(sample(q1.x, q1.y) < sample(q1.z, q1.w));
