@@ -164,7 +164,9 @@ def roofline_blocks(stage_ms, launch_frames, bytes_frame, extract_total_ms, live
           "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "algorithmic_bytes_per_frame": int(bytes_frame),
           "frames_per_launch": launch_frames, "kernel_ms_per_launch": round(float(stage_ms[dom]), 4),
           "pipeline_achieved_GBs": round(bytes_frame * launch_frames / (extract_total_ms * 1e-3) / 1e9, 2),
-          "binding": "valu_issue (see roofline_valu): the kernel moves ~1 MB/frame from L2, HBM is not what limits it"}
+          "binding": ("valu_issue (see roofline_valu): the kernel moves ~1 MB/frame from L2, HBM is not what limits it"
+                      if STAGES[dom].startswith(("k_fast", "k_orient")) else
+                      "latency of small launches (a chain of 5 pyramid launches per batch, ~50 % VALU-busy), not HBM")}
     key = STAGES[dom].split("(")[0]
     tr = load_profile("pmc_traffic.json")
     lt = live_traffic(key, launch_frames) if live else None
@@ -693,7 +695,8 @@ def run_c5(args, rank, local_rank, world, dev, comm_dev, dist):
            "roofline": {"bound": "hbm", "kernel": "k_match_bow (+ k_vocab_transform of the query)", "achieved": round(ach, 2),
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
                         "algorithmic_bytes_per_query": int(bytes_query), "kernel_ms_per_launch": round(match_ms, 4),
-                        "binding": "latency of the per-node descriptor loads (43 % VALU-busy), not HBM"}}
+                        "binding": "vector-instruction issue in the per-node matching loop (51 % VALU-busy over the whole kernel, ~1900 "
+                                   "instructions per wave; profiles/r02_valu.json), not HBM"}}
     if world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle
