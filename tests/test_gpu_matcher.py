@@ -436,6 +436,37 @@ def test_search_by_bow_randomized_sizes():
     assert checked > 500                                           # the planted duplicates do get matched
 
 
+def test_search_by_bow_features_competing_for_the_same_partner():
+    """Many features of a node want the SAME Frame feature (the greedy "already taken" rule; in the kernel: the test that
+    tells whether the four rows of a group are coupled, and its row-by-row fallback), nodes of 1..40 features; both
+    variants.  tools/stress_parity.py runs thousands of these."""
+    rng = np.random.default_rng(4242)
+    total = 0
+    for t in range(40):
+        na, nb = (int(rng.integers(1, 80)), int(rng.integers(1, 80))) if t % 4 == 0 else (int(rng.integers(1, 1500)), int(rng.integers(1, 1500)))
+        reuse, maxflip = float(rng.choice([0.05, 0.2, 0.6])), int(rng.choice([2, 8, 30]))
+        ratio, ori = float(rng.choice([0.7, 0.9, 1.0])), bool(rng.integers(0, 2))
+        db = rng.integers(0, 256, (nb, 32), dtype=np.uint8)
+        pool = rng.integers(0, nb, max(1, int(nb * reuse)))
+        da = db[pool[rng.integers(0, len(pool), na)]].copy()
+        for r in range(na):
+            for b in rng.integers(0, 256, rng.integers(0, maxflip + 1)):
+                da[r, b >> 3] ^= np.uint8(1 << (b & 7))
+        aa, ab = rng.uniform(0, 360, na).astype(np.float32), rng.uniform(0, 360, nb).astype(np.float32)
+        va, vb = (rng.random(na) < 0.8).astype(np.uint8), (rng.random(nb) < 0.8).astype(np.uint8)
+        fva, ta = _fv(da)
+        fvb, tb = _fv(db)
+        m = capi.Matcher(ratio, ori)
+        wn, w = oracle.search_by_bow(da, aa, va, fva, db, ab, fvb, ratio, ori)
+        gn, g = m.search_by_bow(da, aa, va, ta, db, ab, tb)
+        assert gn == wn and np.array_equal(g, w), ("KF-F", t, na, nb)
+        wn2, w2 = oracle.search_by_bow_kk(da, aa, va, fva, db, ab, vb, fvb, ratio, ori)
+        gn2, g2 = m.search_by_bow_kk(da, aa, va, ta, db, ab, vb, tb)
+        assert gn2 == wn2 and np.array_equal(g2, w2), ("KF-KF", t, na, nb)
+        total += wn + wn2
+    assert total > 2000
+
+
 def test_search_by_bow_rotation_histogram_ties():
     """ComputeThreeMaxima on the device (three wave maxima) against the reference's sequential scan: planted matches whose
     rotation differences fall into a few bins with EQUAL counts (ties go to the lower bin), with one dominant bin (the
