@@ -54,6 +54,62 @@ __device__ __forceinline__ int3 qt_cuts(const unsigned long long* keys, const Qt
     return c;
 }
 
+// The initial sort by key, without a sorting network: the bitonic sort of ~1000 keys is 45 barrier-separated steps of
+// dependent LDS round trips (13 us of a 45 us workgroup).  The top of a key is (root, quadrant path), so a bucket =
+// (root, first D path digits) is a contiguous range of the sorted order:
+//   1 histogram of the buckets with LDS atomics (the returned slot is an arbitrary order inside the bucket)
+//   2 exclusive scan of the histogram by one wave
+//   3 scatter to tmp[start[bucket] + slot]
+//   4 rank every key inside its bucket (keys are unique; buckets hold ~n / 64 keys) -> keys[]
+// Five barriers.  Returns false -- keys untouched -- when the scratch is too small or a bucket holds more than
+// QT_BUCKET_MAX keys (clustered corners: the rank step is quadratic in the bucket size); the caller then sorts with the
+// network.  scratch = everything behind keys in the workgroup's LDS (node lists, unused until the sort is done).
+#define QT_BUCKET_MAX 96
+__device__ __forceinline__ bool qt_bucket_sort(unsigned long long* keys, int n, int nIni, unsigned char* scratch, int scratchBytes,
+                                               int* shFlag)
+{
+    const int T = blockDim.x, tid = threadIdx.x;
+    const int D = n >= 256 ? 3 : 2;                    // path digits in the bucket index: 64 or 16 buckets per root
+    const int nb = nIni << (2 * D);
+    if ((size_t)n * 10 + (size_t)nb * 8 + 16 > (size_t)scratchBytes || nb > 1024) return false;
+    const int shift = ORB_KEY_PATH_SHIFT + 2 * (ORB_KEY_PATH_LEVELS - D);      // key >> shift = root << 2D | first D digits
+    unsigned long long* tmp = reinterpret_cast<unsigned long long*>(scratch);
+    int* cnt = reinterpret_cast<int*>(tmp + n);
+    int* start = cnt + nb;
+    unsigned short* slot = reinterpret_cast<unsigned short*>(start + nb);
+    for (int t = tid; t < nb; t += T) cnt[t] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += T) slot[i] = (unsigned short)atomicAdd(&cnt[(int)(keys[i] >> shift)], 1);
+    __syncthreads();
+    if (tid < 64) {                                    // exclusive scan over the buckets: lane owns a contiguous chunk
+        const int C = (nb + 63) / 64;
+        const int b = min(tid * C, nb), e = min(b + C, nb);
+        int sum = 0, mx = 0;
+        for (int t = b; t < e; t++) { const int c = cnt[t]; sum += c; mx = max(mx, c); }
+        const int incl = orb_wave_scan_incl(sum);
+        int run = incl - sum;
+        for (int t = b; t < e; t++) { start[t] = run; run += cnt[t]; }
+        mx = (int)~orb_wave_umin(~(unsigned)mx);
+        if (tid == 0) *shFlag = mx;
+    }
+    __syncthreads();
+    if (*shFlag > QT_BUCKET_MAX) return false;         // (uniform; nothing has been moved yet)
+    for (int i = tid; i < n; i += T) {
+        const unsigned long long k = keys[i];
+        tmp[start[(int)(k >> shift)] + slot[i]] = k;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += T) {
+        const unsigned long long k = tmp[i];
+        const int b = (int)(k >> shift), s0 = start[b], c = cnt[b];
+        int rank = 0;
+        for (int j = 0; j < c; j++) rank += tmp[s0 + j] < k;
+        keys[s0 + rank] = k;
+    }
+    __syncthreads();
+    return true;
+}
+
 // in-place exclusive scan of a[0..n) by the whole block; returns the total.  part = int[blockDim.x+1].
 __device__ int qt_scan(int* a, int n, int* part)
 {
@@ -86,7 +142,7 @@ __device__ int qt_scan(int* a, int n, int* part)
 __device__ __forceinline__ void qt_body(unsigned long long* keys, int n, const OrbGeom& G, const OrbLevelGeom& L, int f,
                                         unsigned long long* prevA, unsigned long long* prevB, QtNode* A, QtNode* B,
                                         int3* cuts, int* va, int* vb, int* part, uint32_t* __restrict__ kpl,
-                                        int* outCount, int* __restrict__ errFlags, int* sh)
+                                        int* outCount, int* __restrict__ errFlags, int* sh, unsigned char* scratch, int scratchBytes)
 {
     // shared words: sh[0] number of roots, sh[1] / sh[2] the two "expandable children" counters (passes alternate between
     // them: the one a pass does not count into is cleared for the next pass), sh[3] t* of the careful phase.
@@ -96,7 +152,7 @@ __device__ __forceinline__ void qt_body(unsigned long long* keys, int n, const O
     int& sh_tstar = sh[3];
     const int tid = threadIdx.x, T = blockDim.x;
     __syncthreads();
-    orb_block_sort(keys, n);
+    if (!(scratch && qt_bucket_sort(keys, n, L.nIni, scratch, scratchBytes, &sh[3]))) orb_block_sort(keys, n);
 
     const int N = L.quota;
     // ---- roots (reference :575-612): empty roots vanish, single-key roots are bNoMore
@@ -315,9 +371,11 @@ __global__ __launch_bounds__(256) void k_quadtree(const OrbGeom G, unsigned long
     unsigned long long* gk = cand + (size_t)f * candSlab + L.candBase;
     if (n <= sortCap) {
         for (int i = tid; i < n; i += T) ldsKeys[i] = gk[i];
-        qt_body(ldsKeys, n, G, L, f, prevA, prevB, A, B, cuts, va, vb, part, kpl, outCount, errFlags, sh);
+        // scratch of the bucket sort: the node lists behind the keys (prevA .. part), unused until the sort is done
+        qt_body(ldsKeys, n, G, L, f, prevA, prevB, A, B, cuts, va, vb, part, kpl, outCount, errFlags, sh,
+                reinterpret_cast<unsigned char*>(prevA), nodeCap * (16 + 2 * (int)sizeof(QtNode) + (int)sizeof(int3) + 8) + 257 * 4);
     } else {
-        qt_body(gk, n, G, L, f, prevA, prevB, A, B, cuts, va, vb, part, kpl, outCount, errFlags, sh);   // rare: sort in global memory
+        qt_body(gk, n, G, L, f, prevA, prevB, A, B, cuts, va, vb, part, kpl, outCount, errFlags, sh, nullptr, 0);   // rare: sort in global memory
     }
 }
 

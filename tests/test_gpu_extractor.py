@@ -368,7 +368,7 @@ def test_large_feature_counts_kitti_size(nf):
     assert n > min(nf, 4000) * 0.8
 
 
-@pytest.mark.parametrize("kind", ["checker1", "checker2", "checker3", "stripes", "blocks", "saltpepper", "gradient_noise", "dots"])
+@pytest.mark.parametrize("kind", ["checker1", "checker2", "checker3", "stripes", "blocks", "saltpepper", "gradient_noise", "dots", "cluster"])
 def test_adversarial_patterns_for_the_strip_detector(kind):
     """Images built to stress what k_fast_strips does differently from a per-cell loop: every pixel a candidate (pair
     rings and the candidate queue overflow -> dense kernel), plateaus of equal scores across cell seams (cell-local NMS,
@@ -389,6 +389,12 @@ def test_adversarial_patterns_for_the_strip_detector(kind):
         m = rng.random((H, W))
         img[m < 0.03] = 255
         img[m > 0.97] = 0
+    elif kind == "cluster":
+        # all corners in one 90 x 70 region: a few hundred candidates, nearly all in ONE bucket of the quadtree's bucket
+        # sort (-> its fallback to the sorting network), the rest of the frame empty cells (iniTh -> minTh fallback)
+        img = np.full((H, W), 128, np.uint8)
+        img[40:110, 60:150] = np.kron(rng.integers(0, 256, (12, 15)), np.ones((6, 6)))[:70, :90].astype(np.uint8)
+        img[200:203, 300:303] = 255
     elif kind == "gradient_noise":
         img = np.clip(xx * 255 // W + rng.integers(-12, 13, (H, W)), 0, 255).astype(np.uint8)
     else:                                                        # bright dots on a 31-px lattice: one per cell, next to the seams
