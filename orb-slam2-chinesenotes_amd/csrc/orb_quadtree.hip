@@ -236,7 +236,31 @@ __device__ __forceinline__ void qt_body(unsigned long long* keys, int n, const O
             size0 = size;
         } else {
             // ---------------- careful phase (:703-765): largest first, stop as soon as size >= N
-            orb_block_sort(prev, pc);                    // ascending (size, seq); processed from the back (:711-713)
+            // ascending (size, seq); processed from the back (:711-713).  Up to a workgroup's worth of candidates (the rule:
+            // the phase starts when 3 x candidates could overshoot N, ~170 on level 0) are rank-sorted -- every thread
+            // counts the entries below its own, 8 independent broadcast reads in flight -- : two barriers instead of the
+            // 36 steps of the network (6.6 -> ~1 us)
+            if (pc <= T) {
+                unsigned long long mine = 0;
+                int rank = 0;
+                if (tid < pc) {
+                    mine = prev[tid];
+                    int j = 0;
+                    for (; j + 8 <= pc; j += 8) {
+                        unsigned long long v[8];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) v[u] = prev[j + u];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) rank += v[u] < mine;
+                    }
+                    for (; j < pc; j++) rank += prev[j] < mine;
+                }
+                __syncthreads();
+                if (tid < pc) prev[rank] = mine;
+                __syncthreads();
+            } else {
+                orb_block_sort(prev, pc);
+            }
             for (int t = tid; t < pc; t += T) {
                 const int idx = (int)(prev[pc - 1 - t] & 0xFFFFFF);
                 const QtNode nd = cur[idx];
