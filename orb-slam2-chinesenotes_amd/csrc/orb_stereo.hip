@@ -10,12 +10,12 @@
 //                      Hamming coarse match (first minimum wins), 11x11 SAD at 11 offsets from LDS
 //                      patches (exact integers: the float patches of the reference hold integers),
 //                      parabola fit and depth in float with the reference's operation order.
-//   k_stereo_outliers  one workgroup: sort (SAD, index), median, cut >= 1.5*1.4*median (:685-698).
+//   k_stereo_outliers  one workgroup per pair: median SAD by histogram selection, cut >= 1.5*1.4*median (:685-698).
 #include <algorithm>
 #include <vector>
 
-#include "orb_block_sort.h"
 #include "orb_extractor_internal.h"
+#include "orb_wave.h"
 
 #pragma clang fp contract(off)
 
@@ -216,71 +216,63 @@ __global__ __launch_bounds__(WAVE) void k_stereo_match(const OrbGeom G, const ui
     }
 }
 
-// one workgroup per pair: sort the left keypoints' (SAD, index) slots (unmatched ones are ~0 and end up behind), median
-// of the matched ones, cut >= 1.5 * 1.4 * median (:685-698).  Sorted in LDS (orb_block_sort) when the slots fit ldsCap
-// entries, in global memory otherwise.
-__global__ __launch_bounds__(1024) void k_stereo_outliers(unsigned long long* __restrict__ pairs0, size_t stride, int nL,
+// one workgroup per pair: median of the matched keypoints' SAD and the cut >= 1.5 * 1.4 * median (:685-698).  The
+// reference sorts (SAD, index) pairs only to read the element in the middle: its SAD is the (n/2)-th order statistic, which
+// two 256-bin histograms find (high byte, then low byte inside the bin the middle falls into; a SAD is at most
+// 121 * 510 < 2^16) -- six barriers instead of the 66 steps of a sorting network over ~2000 slots, and no LDS or
+// global-memory sort whatever the number of keypoints.  Unmatched slots are ~0.
+__global__ __launch_bounds__(1024) void k_stereo_outliers(const unsigned long long* __restrict__ pairs0, size_t stride, int nL,
                                                           const int32_t* __restrict__ countsL,
-                                                          float* __restrict__ uRight0, float* __restrict__ depth0, int ldsCap)
+                                                          float* __restrict__ uRight0, float* __restrict__ depth0)
 {
-    extern __shared__ unsigned long long spairs[];
-    __shared__ int nValid;
-    const int pr = blockIdx.x;
-    unsigned long long* gp = pairs0 + stride * pr;
+    __shared__ int hist[256];
+    __shared__ int sel[3];                                         // matched count, chosen bin, rank inside it
+    const int pr = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
+    const unsigned long long* gp = pairs0 + stride * pr;
     float* uRight = uRight0 + stride * pr;
     float* depth = depth0 + stride * pr;
     const int nAll = countsL ? min(countsL[pr], (int)stride) : nL;
     if (nAll <= 0) return;
-    unsigned long long* pairs = gp;
-    if (nAll <= ldsCap) {
-        for (int i = threadIdx.x; i < nAll; i += blockDim.x) spairs[i] = gp[i];
+    int median = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        if (tid < 256) hist[tid] = 0;
         __syncthreads();
-        orb_block_sort(spairs, nAll);
-        pairs = spairs;
-    } else {
-        int np2 = 1;
-        while (np2 < nAll) np2 <<= 1;
+        const int wantHi = pass ? sel[1] : 0;
+        for (int i = tid; i < nAll; i += T) {
+            const unsigned long long e = gp[i];
+            if (e == ~0ull) continue;
+            const unsigned sad = min((unsigned)(e >> 32), 0xFFFFu);
+            if (pass == 0) atomicAdd(&hist[sad >> 8], 1);
+            else if ((int)(sad >> 8) == wantHi) atomicAdd(&hist[sad & 0xFFu], 1);
+        }
         __syncthreads();
-        for (int k = 2; k <= np2; k <<= 1) {
-            for (int i = threadIdx.x; i < np2; i += blockDim.x) {
-                const int p = i ^ (k - 1);
-                if (p > i && p < nAll) {
-                    const unsigned long long x = gp[i], y = gp[p];
-                    if (x > y) { gp[i] = y; gp[p] = x; }
-                }
+        if (tid < 64) {                                            // one wave: the bin in which the wanted rank falls
+            const int c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2 = hist[4 * tid + 2], c3 = hist[4 * tid + 3];
+            const int mine = c0 + c1 + c2 + c3;
+            const int incl = orb_wave_scan_incl(mine);
+            const int total = __builtin_amdgcn_readlane(incl, 63);
+            const int want = pass ? sel[2] : total / 2;            // rank (0-based) of the element in the middle (:687)
+            const int before = incl - mine;
+            if (total > 0 && want >= before && want < incl) {      // exactly one lane
+                int r = want - before, bin = 4 * tid;
+                if (r >= c0) { r -= c0; bin++; if (r >= c1) { r -= c1; bin++; if (r >= c2) { r -= c2; bin++; } } }
+                sel[1] = bin;
+                sel[2] = r;
             }
-            __syncthreads();
-            for (int j = k >> 2; j > 0; j >>= 1) {
-                for (int i = threadIdx.x; i < np2; i += blockDim.x) {
-                    const int p = i ^ j;
-                    if (p > i && p < nAll) {
-                        const unsigned long long x = gp[i], y = gp[p];
-                        if (x > y) { gp[i] = y; gp[p] = x; }
-                    }
-                }
-                __syncthreads();
-            }
+            if (tid == 0 && pass == 0) sel[0] = total;
         }
+        __syncthreads();
+        if (sel[0] == 0) return;                                   // reference: UB on the empty vector (:686)
+        median = pass ? (median << 8) | sel[1] : sel[1];
+        __syncthreads();
     }
-    if (threadIdx.x == 0) {                                        // number of matched keypoints: first ~0 in the sorted slots
-        int a = 0, b = nAll;
-        while (a < b) {
-            const int mid = (a + b) >> 1;
-            if (pairs[mid] != ~0ull) a = mid + 1; else b = mid;
-        }
-        nValid = a;
-    }
-    __syncthreads();
-    const int n = nValid;
-    if (n == 0) return;                                            // reference: UB on the empty vector (:686)
-    const float median = (float)(int)(pairs[n / 2] >> 32);
-    const float thDist = __fmul_rn(1.5f * 1.4f, median);
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const unsigned long long e = pairs[i];
-        if (!((float)(int)(e >> 32) < thDist)) {                   // sorted ascending: same set as the backwards scan
-            const int iL = (int)(e & 0xFFFFFFFFu);
-            uRight[iL] = -1.0f;
-            depth[iL] = -1.0f;
+    const float thDist = __fmul_rn(1.5f * 1.4f, (float)median);
+    for (int i = tid; i < nAll; i += T) {
+        const unsigned long long e = gp[i];
+        if (e == ~0ull) continue;
+        if (!((float)(int)(e >> 32) < thDist)) {
+            uRight[i] = -1.0f;                                     // slot i = left keypoint i
+            depth[i] = -1.0f;
         }
     }
 }
@@ -327,8 +319,7 @@ static int stereo_launch(orb_extractor* left, orb_extractor* right, int frameL, 
                        (const uint8_t*)left->dPyr.p + left->pyrSlab * frameL, left->pyrSlab,
                        (const uint8_t*)right->dPyr.p + right->pyrSlab * frameR, right->pyrSlab, kL, dL, nL, cL, kR, dR, nR, cR,
                        stride, maxD, mbf, uR, dep, pairs, rec, recStride, lv, unsorted);
-    const int ldsCap = (int)std::min<size_t>(stride, 4096);         // <= 32 KB of (SAD, index) pairs
-    hipLaunchKernelGGL(k_stereo_outliers, dim3(nPairs), dim3(1024), (size_t)8 * ldsCap, st, pairs, perPair, nL, cL, uR, dep, ldsCap);
+    hipLaunchKernelGGL(k_stereo_outliers, dim3(nPairs), dim3(1024), 0, st, pairs, perPair, nL, cL, uR, dep);
     ORB_HIP_TRY(hipGetLastError());
     return ORB_OK;
 }
