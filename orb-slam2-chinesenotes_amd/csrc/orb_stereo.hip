@@ -88,13 +88,21 @@ __global__ __launch_bounds__(WAVE) void k_stereo_match(const OrbGeom G, const ui
     const uint8_t* pyrL = pyrL0 + slabL * pr;
     const uint8_t* pyrR = pyrR0 + slabR * pr;
     const orb_keypoint* kL = kL0 + stride * pr;
-    const orb_keypoint* kR = kR0 + stride * pr;
     const uint8_t* dL = dL0 + stride * pr * 32;
     const uint8_t* dR = dR0 + stride * pr * 32;
     float* uRight = uRight0 + stride * pr;
     float* depth = depth0 + stride * pr;
     unsigned long long* pairs = pairs0 + stride * pr;
     if (iL >= N) return;
+    // the pair's level table and order flag are requested here, before the left keypoint is known (one round trip less in
+    // the chain keypoint -> level range -> records -> descriptors -> patches)
+    int lvAll[ORB_MAX_LEVELS + 1];
+    {
+        const int* lv = lv0 + (size_t)pr * (ORB_MAX_LEVELS + 1);
+#pragma unroll
+        for (int o = 0; o <= ORB_MAX_LEVELS; o++) lvAll[o] = lv[o];
+    }
+    const int unsortedR = unsorted0[pr];
     // (every left keypoint owns slot iL of `pairs`: ~0 = no match.  One atomic slot counter per pair used to serialise all
     // the waves of a batch on ONE cache line of the L2: 64 k returning atomics took longer than the search itself)
     if (lane == 0) { uRight[iL] = -1.0f; depth[iL] = -1.0f; pairs[iL] = ~0ull; }
@@ -120,12 +128,16 @@ __global__ __launch_bounds__(WAVE) void k_stereo_match(const OrbGeom G, const ui
     // are requested at once, then the descriptors of their candidates, then the distances.
     const uint4* recs = rec0 + recStride * pr;
     int scanLo = 0, scanHi = Nr;
-    if (!unsorted0[pr]) {
-        const int* lv = lv0 + (size_t)pr * (ORB_MAX_LEVELS + 1);
-        scanLo = lv[min(max(levelL - 1, 0), G.nlevels)];
-        scanHi = lv[min(max(levelL + 2, 0), G.nlevels)];
+    if (!unsortedR) {
+        const int iLo = min(max(levelL - 1, 0), G.nlevels), iHi = min(max(levelL + 2, 0), G.nlevels);
+#pragma unroll
+        for (int o = 0; o <= ORB_MAX_LEVELS; o++) {               // (a select chain: the table sits in registers)
+            if (o == iLo) scanLo = lvAll[o];
+            if (o == iHi) scanHi = lvAll[o];
+        }
     }
     unsigned best = 0xFFFFFFFFu;
+    float bestX = 0.0f;                                            // x of this lane's best candidate (its record is at hand)
     for (int base = scanLo & ~(WAVE - 1); base < scanHi; base += 4 * WAVE) {
         uint4 rc[4];
 #pragma unroll
@@ -150,9 +162,11 @@ __global__ __launch_bounds__(WAVE) void k_stereo_match(const OrbGeom G, const ui
             if (cand[k]) {
                 const int dist = __popc(dl[0] ^ lo[k].x) + __popc(dl[1] ^ lo[k].y) + __popc(dl[2] ^ lo[k].z) + __popc(dl[3] ^ lo[k].w) +
                                  __popc(dl[4] ^ hi[k].x) + __popc(dl[5] ^ hi[k].y) + __popc(dl[6] ^ hi[k].z) + __popc(dl[7] ^ hi[k].w);
-                best = min(best, ((unsigned)dist << 16) | (unsigned)(base + k * WAVE + lane));
+                const unsigned key = ((unsigned)dist << 16) | (unsigned)(base + k * WAVE + lane);
+                if (key < best) { best = key; bestX = __uint_as_float(rc[k].w); }
             }
     }
+    const unsigned mineBest = best;
     best = st_umin_dpp(best);
     const int bestDist = (best == 0xFFFFFFFFu) ? 100 : min(100, (int)(best >> 16));   // init TH_HIGH, strict <
     if (!(bestDist < 75) || best == 0xFFFFFFFFu) return;                              // thOrbDist (:518, :599)
@@ -160,7 +174,10 @@ __global__ __launch_bounds__(WAVE) void k_stereo_match(const OrbGeom G, const ui
 
     // ---- SAD refinement on the pyramid level of the LEFT keypoint (:601-648)
     const OrbLevelGeom& Lv = G.L[levelL];
-    const float uR0 = kR[bestIdxR].x;
+    // mvKeysRight[bestIdxR].pt.x (:608) from the lane that holds the winner (keys are unique): no load
+    const unsigned long long owner = __ballot(mineBest == best);
+    const float uR0 = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(bestX), (int)__builtin_ctzll(owner)));
+    (void)bestIdxR;
     const float sf = Lv.invScale;
     const float scaleduL = roundf(__fmul_rn(kpL.x, sf)), scaledvL = roundf(__fmul_rn(kpL.y, sf));
     const float scaleduR0 = roundf(__fmul_rn(uR0, sf));
@@ -187,19 +204,21 @@ __global__ __launch_bounds__(WAVE) void k_stereo_match(const OrbGeom G, const ui
         part[inc][dy] = s;
     }
     __syncthreads();
-    if (lane != 0) return;
-    int sad[11];
-    for (int inc = 0; inc < 11; inc++) {
-        int s = 0;
-        for (int dy = 0; dy < 11; dy++) s += part[inc][dy];
-        sad[inc] = s;
+    // the 11 SADs by 11 lanes, their first minimum (:641-645: strict <, so the lower offset wins ties) as one wave minimum
+    // of (SAD << 4 | offset), its neighbours by v_readlane -- one lane summing 121 values serially was a third of the
+    // kernel's instructions (the kernel is issue-bound: 64 k waves per 32 KITTI pairs)
+    int mySad = 0;
+    if (lane < 11) {
+#pragma unroll
+        for (int dy = 0; dy < 11; dy++) mySad += part[lane][dy];
     }
-    int bestSad = 0x7FFFFFFF, bestinc = 5;                        // bestincR = 0
-    for (int inc = 0; inc < 11; inc++)
-        if (sad[inc] < bestSad) { bestSad = sad[inc]; bestinc = inc; }   // strict <, first minimum (:641-645)
+    const unsigned kb = st_umin_dpp(lane < 11 ? ((unsigned)mySad << 4) | (unsigned)lane : 0xFFFFFFFFu);
+    const int bestinc = (int)(kb & 15u), bestSad = (int)(kb >> 4);
     const int bestincR = bestinc - 5;
     if (bestincR == -Lr || bestincR == Lr) return;                 // :651
-    const float dist1 = (float)sad[bestinc - 1], dist2 = (float)sad[bestinc], dist3 = (float)sad[bestinc + 1];
+    const float dist1 = (float)__builtin_amdgcn_readlane(mySad, bestinc - 1), dist2 = (float)bestSad,
+                dist3 = (float)__builtin_amdgcn_readlane(mySad, bestinc + 1);
+    if (lane != 0) return;
     const float deltaR = __fdiv_rn(__fsub_rn(dist1, dist3),
                                    __fmul_rn(2.0f, __fsub_rn(__fadd_rn(dist1, dist3), __fmul_rn(2.0f, dist2))));
     if (deltaR < -1 || deltaR > 1) return;
