@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One-off parity stress on the GPU box (not part of the suites): many seeded random SearchByBoW cases built to make the
 features of a vocabulary node COMPETE for the same partner (the greedy "already taken" rule, the row-coupling test of the
-4-row kernel path, nodes of 1..40 features), both variants, against the oracle.   usage: stress_parity.py [trials]"""
+4-row kernel path, nodes of 1..40 features), both variants, against the oracle.   usage: stress_parity.py [trials] | --extract [trials]"""
 import os
 import sys
 
@@ -33,7 +33,59 @@ def competing_sets(rng, na, nb, reuse, maxflip):
     return da, db
 
 
+def random_image(rng, w, h):
+    kind = int(rng.integers(0, 6))
+    if kind == 0:                                                  # the benchmark's scenes
+        return synth.synth_frame(int(rng.integers(0, 100000)), w, h)
+    yy, xx = np.mgrid[0:h, 0:w]
+    if kind == 1:                                                  # blocks of random grey: corners everywhere
+        p = int(rng.integers(3, 12))
+        return np.kron(rng.integers(0, 256, (h // p + 1, w // p + 1)), np.ones((p, p)))[:h, :w].astype(np.uint8)
+    if kind == 2:                                                  # corners clustered in one or two spots, the rest flat
+        img = np.full((h, w), int(rng.integers(60, 200)), np.uint8)
+        for _ in range(int(rng.integers(1, 3))):
+            bw, bh = int(rng.integers(20, max(21, w // 3))), int(rng.integers(20, max(21, h // 3)))
+            x0, y0 = int(rng.integers(0, w - bw)), int(rng.integers(0, h - bh))
+            img[y0:y0 + bh, x0:x0 + bw] = np.kron(rng.integers(0, 256, (bh // 5 + 1, bw // 5 + 1)), np.ones((5, 5)))[:bh, :bw]
+        return img
+    if kind == 3:                                                  # noise: every pixel a candidate at the low threshold
+        return rng.integers(0, 256, (h, w)).astype(np.uint8)
+    if kind == 4:                                                  # gradient + mild noise: few, weak corners (minTh fallback)
+        return np.clip(xx * 255 // w + rng.integers(-9, 10, (h, w)), 0, 255).astype(np.uint8)
+    return (((yy // int(rng.integers(1, 9)) + xx // int(rng.integers(1, 9))) & 1) * int(rng.integers(40, 220)) + 20).astype(np.uint8)
+
+
+def extract_stress(trials):
+    """Random image sizes, feature counts, pyramid shapes and contents through orb_extract against the oracle, byte for
+    byte (exercises the quadtree's bucket / rank sorts and their fallbacks, strip overflow, tiny upper levels)."""
+    rng = np.random.default_rng(777)
+    total = 0
+    for t in range(trials):
+        w, h = int(rng.integers(96, 900)), int(rng.integers(96, 700))
+        nf = int(rng.choice([50, 200, 500, 1000, 2000, 3500]))
+        levels, sf = int(rng.choice([3, 5, 8, 8, 8])), float(rng.choice([1.2, 1.2, 1.1, 1.5]))
+        ini, mn = int(rng.choice([20, 20, 12, 40])), int(rng.choice([7, 7, 5]))
+        img = np.ascontiguousarray(random_image(rng, w, h))
+        try:
+            ex = capi.Extractor(nf, sf, levels, ini, mn)
+            kps, desc = ex.extract(img)
+        except capi.OrbError as e:
+            if e.code == -5:                                       # ORB_ERR_UNSUPPORTED: outside the geometry envelope
+                continue
+            raise
+        ref = oracle.Extractor(nf, sf, levels, ini, mn)
+        rk, rd = ref.extract(img)
+        assert kps.tobytes() == rk.tobytes() and np.array_equal(desc, rd), ("extract", t, w, h, nf, levels, sf, ini, mn)
+        total += len(kps)
+        ex.close()
+        if t % 25 == 24:
+            print("extract trial %d ok, %d keypoints so far" % (t + 1, total), flush=True)
+    print("stress_parity --extract: %d trials identical to the oracle, %d keypoints" % (trials, total))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--extract":
+        return extract_stress(int(sys.argv[2]) if len(sys.argv) > 2 else 150)
     trials = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     rng = np.random.default_rng(20261004)
     matches = 0
