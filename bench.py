@@ -82,9 +82,11 @@ def parse():
     ap.add_argument("--input-sets", type=int, default=2,
                     help="distinct input batches that consecutive steps alternate between: one 157 MB batch re-read every "
                          "step would sit in the 256 MB Infinity Cache and flatter the pyramid's first kernel")
-    ap.add_argument("--pipeline", type=int, default=2,
+    ap.add_argument("--pipeline", type=int, default=0,
                     help="number of independent (extractor, matcher, output buffers) lanes that consecutive steps alternate "
-                         "between; lanes run on their own streams, so step k+1 overlaps step k")
+                         "between; lanes run on their own streams, so step k+1 overlaps step k.  Default (0): 4 lanes for "
+                         "batches of >= 256 frames per launch (measured 2 / 3 / 4 / 6 / 8 lanes: 319 / 320 / 327 / 329 / 328 k "
+                         "frames/s), 2 below (64-frame batches: 276 / 273 / 265 k with 2 / 4 / 8 -- the host's launch rate)")
     ap.add_argument("--frames-per-gpu", type=int, default=512, help="batch size B (weak: per GPU; strong: in total)")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
@@ -214,6 +216,8 @@ def run_c4(args, rank, local_rank, world, dev, comm_dev, dist):
         first, B = shard.weak_range(args.frames_per_gpu, rank)
     if B <= 0:
         raise SystemExit("rank %d has no frames" % rank)
+    if args.pipeline <= 0:
+        args.pipeline = 4 if B >= 256 else 2
     ex = capi.Extractor(args.nfeatures, 1.2, 8, 20, 7, device=local_rank)
     mt = capi.Matcher(0.7, True, device=local_rank)           # Tracking.cc:815 parameters
     cap = ex.max_keypoints
