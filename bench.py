@@ -295,8 +295,10 @@ def run_c4(args, rank, local_rank, world, dev, comm_dev, dist):
             ln["mt"].sync()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
         step()
+        if i < 2 * len(lanes):                     # a caller that synchronises lets every lane's FAST strip lengths settle
+            full_sync()                            # (orb_check_status shortens a level's strips per overflowing sync)
     full_sync()
     if dist is not None:
         dist.barrier()
@@ -506,9 +508,11 @@ def run_c3(args, rank, local_rank, world, dev, comm_dev, dist):
         capi.stereo_match_batch_device(exl, exr, 0, 0, S, kl.data_ptr(), dl.data_ptr(), cl.data_ptr(), kr.data_ptr(), dr.data_ptr(),
                                        cr.data_ptr(), cap, MB, MBF, ur.data_ptr(), dp.data_ptr())
 
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
         step()
-    exl.sync(); torch.cuda.synchronize()
+        if i < 4:                                  # a caller that synchronises lets the strip lengths settle (orb_check_status
+            exl.sync(); exr.sync()                 # shortens a level's FAST strips by one cell per overflowing sync)
+    exl.sync(); exr.sync(); torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
@@ -650,6 +654,9 @@ def run_c5(args, rank, local_rank, world, dev, comm_dev, dist):
             extract(i + 1)
             match(i)
 
+    for _ in range(3):                             # (synchronised calls first: the FAST strip lengths settle)
+        run(1)
+        ex.sync(); mt.sync()
     run(max(args.warmup, 2))
     ex.sync(); mt.sync(); torch.cuda.synchronize()
     if dist is not None:
