@@ -352,7 +352,10 @@ int orb_stereo_match_device(orb_extractor* left, orb_extractor* right, int frame
                             float mb, float mbf, float* d_u_right, float* d_depth);
 
 /* Diagnostics of the last synchronised batch: per level, how many FAST strips overflowed their candidate queue and were
- * redone by the dense kernel (same results, more time), and how many strips a frame has on that level. */
+ * redone by the dense kernel (same results, more time), and how many strips a frame has on that level.  The library
+ * shortens the strips of a level that overflows: at every orb_extractor_sync / host call, and -- for device pipelines
+ * that never synchronise the handle -- from counters that every fourth orb_extract_batch_device leaves in pinned memory
+ * behind an event and a later call picks up once they have arrived (no blocking). */
 int orb_get_fast_overflows(orb_extractor* h, int32_t* overflowed, int32_t* strips_per_frame);
 
 /* The whole pyramid of device-resident frame `frame` of the last batch with ONE device-to-host copy and one

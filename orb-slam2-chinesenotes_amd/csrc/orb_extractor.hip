@@ -168,6 +168,8 @@ extern "C" int orb_extractor_create(const orb_extractor_params* p, int device_id
     for (int k = 0; k < orb_extractor::kProfSlots; k++)
         for (int i = 0; i < 5; i++) (void)hipEventCreate(&h->ev[k][i]);
     (void)hipEventCreateWithFlags(&h->waitEv, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&h->ovfEv, hipEventDisableTiming);
+    if (hipHostMalloc((void**)&h->ovfHost, orb_extractor::kOvfInts * 4, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); h->ovfHost = nullptr; }
     int rc = h->dPattern.ensure(1024);
     if (rc == ORB_OK) {
         if (hipMemcpy(h->dPattern.p, ORB_BRIEF_PATTERN_XY, 1024, hipMemcpyHostToDevice) != hipSuccess) rc = ORB_ERR_HIP;
@@ -207,6 +209,8 @@ extern "C" void orb_extractor_destroy(orb_extractor* h)
         for (int i = 0; i < 5; i++)
             if (h->ev[k][i]) (void)hipEventDestroy(h->ev[k][i]);
     if (h->waitEv) (void)hipEventDestroy(h->waitEv);
+    if (h->ovfEv) (void)hipEventDestroy(h->ovfEv);
+    if (h->ovfHost) (void)hipHostFree(h->ovfHost);
     orb_pipe_release(h);
     if (h->graph1.exec) (void)hipGraphExecDestroy(h->graph1.exec);
     if (h->graph1.graph) (void)hipGraphDestroy(h->graph1.graph);
@@ -302,6 +306,24 @@ extern "C" int orb_extractor_wait_for(orb_extractor* h, void* other_stream)
 
 extern "C" void* orb_extractor_stream(orb_extractor* h) { return h ? (void*)h->stream : nullptr; }
 
+// levels whose strips overflowed their candidate queue get shorter strips (results never depend on the strip length).
+// `serial` = the batch the counters belong to: counters of batches launched before an adjustment took effect are ignored.
+static void apply_fast_overflows(orb_extractor* h, const int* perLevel, unsigned serial)
+{
+    if (h->fastStripFixed || (int)(serial - h->ovfAppliedSerial) <= 0) return;
+    h->ovfAppliedSerial = serial;
+    bool changed = false;
+    for (int l = 0; l < h->prm.nlevels; l++)
+        if (h->fastStripK[l] > 1 && perLevel[l] > 0) {   // one redone strip already costs the batch ~35 us of serial latency
+            h->fastStripK[l]--;
+            changed = true;
+        }
+    if (changed) {
+        h->geomDirty = true;                           // the next call rebuilds the geometry
+        h->ovfAppliedSerial = h->batchSerial;          // batches already launched still ran with the longer strips
+    }
+}
+
 extern "C" int orb_extract_batch_device(orb_extractor* h, const uint8_t* d_imgs, int nFrames, int rows, int cols,
                                         size_t rowStride, size_t frameStride, orb_keypoint* d_kps,
                                         uint8_t* d_desc, int cap, int32_t* d_counts)
@@ -317,6 +339,14 @@ extern "C" int orb_extract_batch_device(orb_extractor* h, const uint8_t* d_imgs,
     }
     if (!d_kps || !d_desc || rowStride < (size_t)cols) return ORB_ERR_INVALID;
     int rc;
+    if (h->ovfPendingSerial && !h->hostCall) {           // overflow counters of an earlier batch, if they have arrived
+        if (hipEventQuery(h->ovfEv) == hipSuccess) {
+            apply_fast_overflows(h, h->ovfHost + 8, h->ovfPendingSerial);
+            h->ovfPendingSerial = 0;
+        } else {
+            (void)hipGetLastError();                     // hipErrorNotReady
+        }
+    }
     if (rows != h->rows || cols != h->cols || h->geomDirty)
         if ((rc = build_geometry(h, rows, cols)) != ORB_OK) return rc;
     if ((rc = ensure_scratch(h, nFrames)) != ORB_OK) return rc;
@@ -371,6 +401,13 @@ extern "C" int orb_extract_batch_device(orb_extractor* h, const uint8_t* d_imgs,
         h->profCount++;
         h->profFrames = n;
     }
+    h->batchSerial++;
+    // (every fourth batch is enough: overflowing content keeps overflowing, and the copy is a bubble at the end of the chain)
+    if (!h->hostCall && !h->fastStripFixed && h->ovfHost && h->ovfPendingSerial == 0 && (h->batchSerial & 3u) == 1u) {
+        ORB_HIP_TRY(hipMemcpyAsync(h->ovfHost, h->ovfCountP(), orb_extractor::kOvfInts * 4, hipMemcpyDeviceToHost, st));
+        ORB_HIP_TRY(hipEventRecord(h->ovfEv, st));
+        h->ovfPendingSerial = h->batchSerial;
+    }
     ORB_HIP_TRY(hipGetLastError());
     return ORB_OK;
 }
@@ -391,16 +428,8 @@ int orb_check_status(orb_extractor* h)
         while (want > 256 && orb_quadtree_lds_bytes(want, h->nodeCap) > budget) want >>= 1;
         if (want > h->sortCap) h->sortCap = want;
     }
-    if (!h->fastStripFixed) {                          // levels whose strips keep overflowing get shorter strips
-        const int* ovf = err + (size_t)(1 + 2 * ORB_MAX_LEVELS) * n + 8;
-        bool changed = false;
-        for (int l = 0; l < h->prm.nlevels; l++)
-            if (h->fastStripK[l] > 1 && ovf[l] > 0) {   // one redone strip already costs the batch ~35 us of serial latency
-                h->fastStripK[l]--;
-                changed = true;
-            }
-        if (changed) h->geomDirty = true;              // the next call rebuilds the geometry (results do not depend on it)
-    }
+    // (host calls see every chunk's own status block: always applied; a device-path sync sees the latest batch's)
+    apply_fast_overflows(h, err + (size_t)(1 + 2 * ORB_MAX_LEVELS) * n + 8, h->hostCall ? h->ovfAppliedSerial + 1 : h->batchSerial);
     for (int f = 0; f < n; f++)
         if (err[f]) {
             orb_set_error("device-side overflow flag 0x%x on frame %d (1 candidates, 2 nodes, 4 output cap)", err[f], f);
@@ -454,6 +483,7 @@ extern "C" int orb_extract_batch(orb_extractor* h, const uint8_t* imgs, int nFra
     }
     if (!kps || !desc || cap <= 0) return ORB_ERR_INVALID;
     ORB_HIP_TRY(hipSetDevice(h->device));
+    struct HostCall { orb_extractor* h; explicit HostCall(orb_extractor* x) : h(x) { h->hostCall = true; } ~HostCall() { h->hostCall = false; } } hostCallGuard(h);
     if (nFrames >= 2 * ORB_PIPE_CHUNK_MIN)                       // large batch: H2D(k+1) | kernels(k) | D2H(k-1)
         return orb_extract_batch_pipelined(h, imgs, nFrames, rows, cols, rowStride, frameStride, kps, desc, cap, counts);
     h->frameBase = 0;

@@ -58,6 +58,13 @@ struct orb_extractor {
     int fastStripsOfLevel[ORB_MAX_LEVELS];
     bool fastStripFixed = false;
     bool geomDirty = false;                 // strip lengths changed: rebuild the geometry on the next call
+    // Strip-length feedback without a sync: a device-path batch leaves its overflow counters in pinned memory behind an
+    // event; the next device-path call applies them if they have arrived (callers that never call orb_extractor_sync
+    // between batches -- device pipelines -- would otherwise keep redoing overflowing strips densely for ever).
+    int* ovfHost = nullptr;                 // pinned copy of the overflow block (kOvfInts ints)
+    hipEvent_t ovfEv = nullptr;
+    unsigned batchSerial = 0, ovfPendingSerial = 0, ovfAppliedSerial = 0;
+    bool hostCall = false;                  // inside orb_extract_batch: status travels with the results, no feedback copy
 
     // device memory
     DevBuf dPattern, dPatternF, dAngTab, dCells, dXtab, dYtab, dXq, dPath;   // constants

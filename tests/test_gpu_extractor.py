@@ -406,6 +406,42 @@ def test_adversarial_patterns_for_the_strip_detector(kind):
     _cmp(np.ascontiguousarray(img), nfeatures=800)
 
 
+def test_strip_lengths_settle_without_any_sync():
+    """A device pipeline that never calls orb_extractor_sync between batches: the overflow counters of every fourth batch
+    come back through pinned memory behind an event and the next call shortens the strips of the levels that overflowed
+    (noise images: every strip overflows its candidate queue at 3 cells per strip).  Results identical all along."""
+    import torch
+    n, W, H = 6, 420, 300
+    rng = np.random.default_rng(31)
+    imgs = rng.integers(0, 256, (n, H, W)).astype(np.uint8)
+    ex = capi.Extractor(600)
+    cap = ex.max_keypoints
+    d = torch.from_numpy(imgs).cuda()
+    k = torch.zeros(n * cap * 28, dtype=torch.uint8, device="cuda")
+    de = torch.zeros(n * cap * 32, dtype=torch.uint8, device="cuda")
+    c = torch.zeros(n, dtype=torch.int32, device="cuda")
+    run = lambda: ex.extract_batch_device(d.data_ptr(), n, H, W, W, W * H, k.data_ptr(), de.data_ptr(), cap, c.data_ptr())
+    run()
+    ex.sync()
+    ovf0, strips0 = ex.fast_overflows()
+    assert ovf0.sum() > 0                                           # the premise: strips do overflow
+    ex2 = capi.Extractor(600)
+    run2 = lambda: ex2.extract_batch_device(d.data_ptr(), n, H, W, W, W * H, k.data_ptr(), de.data_ptr(), cap, c.data_ptr())
+    for _ in range(24):
+        run2()
+        torch.cuda.synchronize()                                    # the GPU finishes, but the HANDLE is never synchronised
+    ex2.sync()
+    ovf1, strips1 = ex2.fast_overflows()
+    assert strips1.sum() > strips0.sum(), (strips0, strips1)        # shorter strips = more of them
+    cnt = c.cpu().numpy()
+    kk = k.cpu().numpy().view(capi.KP_DTYPE).reshape(n, cap)
+    dd = de.cpu().numpy().reshape(n, cap, 32)
+    ref = oracle.Extractor(600)
+    for i in range(n):
+        rk, rd = ref.extract(imgs[i])
+        assert cnt[i] == len(rk) and kk[i, :len(rk)].tobytes() == rk.tobytes() and np.array_equal(dd[i, :len(rk)], rd)
+
+
 def test_host_batch_pipeline_strided_rows_and_tiny_tail():
     """The chunked host pipeline with a row stride larger than the width (pageable: row-wise staging; pinned: 2-D copies),
     17 frames (chunks of 8, 8 and a tail of 1) and more handles' worth of frames than devices in orb_multi (3 frames on
