@@ -306,6 +306,16 @@ extern "C" int orb_extractor_wait_for(orb_extractor* h, void* other_stream)
 
 extern "C" void* orb_extractor_stream(orb_extractor* h) { return h ? (void*)h->stream : nullptr; }
 
+// the quadtree's LDS sort capacity follows the largest candidate count seen (within the LDS budget)
+static void grow_sort_cap(orb_extractor* h, int maxCandidates)
+{
+    int want = 1024;
+    while (want < maxCandidates && want < 4096) want <<= 1;
+    const size_t budget = orb_quadtree_lds_bytes(256, h->nodeCap) > 60 * 1024 ? (size_t)ORB_QT_LDS_MAX : (size_t)60 * 1024;
+    while (want > 256 && orb_quadtree_lds_bytes(want, h->nodeCap) > budget) want >>= 1;
+    if (want > h->sortCap) h->sortCap = want;
+}
+
 // levels whose strips overflowed their candidate queue get shorter strips (results never depend on the strip length).
 // `serial` = the batch the counters belong to: counters of batches launched before an adjustment took effect are ignored.
 static void apply_fast_overflows(orb_extractor* h, const int* perLevel, unsigned serial)
@@ -342,6 +352,7 @@ extern "C" int orb_extract_batch_device(orb_extractor* h, const uint8_t* d_imgs,
     if (h->ovfPendingSerial && !h->hostCall) {           // overflow counters of an earlier batch, if they have arrived
         if (hipEventQuery(h->ovfEv) == hipSuccess) {
             apply_fast_overflows(h, h->ovfHost + 8, h->ovfPendingSerial);
+            grow_sort_cap(h, h->ovfHost[1]);                 // (word 1: largest candidate set that did not fit the LDS sort)
             h->ovfPendingSerial = 0;
         } else {
             (void)hipGetLastError();                     // hipErrorNotReady
@@ -392,7 +403,7 @@ extern "C" int orb_extract_batch_device(orb_extractor* h, const uint8_t* d_imgs,
                            (const uint32_t*)h->dPath.p, scand, h->candSlab, scc, serr, h->ovfCountP(), (int*)h->dOvf.p,
                            h->prm.ini_th_fast, h->prm.min_th_fast, h->fastPdw, h->fastRows, h->fastSdw, h->fastCandCap, n);
     if (prof) ORB_HIP_TRY(hipEventRecord(pe[2], st));
-    orb_launch_quadtree(st, G, scand, h->candSlab, scc, skpl, skc, serr, h->sortCap, h->nodeCap, n);
+    orb_launch_quadtree(st, G, scand, h->candSlab, scc, skpl, skc, serr, h->sortCap, h->nodeCap, n, h->ovfCountP());
     if (prof) ORB_HIP_TRY(hipEventRecord(pe[3], st));
     orb_launch_orient_desc(st, G, pyr, h->pyrSlab, skpl, skc, (const float*)h->dPatternF.p, (const uint4*)h->dAngTab.p, d_kps, d_desc, cap,
                            d_counts, serr, n);
@@ -422,11 +433,7 @@ int orb_check_status(orb_extractor* h)
     {                                                  // adapt the quadtree's LDS sort capacity to the data
         int mx = 0;
         for (size_t i = 0; i < (size_t)ORB_MAX_LEVELS * n; i++) mx = std::max(mx, cand[i]);
-        int want = 1024;
-        while (want < mx && want < 4096) want <<= 1;
-        const size_t budget = orb_quadtree_lds_bytes(256, h->nodeCap) > 60 * 1024 ? (size_t)ORB_QT_LDS_MAX : (size_t)60 * 1024;
-        while (want > 256 && orb_quadtree_lds_bytes(want, h->nodeCap) > budget) want >>= 1;
-        if (want > h->sortCap) h->sortCap = want;
+        grow_sort_cap(h, mx);
     }
     // (host calls see every chunk's own status block: always applied; a device-path sync sees the latest batch's)
     apply_fast_overflows(h, err + (size_t)(1 + 2 * ORB_MAX_LEVELS) * n + 8, h->hostCall ? h->ovfAppliedSerial + 1 : h->batchSerial);

@@ -363,7 +363,8 @@ __device__ __forceinline__ void qt_body(unsigned long long* keys, int n, const O
 __global__ __launch_bounds__(256) void k_quadtree(const OrbGeom G, unsigned long long* __restrict__ cand,
                                                   size_t candSlab, const int* __restrict__ candCount,
                                                   uint32_t* __restrict__ kpl, int* __restrict__ kpCount,
-                                                  int* __restrict__ errFlags, int sortCap, int nodeCap)
+                                                  int* __restrict__ errFlags, int sortCap, int nodeCap,
+                                                  int* __restrict__ ovfBlock)
 {
     extern __shared__ unsigned long long qsm[];
     // LDS carve-up: keys[sortCap] | prevA,prevB[nodeCap] (u64) | A,B[nodeCap] (QtNode) | cuts[nodeCap] (int3)
@@ -399,6 +400,9 @@ __global__ __launch_bounds__(256) void k_quadtree(const OrbGeom G, unsigned long
         qt_body(ldsKeys, n, G, L, f, prevA, prevB, A, B, cuts, va, vb, part, kpl, outCount, errFlags, sh,
                 reinterpret_cast<unsigned char*>(prevA), nodeCap * (16 + 2 * (int)sizeof(QtNode) + (int)sizeof(int3) + 8) + 257 * 4);
     } else {
+        // more candidates than the LDS holds: the host grows the sort capacity when it hears of it (word 1 of the overflow
+        // block: at a sync, or through the unsynchronised feedback of orb_extract_batch_device)
+        if (tid == 0) atomicMax(&ovfBlock[1], n);
         qt_body(gk, n, G, L, f, prevA, prevB, A, B, cuts, va, vb, part, kpl, outCount, errFlags, sh, nullptr, 0);   // rare: sort in global memory
     }
 }
@@ -410,12 +414,12 @@ size_t orb_quadtree_lds_bytes(int sortCap, int nodeCap)
 
 void orb_launch_quadtree(hipStream_t st, const OrbGeom& G, unsigned long long* cand, size_t candSlab,
                          const int* candCount, uint32_t* kpl, int* kpCount, int* errFlags, int sortCap,
-                         int nodeCap, int nFrames)
+                         int nodeCap, int nFrames, int* ovfBlock)
 {
     const size_t lds = orb_quadtree_lds_bytes(sortCap, nodeCap);
     // quotas beyond ~1000 per level (nFeatures >~ 4500) need more than the default 64 KB of dynamic LDS: a workgroup may
     // use the CU's whole 160 KB (one workgroup per CU then -- only the huge-quota configurations pay that)
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_quadtree, dim3(nFrames, G.nlevels), dim3(256), lds, st, G, cand, candSlab, candCount,
-                       kpl, kpCount, errFlags, sortCap, nodeCap);
+                       kpl, kpCount, errFlags, sortCap, nodeCap, ovfBlock);
 }
