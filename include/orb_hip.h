@@ -404,6 +404,12 @@ int orb_stereo_match_batch_device(orb_extractor* left, orb_extractor* right, int
 /* ---------------------------------------------------------------- misc ---------------------*/
 const char* orb_last_error(void);   /* thread-local description of the last failure */
 const char* orb_version(void);
+/* ABI guard: the structs of this header grow between releases (orb_featstore gained the CSR pointers in 2).  A caller
+ * built against an older header would be read past the end of its struct: compare orb_abi_version() with the
+ * ORB_HIP_ABI_VERSION it was compiled with and orb_sizeof_featstore() with sizeof(orb_featstore) before the first call. */
+#define ORB_HIP_ABI_VERSION 3
+int orb_abi_version(void);
+size_t orb_sizeof_featstore(void);
 
 #ifdef __cplusplus
 }

@@ -26,7 +26,9 @@ void orb_set_error(const char* fmt, ...)
     va_end(ap);
 }
 extern "C" const char* orb_last_error(void) { return g_err; }
-extern "C" const char* orb_version(void) { return "orbhip 0.1 (gfx950)"; }
+extern "C" const char* orb_version(void) { return "orbhip 0.3 (gfx950)"; }
+extern "C" int orb_abi_version(void) { return ORB_HIP_ABI_VERSION; }
+extern "C" size_t orb_sizeof_featstore(void) { return sizeof(orb_featstore); }
 
 // level sizes, FAST strips, quadtree boxes, slab layout for a rows x cols input: planned on the host
 // (orb_geometry_host.h), LDS budgets checked, constants uploaded, then committed to the handle -- a failed call leaves
@@ -44,7 +46,8 @@ static int build_geometry(orb_extractor* h, int rows, int cols)
     // LDS sort capacity per (frame, level) instance; larger candidate sets are sorted in global memory.
     // It starts small (more resident workgroups: the kernel is latency-bound) and orb_extractor_sync() grows it to
     // the largest candidate count actually seen, so steady-state batches sort in LDS.
-    int sortCap = 1024;
+    // A rebuild for shorter FAST strips (same image size) keeps what the feedback has already grown it to.
+    int sortCap = (rows == h->lastGeomRows && cols == h->lastGeomCols) ? std::max(h->sortCap, 1024) : 1024;
     // per-workgroup LDS budget: 60 KB (several workgroups per CU) unless the node arrays alone need more
     const size_t qtBudget = orb_quadtree_lds_bytes(256, nodeCap) > 60 * 1024 ? (size_t)ORB_QT_LDS_MAX : (size_t)60 * 1024;
     while (sortCap > 256 && orb_quadtree_lds_bytes(sortCap, nodeCap) > qtBudget) sortCap >>= 1;
@@ -102,6 +105,8 @@ static int build_geometry(orb_extractor* h, int rows, int cols)
     h->framesCap = 0;                                  // slabs changed size: re-allocate lazily
     h->rows = rows;
     h->cols = cols;
+    h->lastGeomRows = rows;
+    h->lastGeomCols = cols;
     h->geomDirty = false;
     h->geomVersion++;
     return ORB_OK;
@@ -115,10 +120,15 @@ static int ensure_scratch(orb_extractor* h, int nFrames)
     if ((rc = h->dCand.ensure(h->candSlab * 8 * nFrames)) != ORB_OK) return rc;
     if ((rc = h->dKpl.ensure((size_t)h->G.kpSlab * 4 * nFrames)) != ORB_OK) return rc;
     if ((rc = h->dOvf.ensure((size_t)4 * std::max<size_t>(1, h->strips.size()) * nFrames)) != ORB_OK) return rc;
-    {
-        const void* before = h->dStat.p;
-        if ((rc = h->dStat.ensure(orb_extractor::statInts(nFrames) * 4)) != ORB_OK) return rc;
-        if (h->dStat.p != before) ORB_HIP_TRY(hipMemsetAsync(h->dStat.p, 0, orb_extractor::kStickyInts * 4, h->stream));   // new block: sticky word starts clear
+    if (orb_extractor::statInts(nFrames) * 4 > h->dStat.bytes) {
+        // a larger status block: the sticky words (error flags of batches that were never synchronised) move with it
+        DevBuf nb;
+        if ((rc = nb.ensure(orb_extractor::statInts(nFrames) * 4)) != ORB_OK) return rc;
+        if (h->dStat.p) ORB_HIP_TRY(hipMemcpyAsync(nb.p, h->dStat.p, orb_extractor::kStickyInts * 4, hipMemcpyDeviceToDevice, h->stream));
+        else ORB_HIP_TRY(hipMemsetAsync(nb.p, 0, orb_extractor::kStickyInts * 4, h->stream));
+        ORB_HIP_TRY(hipStreamSynchronize(h->stream));          // earlier batches still write the old block; rare (growth only)
+        h->dStat.release();
+        h->dStat = nb;
     }
     h->framesCap = nFrames;
     return ORB_OK;
@@ -435,8 +445,9 @@ int orb_check_status(orb_extractor* h)
         for (size_t i = 0; i < (size_t)ORB_MAX_LEVELS * n; i++) mx = std::max(mx, cand[i]);
         grow_sort_cap(h, mx);
     }
-    // (host calls see every chunk's own status block: always applied; a device-path sync sees the latest batch's)
-    apply_fast_overflows(h, err + (size_t)(1 + 2 * ORB_MAX_LEVELS) * n + 8, h->hostCall ? h->ovfAppliedSerial + 1 : h->batchSerial);
+    // (h->statSerial: the batch this block belongs to -- a pipelined host batch retires chunk k while chunk k+1, launched
+    // with the same strips, is in flight; its counters must not shorten the strips a second time)
+    apply_fast_overflows(h, err + (size_t)(1 + 2 * ORB_MAX_LEVELS) * n + 8, h->statSerial ? h->statSerial : h->batchSerial);
     for (int f = 0; f < n; f++)
         if (err[f]) {
             orb_set_error("device-side overflow flag 0x%x on frame %d (1 candidates, 2 nodes, 4 output cap)", err[f], f);
@@ -458,6 +469,7 @@ extern "C" int orb_extractor_sync(orb_extractor* h)
         h->hStat.resize(orb_extractor::statInts(h->lastFrames));
         ORB_HIP_TRY(hipMemcpy(h->hStat.data(), h->dStat.p, h->hStat.size() * 4, hipMemcpyDeviceToHost));
         h->statFetched = true;
+        h->statSerial = 0;
         if (h->hStat[orb_extractor::kStickyInts - 1]) ORB_HIP_TRY(hipMemset(h->dStat.p, 0, orb_extractor::kStickyInts * 4));
         return orb_check_status(h);
     }
@@ -534,9 +546,12 @@ extern "C" int orb_extract_batch(orb_extractor* h, const uint8_t* imgs, int nFra
     };
     orb_extractor::Graph& Gr = h->graph1;
     const bool graphable = nFrames == 1 && whole && !h->profiling && !Gr.broken && !std::getenv("ORB_NO_GRAPH");
+    const void* curBufs[10];
+    h->graph_bufs(curBufs);                                    // (after the ensure() calls above: what this call will address)
     const bool sameKey = graphable && Gr.rows == rows && Gr.cols == cols && Gr.cap == cap && Gr.sortCap == h->sortCap &&
                          Gr.geomVersion == h->geomVersion && Gr.pattern == (const void*)h->patternPtr && Gr.stage == h->hStage &&
-                         rows == h->rows && cols == h->cols && !h->geomDirty;
+                         rows == h->rows && cols == h->cols && !h->geomDirty && h->framesCap >= 1 &&
+                         std::memcmp(Gr.bufs, curBufs, sizeof(curBufs)) == 0;
     bool launched = false;
     if (sameKey && !Gr.exec) {
         // an eager call with this key has been through: everything is allocated and built, so the same calls can be
@@ -568,6 +583,7 @@ extern "C" int orb_extract_batch(orb_extractor* h, const uint8_t* imgs, int nFra
         if (graphable && !Gr.broken && !sameKey && h->lastFrames == 1) {     // remember the key: the next call captures
             Gr.rows = rows; Gr.cols = cols; Gr.cap = cap; Gr.sortCap = h->sortCap; Gr.geomVersion = h->geomVersion;
             Gr.pattern = (const void*)h->patternPtr; Gr.stage = h->hStage;
+            h->graph_bufs(Gr.bufs);                            // (after the eager chain: ensure_scratch has run)
             if (Gr.exec) { (void)hipGraphExecDestroy(Gr.exec); Gr.exec = nullptr; }
         }
     }
@@ -578,6 +594,7 @@ extern "C" int orb_extract_batch(orb_extractor* h, const uint8_t* imgs, int nFra
     ORB_HIP_TRY(hipStreamSynchronize(h->stream));
     h->hStat.assign((const int*)stg, (const int*)stg + orb_extractor::statInts(nFrames));
     h->statFetched = true;
+    h->statSerial = 0;                                         // = the batch just run
     if (h->hStat[orb_extractor::kStickyInts - 1]) ORB_HIP_TRY(hipMemset(h->dStat.p, 0, orb_extractor::kStickyInts * 4));
     std::memcpy(counts, stg + statB, cntB);
     if ((rc = orb_check_status(h)) != ORB_OK) return rc;

@@ -46,6 +46,7 @@ struct orb_extractor {
 
     // geometry for the current image size
     int rows = 0, cols = 0;
+    int lastGeomRows = 0, lastGeomCols = 0;     // size of the last successful geometry build (survives a failed one)
     OrbGeom G;
     std::vector<OrbStrip> strips;               // FAST work items (runs of cells of one cell row)
     int nCells = 0;
@@ -64,6 +65,7 @@ struct orb_extractor {
     int* ovfHost = nullptr;                 // pinned copy of the overflow block (kOvfInts ints)
     hipEvent_t ovfEv = nullptr;
     unsigned batchSerial = 0, ovfPendingSerial = 0, ovfAppliedSerial = 0;
+    unsigned statSerial = 0;                // batch that h->hStat belongs to (0 = the latest one)
     bool hostCall = false;                  // inside orb_extract_batch: status travels with the results, no feedback copy
 
     // device memory
@@ -101,10 +103,18 @@ struct orb_extractor {
         int rows = 0, cols = 0, cap = 0, sortCap = 0, geomVersion = -1;
         const void* pattern = nullptr;
         const void* stage = nullptr;
+        // every device buffer the captured nodes address: a later, larger batch re-allocates them (ensure_scratch, the
+        // staging of the host-buffer API) and a replay would run on freed memory
+        const void* bufs[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         int seenSame = 0;                       // eager calls with the current key (capture after the first)
         bool broken = false;                    // a graph API call failed once: stay eager
     } graph1;
     int geomVersion = 0;                        // bumped by every geometry build
+    void graph_bufs(const void* (&b)[10]) const
+    {
+        const void* cur[10] = {dPyr.p, dCand.p, dKpl.p, dOvf.p, dStat.p, dImgs.p, dKps.p, dDesc.p, dCounts.p, dPatternF.p};
+        for (int i = 0; i < 10; i++) b[i] = cur[i];
+    }
 
     int frameBase = 0;                          // batch index of the device-resident frame 0 (pipelined host batches keep
                                                 // only their last chunk on the device)

@@ -358,7 +358,7 @@ __global__ __launch_bounds__(WAVE) void k_fast_strips(const OrbGeom G, const uin
     if (nCand == 0) return;
     if (nCand > candCap) {                                         // redone by k_fast_strips_dense
         if (lane == 0) {
-            ovfList[atomicAdd(ovfCount, 1)] = (f << 16) | si;
+            ovfList[atomicAdd(ovfCount, 1)] = (int)(((unsigned)f << 16) | (unsigned)si);   // f, si <= 65535 (checked on the host)
             atomicAdd(&ovfCount[8 + S.level], 1);             // statistics for the host: which levels need shorter strips
         }
         return;
@@ -463,8 +463,8 @@ __global__ __launch_bounds__(WAVE) void k_fast_strips_dense(const OrbGeom G, con
     const int nList = *ovfCount;
     const int lowTh = min(iniTh, minTh);
     for (int li = blockIdx.x; li < nList; li += gridDim.x) {
-        const int ent = ovfList[li];
-        const int f = ent >> 16, si = ent & 0xffff;
+        const unsigned ent = (unsigned)ovfList[li];
+        const int f = (int)(ent >> 16), si = (int)(ent & 0xffffu);
         const OrbStrip S = strips[si];
         const OrbLevelGeom& L = G.L[S.level];
         __syncthreads();                                           // previous strip's LDS reads are done

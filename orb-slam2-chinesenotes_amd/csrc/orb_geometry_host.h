@@ -345,6 +345,10 @@ static int orb_plan_geometry(const orb_extractor_params& prm, const OrbHostTable
         P.ytabOff[l] = yt.size();
         yt.insert(yt.end(), t.begin(), t.end());
     }
+    if (strips.size() > 65535) {                                       // the FAST overflow list packs (frame << 16 | strip)
+        orb_set_error("%zu FAST strips per frame: more than the 65535 the overflow list can address", strips.size());
+        return ORB_ERR_UNSUPPORTED;
+    }
     P.nCells = nCells;
     P.pyrSlab = (size_t)align_up((int)pyrOff, 256);
     P.candSlab = candOff;

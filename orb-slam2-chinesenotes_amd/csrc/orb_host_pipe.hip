@@ -94,6 +94,7 @@ int orb_extract_batch_pipelined(orb_extractor* h, const uint8_t* imgs, int nFram
     if ((rc = ensure_pinned(&P.pinOut[0], &P.pinOutBytes, outB, &P.pinOut[1])) != ORB_OK) return rc;
     hipStream_t cs = h->stream;
     int firstErr = ORB_OK;
+    unsigned chunkSerial[2] = {0, 0};
 
     auto issue = [&](int k) -> int {
         const int s = k & 1, f0 = k * C, c = std::min(C, nFrames - f0);
@@ -124,6 +125,7 @@ int orb_extract_batch_pipelined(orb_extractor* h, const uint8_t* imgs, int nFram
         int r = orb_extract_batch_device(h, (const uint8_t*)P.dImg[s].p, c, rows, cols, cols, imgBytes, (orb_keypoint*)P.dKps[s].p,
                                          (uint8_t*)P.dDesc[s].p, cap, (int32_t*)P.dCnt[s].p);
         if (r != ORB_OK) return r;
+        chunkSerial[s] = h->batchSerial;
         // the status block is the handle's single one: it leaves on the compute stream, before the next chunk clears it
         uint8_t* po = (uint8_t*)P.pinOut[s];
         ORB_HIP_TRY(hipMemcpyAsync(po, h->dStat.p, orb_extractor::statInts(c) * 4, hipMemcpyDeviceToHost, cs));
@@ -148,7 +150,9 @@ int orb_extract_batch_pipelined(orb_extractor* h, const uint8_t* imgs, int nFram
         const int keepFrames = h->lastFrames;                  // orb_check_status reads the block of `c` frames
         h->lastFrames = c;
         h->hStat.assign((const int*)po, (const int*)po + orb_extractor::statInts(c));
+        h->statSerial = chunkSerial[s];
         int r = orb_check_status(h);
+        h->statSerial = 0;
         h->lastFrames = keepFrames;
         std::memcpy(counts + f0, po + statB, (size_t)4 * c);
         if (r != ORB_OK) return r;

@@ -730,9 +730,9 @@ extern "C" int orb_bow_build_csr_device(orb_matcher* m, const uint16_t* d_node_o
     if (nFrames == 0) return ORB_OK;
     if (cap <= 0 || cap > 8192) { orb_set_error("featstore cap must be 1..8192"); return ORB_ERR_UNSUPPORTED; }
     const size_t lds = (size_t)cap * 8 + (size_t)nNodes * 8;
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_csr), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (lds > 156 * 1024) { orb_set_error("feature capacity %d x %d nodes exceeds the CSR kernel's LDS budget", cap, nNodes); return ORB_ERR_UNSUPPORTED; }
-    ORB_HIP_TRY(hipSetDevice(m->device));
+    ORB_HIP_TRY(hipSetDevice(m->device));                      // the attribute below is per device
+    if (lds > 64 * 1024) ORB_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_csr), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_build_csr, dim3(nFrames), dim3(1024), lds, m->stream, d_node_of, d_counts, cap, nNodes, d_keys, d_start,
                        d_cnt);
     ORB_HIP_TRY(hipGetLastError());

@@ -65,7 +65,7 @@ SYMBOLS = [
     "orb_hamming", "orb_three_maxima", "orb_matcher_create", "orb_matcher_destroy", "orb_matcher_sync",
     "orb_match_bow", "orb_match_bow_kk", "orb_match_init", "orb_match_projection", "orb_match_projection_best", "orb_match_triangulation", "orb_vocab_create", "orb_vocab_destroy", "orb_vocab_level_nodes", "orb_bow_transform",
     "orb_bow_transform_device", "orb_distinctive_descriptors", "orb_distinctive_descriptors_device", "orb_bow_assign_device", "orb_match_bow_batch_device", "orb_bow_build_csr_device",
-    "orb_matcher_stream", "orb_stereo_match", "orb_stereo_match_device", "orb_stereo_match_batch_device", "orb_extractor_wait_for", "orb_matcher_wait_for", "orb_last_error", "orb_version", "orb_multi_create", "orb_multi_destroy", "orb_multi_devices", "orb_multi_handle",
+    "orb_matcher_stream", "orb_stereo_match", "orb_stereo_match_device", "orb_stereo_match_batch_device", "orb_extractor_wait_for", "orb_matcher_wait_for", "orb_last_error", "orb_version", "orb_abi_version", "orb_sizeof_featstore", "orb_multi_create", "orb_multi_destroy", "orb_multi_devices", "orb_multi_handle",
     "orb_multi_set_pattern", "orb_multi_extract_batch", "orb_shard_range",
 ]
 

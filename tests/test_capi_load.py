@@ -28,6 +28,14 @@ def test_exports_every_declared_symbol(lib):
         assert hasattr(lib, s), s
 
 
+def test_abi_version_and_struct_sizes(lib):
+    """orb_featstore grew; callers can compare the library's idea of it with their own."""
+    hdr = open(os.path.join(ROOT, "include", "orb_hip.h")).read()
+    assert lib.orb_abi_version() == int(re.search(r"#define ORB_HIP_ABI_VERSION (\d+)", hdr).group(1))
+    lib.orb_sizeof_featstore.restype = ctypes.c_size_t
+    assert lib.orb_sizeof_featstore() == ctypes.sizeof(capi.FeatStoreC)
+
+
 def test_keypoint_layout_is_cv_keypoint():
     assert capi.KP_DTYPE.itemsize == 28 and capi.KP_DTYPE == oracle.KP_DTYPE
 

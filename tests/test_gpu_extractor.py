@@ -307,6 +307,52 @@ def test_single_frame_graph_replay_is_bit_exact():
     ex.close(); ex2.close()
 
 
+def test_graph_replay_after_the_scratch_buffers_moved():
+    """the captured single-frame graph bakes in the scratch slabs; a later batch that needs more frames
+    re-allocates them.  The graph key now holds every captured device pointer, so the next single-frame call re-captures
+    instead of replaying on freed memory.  Orders: small host batch (non-pipelined staging grows), pipelined host batch,
+    device batch of 64 frames -- each followed by single-frame calls, all bit-exact."""
+    import torch
+    W, H = 320, 240
+    ex, ref = capi.Extractor(500), oracle.Extractor(500)
+
+    def single(i):
+        img = synth.synth_frame(300 + i, W, H)
+        k, d = ex.extract(img)
+        rk, rd = ref.extract(img)
+        assert k.tobytes() == rk.tobytes() and np.array_equal(d, rd), i
+
+    for i in range(3):
+        single(i)                                                # eager, capture, replay
+    imgs = synth.synth_sequence(320, 6, W, H)
+    for (k, d), im in zip(ex.extract_batch(imgs), imgs):          # 6 frames: dImgs / dKps / dDesc / scratch all grow
+        rk, rd = ref.extract(im)
+        assert k.tobytes() == rk.tobytes() and np.array_equal(d, rd)
+    for i in range(3, 6):
+        single(i)
+    imgs = synth.synth_sequence(330, 45, W, H)
+    got = ex.extract_batch(imgs)                                  # pipelined path (chunks of >= 8 frames)
+    rk, rd = ref.extract(imgs[44])
+    assert got[44][0].tobytes() == rk.tobytes()
+    for i in range(6, 9):
+        single(i)
+    B = 64
+    cap = ex.max_keypoints
+    d_img = torch.from_numpy(synth.synth_sequence(340, B, W, H)).cuda()
+    d_kps = torch.zeros((B, cap, 28), dtype=torch.uint8, device="cuda")
+    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+    d_cnt = torch.zeros(B, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    ex.extract_batch_device(d_img.data_ptr(), B, H, W, W, W * H, d_kps.data_ptr(), d_desc.data_ptr(), cap, d_cnt.data_ptr())
+    ex.sync()
+    rk, rd = ref.extract(d_img[B - 1].cpu().numpy())
+    n = int(d_cnt[B - 1])
+    assert n == len(rk) and d_kps[B - 1, :n].cpu().numpy().tobytes() == rk.tobytes()
+    for i in range(9, 13):
+        single(i)
+    ex.close()
+
+
 def test_randomized_geometry_and_parameter_sweep():
     """40 seeded random (size, nfeatures, levels, scale factor, thresholds) combinations, each bit-exact against the
     oracle stage by stage: exercises odd widths/heights, degenerate upper levels, every resize path, cell grids with
