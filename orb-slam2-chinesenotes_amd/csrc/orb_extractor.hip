@@ -37,7 +37,8 @@ static int build_geometry(orb_extractor* h, int rows, int cols)
 {
     h->rows = h->cols = 0;
     OrbGeomPlan P;
-    int rc = orb_plan_geometry(h->prm, h->tables, h->fastStripK, rows, cols, P);
+    // strips cut by the self-tuning default (not by ORB_FAST_STRIP) stay within the 112-byte rows of k_fast_strips_p<28>
+    int rc = orb_plan_geometry(h->prm, h->tables, h->fastStripK, rows, cols, P, h->fastStripFixed ? 0 : 112);
     if (rc != ORB_OK) return rc;
     const OrbGeom& G = P.G;
     std::vector<OrbStrip>& strips = P.strips;
@@ -97,6 +98,9 @@ static int build_geometry(orb_extractor* h, int rows, int cols)
     h->fastPdw = maxPdw;
     h->fastRows = maxRows;
     h->fastSdw = maxSdw;
+    // the fixed-pitch detector (k_fast_strips_p<P>) needs rows within its pitch
+    h->fastP = 0;
+    if (!std::getenv("ORB_FAST_GENERIC")) h->fastP = maxPdw <= 20 ? 20 : maxPdw <= 28 ? 28 : 0;
     // candidate queue of a strip (pixels whose score exceeds the lower threshold); a strip with more switches to
     // the dense scan.  At most 64 queue steps (one bit per step in the kernel).
     h->fastCandCap = 640;
@@ -411,7 +415,7 @@ extern "C" int orb_extract_batch_device(orb_extractor* h, const uint8_t* d_imgs,
     if (prof) ORB_HIP_TRY(hipEventRecord(pe[1], st));
     orb_launch_fast_strips(st, G, pyr, h->pyrSlab, (const OrbStrip*)h->dCells.p, (int)h->strips.size(),
                            (const uint32_t*)h->dPath.p, scand, h->candSlab, scc, serr, h->ovfCountP(), (int*)h->dOvf.p,
-                           h->prm.ini_th_fast, h->prm.min_th_fast, h->fastPdw, h->fastRows, h->fastSdw, h->fastCandCap, n);
+                           h->prm.ini_th_fast, h->prm.min_th_fast, h->fastPdw, h->fastRows, h->fastSdw, h->fastCandCap, n, h->fastP);
     if (prof) ORB_HIP_TRY(hipEventRecord(pe[2], st));
     orb_launch_quadtree(st, G, scand, h->candSlab, scc, skpl, skc, serr, h->sortCap, h->nodeCap, n, h->ovfCountP());
     if (prof) ORB_HIP_TRY(hipEventRecord(pe[3], st));

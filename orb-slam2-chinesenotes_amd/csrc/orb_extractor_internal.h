@@ -53,6 +53,7 @@ struct orb_extractor {
     size_t pyrSlab = 0, candSlab = 0;
     int sortCap = 4096, nodeCap = 0, maxKp = 0;
     int fastPdw = 20, fastRows = 66, fastSdw = 18, fastCandCap = 640;   // LDS sizing of k_fast_strips
+    int fastP = 0;                          // compile-time pitch of k_fast_strips_p in use (0: the generic kernel)
     // cells per strip aimed at, per level.  Starts at 3 and is lowered for a level whose strips keep overflowing the
     // candidate queue (coarse levels have several times more corners per pixel); ORB_FAST_STRIP=k fixes it (tuning).
     int fastStripK[ORB_MAX_LEVELS];

@@ -29,6 +29,7 @@
 //   * the quadtree path of a candidate is two table look-ups (x and y bisect independently);
 //   * everything derived from the strip rectangle alone comes precomputed in the 48-byte OrbStrip record.
 #include <algorithm>
+#include <type_traits>
 
 #include "orb_kernels.h"
 #include "orb_wave.h"
@@ -80,6 +81,13 @@ __device__ __forceinline__ unsigned pk_add_u16_s(unsigned a, unsigned sUniform)
     unsigned d;
     asm("v_pk_add_u16 %0, %1, %2" : "=v"(d) : "v"(a), "s"(sUniform));
     return d;
+}
+typedef unsigned short orb_us2 __attribute__((ext_vector_type(2)));
+// v_pk_add_u16 through the vector type: the compiler sees the operands (the inline-asm form with a scalar operand made it
+// pad the preceding v_cmp with five s_nop)
+__device__ __forceinline__ unsigned pk_add_u16_n(unsigned a, unsigned b)
+{
+    return __builtin_bit_cast(unsigned, __builtin_bit_cast(orb_us2, a) + __builtin_bit_cast(orb_us2, b));
 }
 __device__ __forceinline__ unsigned pk_max_i16(unsigned a, unsigned b)
 {
@@ -441,6 +449,323 @@ __global__ __launch_bounds__(WAVE) void k_fast_strips(const OrbGeom G, const uin
     }
 }
 
+
+// =====================================================================================================================
+// k_fast_strips_p<P>: the same strip detector with a COMPILE-TIME tile pitch of P dwords (P % 8 == 4) and leaner
+// bookkeeping around the same arithmetic (round 3: the kernel runs at the issue rate of its instruction mix, so the
+// only lever is fewer vector instructions; r02 counters: 1980 per strip-wave, of which staging 150, phase A 84 per 64
+// quads, phase B 145 per 64 pairs).  What changed against k_fast_strips:
+//   * every LDS access is (one address VGPR + immediate offset): the 11 / 21 window reads of phases A / B need no
+//     per-row address arithmetic;
+//   * staging moves 16-byte chunks, 64 / CL rows per step, with loop-invariant lane -> (row, chunk) decode: ~3 vector
+//     instructions per load instead of 15;
+//   * phase A walks the zone in blocks of 8 rows, COLUMN-major inside a block (lane -> row = lane & 7, quad += 8 per step):
+//     with P = 4 (mod 8) the 32 lanes of an LDS access group cover 4 columns x 8 rows = 32 distinct banks (row-major
+//     enumeration put a few lanes of the next row on the banks of the previous one: every read 2-way conflicted), and
+//     the whole per-lane state is ONE register ((window address << 8) | quad): add, compare, select, add, shift;
+//   * the queue entry of a surviving pair IS the LDS address of its 7 x 3-dword window; phase B decodes (row, column)
+//     from it only for the few pixels that become candidates (constant division by the pitch);
+//   * pixels of an edge quad that lie outside the zone are not tested in phase B any more: their candidates are dropped
+//     when the candidates are scattered into the score map (their queue score is zeroed, so the NMS ignores them).
+// Same results as k_fast_strips bit for bit (tests/test_gpu_extractor.py::test_fast_strip_sizes_and_queue_overflow runs
+// both); geometries with strips wider than the largest instantiated pitch use the generic kernel.
+#define F2_RING 128                    // entries of one pair ring
+
+template <int P>
+struct FastP {
+    static constexpr int ROWB = 4 * P;                                     // tile row pitch in bytes
+    static constexpr int HDR = ((2 * F2_RING * 2 + 16 + ROWB - 1) / ROWB) * ROWB;   // rings + pad, a multiple of ROWB
+    static constexpr int CL = (P / 4 <= 8) ? 8 : 16;                       // lanes per staged row (16-byte chunks)
+    static constexpr int RI = 64 / CL;                                     // rows per staging step
+    static constexpr int MAXIT = (66 + RI - 1) / RI;                       // strips are at most 66 rows tall
+    static_assert(P % 8 == 4 && P / 4 <= 16, "pitch must be 4 (mod 8) dwords and at most 16 chunks");
+    static_assert(HDR % 16 == 0 && ROWB % 16 == 0, "16-byte aligned tile rows");
+};
+size_t orb_fast_p_lds_bytes(int P, int rowsMax, int candCap)
+{
+    const int rowb = 4 * P, hdr = ((2 * F2_RING * 2 + 16 + rowb - 1) / rowb) * rowb;
+    // phase A's last block may run up to 7 rows past the zone: those windows are read (never used); they land in the
+    // candidate arrays behind the tile, which therefore cover at least 8 tile rows
+    const size_t tail = std::max<size_t>((size_t)3 * candCap + 16, (size_t)8 * rowb + 16);
+    return (size_t)hdr + (size_t)rowsMax * rowb + 16 + tail;
+}
+
+typedef unsigned int orb_u32x4 __attribute__((ext_vector_type(4)));
+typedef orb_u32x4 __attribute__((aligned(8))) orb_u32x4_a8;
+// LDS accesses of the hot loops by raw byte address (address space 3 pointers made from integers): the kernel owns no
+// static LDS, so its dynamic block starts at address 0 (checked once at the top of the kernel) and no access pays an add
+// of the block's (relocatable) base
+typedef __attribute__((address_space(3))) uint32_t orb_lds_u32;
+typedef __attribute__((address_space(3))) uint16_t orb_lds_u16;
+__device__ __forceinline__ const orb_lds_u32* lds_dw(unsigned byteAddr) { return reinterpret_cast<const orb_lds_u32*>(byteAddr); }
+__device__ __forceinline__ orb_lds_u16* lds_hw(unsigned byteAddr) { return reinterpret_cast<orb_lds_u16*>(byteAddr); }
+
+template <int P>
+__global__ __launch_bounds__(WAVE) void k_fast_strips_p(const OrbGeom G, const uint8_t* __restrict__ pyr, size_t pyrSlab,
+                                                        const OrbStrip* __restrict__ strips,
+                                                        const uint32_t* __restrict__ pathTab,
+                                                        unsigned long long* __restrict__ cand, size_t candSlab,
+                                                        int* __restrict__ candCount, int* __restrict__ errFlags,
+                                                        int* __restrict__ ovfCount, int* __restrict__ ovfList, int iniTh,
+                                                        int minTh, int rowsMax, int candCap, int nStrips, int nFrames,
+                                                        unsigned invPerFrame)
+{
+    // dynamic LDS (bytes): [ring A 256 | ring B 256 | pad .. HDR) | tile rowsMax x ROWB | 16 | candPos 2 candCap | candScore candCap]
+    extern __shared__ uint32_t fsm[];
+    constexpr int ROWB = FastP<P>::ROWB, TB = FastP<P>::HDR;
+    uint8_t* lds = reinterpret_cast<uint8_t*>(fsm);
+    const int lane = threadIdx.x;
+    int f, si;
+    if (invPerFrame) {                                             // 1-D XCD-aware grid: a frame's strips share one L2
+        if (!orb_xcd_decode(blockIdx.x, (unsigned)nStrips, invPerFrame, nFrames, f, si)) return;
+    } else {
+        f = blockIdx.y;
+        si = blockIdx.x;
+    }
+    if ((unsigned)(uintptr_t)((__attribute__((address_space(3))) uint32_t*)fsm) != 0u) {   // see lds_dw
+        if (lane == 0) orb_flag_error(errFlags, f, 1);
+        return;
+    }
+    const OrbStrip S = strips[si];
+    const OrbLevelGeom& L = G.L[S.level];
+
+    // ---- stage rows [y0, y0 + h) from the 8-byte aligned column x0 - xoff, ROWB bytes per row, 16 bytes per lane
+    {
+        constexpr int CL = FastP<P>::CL, RI = FastP<P>::RI, MAXIT = FastP<P>::MAXIT, NC = P / 4;
+        const int rr = lane / CL, c = lane % CL;
+        const int h = S.h, pitch = L.pitch;
+        const uint8_t* src = pyr + (size_t)f * pyrSlab + L.pyrOff + (size_t)(S.y0 + rr) * pitch + (S.x0 - S.xoff) + 16 * c;
+        uint8_t* dst = lds + TB + rr * ROWB + 16 * c;
+        const bool act = c < NC;
+        orb_u32x4 v[MAXIT];
+#pragma unroll
+        for (int it = 0; it < MAXIT; it++)
+            if (it * RI < h) {                                     // (uniform)
+                if (act && it * RI + rr < h) v[it] = *reinterpret_cast<const orb_u32x4_a8*>(src + (size_t)it * RI * pitch);
+            }
+#pragma unroll
+        for (int it = 0; it < MAXIT; it++)
+            if (it * RI < h) {
+                if (act && it * RI + rr < h) *reinterpret_cast<orb_u32x4*>(dst + it * RI * ROWB) = v[it];
+            }
+    }
+    __syncthreads();
+
+    uint16_t* ringA = reinterpret_cast<uint16_t*>(lds);
+    uint16_t* ringB = ringA + F2_RING;
+    const int CB = TB + rowsMax * ROWB + 16;                       // candidate positions (u16: row << 8 | col), then scores (u8)
+    uint16_t* candPos = reinterpret_cast<uint16_t*>(lds + CB);
+    uint8_t* candScore = lds + CB + 2 * candCap;
+    const int lowTh = min(iniTh, minTh);
+    int nCand = 0;
+
+    // ---- phases A and B (see fast_detect): x = (LDS byte address of the window's first dword << 8) | quad index in the zone
+    {
+        const int zh = S.zh, nq = S.nq, qLo = S.qLo;
+        unsigned thKV = (unsigned)(0x7fff - lowTh) * 0x10001u;
+        asm volatile("" : "+v"(thKV));                             // (a vector register: no scalar operand in the loop's packed adds)
+        const int nBlocks = (zh + 7) >> 3, nItems = nBlocks * 8 * nq;
+        // item j = base + lane -> column c = j >> 3 over all blocks, block = c / nq, quad = c % nq, row = 8 block + (lane & 7).
+        // Strips of >= 8 quads advance incrementally (a step of 8 columns wraps into the next block at most once); the few
+        // narrower ones (clipped last cells) decode every step from scratch.
+        const bool narrow = nq < 8;
+        const float rcpNq = __frcp_rn((float)nq);
+        auto decode = [&](int base) -> unsigned {
+            const int c = (base + lane) >> 3;
+            const int blk = (int)(((float)c + 0.5f) * rcpNq);       // c <= 600, nq <= 7: 0.5 / nq is far above the rounding error
+            const int qi = c - blk * nq;
+            return ((unsigned)(TB + ((blk * 8 + (lane & 7)) * P + qLo + qi - 1) * 4) << 8) | (unsigned)qi;
+        };
+        unsigned x = narrow ? decode(0) : ((unsigned)(TB + ((lane & 7) * P + qLo + (lane >> 3) - 1) * 4) << 8) | (unsigned)(lane >> 3);
+        const unsigned xStep = (32u << 8) | 8u;
+        unsigned xWrapV = ((unsigned)(8 * ROWB - 4 * nq) << 8) - (unsigned)nq;
+        asm volatile("" : "+v"(xWrapV));                           // stays in a vector register (v_cndmask cannot take it as a scalar)
+        const unsigned aEnd = (unsigned)(TB + zh * ROWB - 4);       // windows of zone rows start below this address (quad - 1 >= -1)
+        int cntA = 0, cntB = 0, headA = 0, headB = 0;               // wave-uniform ring state
+        constexpr unsigned kRowMagic = (unsigned)(((1ull << 32) + ROWB - 1) / ROWB);   // floor(a / ROWB) for a < 2^16
+        auto bstep = [&](auto Htag, const uint16_t* ring, int head, int n) {
+            constexpr int H = decltype(Htag)::value;
+            const bool act = lane < n;
+            unsigned s2 = 0, a = 0;
+            if (act) {
+                a = ring[(head + lane) & (F2_RING - 1)];
+                const orb_lds_u32* p = lds_dw(a);
+                unsigned W[7][3];
+#pragma unroll
+                for (int r = 0; r < 7; r++) { W[r][0] = p[r * P]; W[r][1] = p[r * P + 1]; W[r][2] = p[r * P + 2]; }
+                s2 = H ? fast_pair<6>(W) : fast_pair<4>(W);         // two scores, one per 16-bit half
+            }
+            const int sLo = (int)(s2 & 0xffffu), sHi = (int)(s2 >> 16);
+            const bool pLo = sLo > lowTh, pHi = sHi > lowTh;
+            const unsigned long long bLo = __ballot(pLo), bHi = __ballot(pHi);
+            if ((bLo | bHi) == 0) return;
+            const int nLo = __popcll(bLo), nHi = __popcll(bHi);
+            if (nCand + nLo + nHi <= candCap) {
+                // (row, col) of the pair's first pixel: a + 4 = TB + zoneRow * ROWB + 4 quad
+                const unsigned a4 = a + 4u, rowAbs = __umulhi(a4, kRowMagic);
+                const unsigned e = ((rowAbs + (unsigned)(3 - TB / ROWB)) << 8) + (a4 - rowAbs * (unsigned)ROWB) + (unsigned)(2 * H);
+                if (pLo) {
+                    const int w = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bLo >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bLo, (unsigned)nCand));
+                    candPos[w] = (uint16_t)e;
+                    candScore[w] = (uint8_t)sLo;
+                }
+                if (pHi) {
+                    const int w = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bHi >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bHi, (unsigned)(nCand + nLo)));
+                    candPos[w] = (uint16_t)(e + 1);
+                    candScore[w] = (uint8_t)sHi;
+                }
+            }
+            nCand += nLo + nHi;
+        };
+        for (int base = 0;; base += WAVE) {
+            const bool more = base < nItems;
+            if (more) {
+                const unsigned a = x >> 8;
+                const orb_lds_u32* p = lds_dw(a);
+                const unsigned c0 = p[3 * P], c1 = p[3 * P + 1], c2 = p[3 * P + 2];           // row y
+                const unsigned u1 = p[1], d1 = p[6 * P + 1];                                  // rows y-3, y+3: x .. x+3
+                const unsigned a0 = p[P], a1 = p[P + 1], a2 = p[P + 2];                       // row y-2
+                const unsigned b0 = p[5 * P], b1 = p[5 * P + 1], b2 = p[5 * P + 2];           // row y+2
+                unsigned u[2];
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const unsigned cc = h ? pick2<6>(c0, c1, c2) : pick2<4>(c0, c1, c2);
+                    const unsigned r0 = h ? pick2<6>(0, d1, 0) : pick2<4>(0, d1, 0);              // k=0  (0,+3)
+                    const unsigned r8 = h ? pick2<6>(0, u1, 0) : pick2<4>(0, u1, 0);              // k=8  (0,-3)
+                    const unsigned r4 = h ? pick2<9>(c0, c1, c2) : pick2<7>(c0, c1, c2);          // k=4  (+3,0)
+                    const unsigned r12 = h ? pick2<3>(c0, c1, c2) : pick2<1>(c0, c1, c2);         // k=12 (-3,0)
+                    const unsigned r2 = h ? pick2<8>(b0, b1, b2) : pick2<6>(b0, b1, b2);          // k=2  (+2,+2)
+                    const unsigned r10 = h ? pick2<4>(a0, a1, a2) : pick2<2>(a0, a1, a2);         // k=10 (-2,-2)
+                    const unsigned r6 = h ? pick2<8>(a0, a1, a2) : pick2<6>(a0, a1, a2);          // k=6  (+2,-2)
+                    const unsigned r14 = h ? pick2<4>(b0, b1, b2) : pick2<2>(b0, b1, b2);         // k=14 (-2,+2)
+                    const unsigned mlo = pk_max3(pk_min2(r0, r8), pk_min2(r4, r12), pk_max2(pk_min2(r2, r10), pk_min2(r6, r14)));
+                    const unsigned mhi = pk_min3(pk_max2(r0, r8), pk_max2(r4, r12), pk_min2(pk_max2(r2, r10), pk_max2(r6, r14)));
+                    u[h] = pk_max_i16(pk_sub_i16(cc, mlo), pk_sub_i16(mhi, cc));                  // U per 16-bit half (signed)
+                }
+                // a pair is queued if one of its pixels has U > lowTh (bit 15 of the half after adding 0x7fff - lowTh) and
+                // it lies on a zone row (the last block of 8 rows may run past the zone)
+                // (the ballots of the two compares are ANDed as scalars: a ballot of their conjunction makes the compiler
+                // materialise the predicate in a register)
+                const bool valid = a < aEnd;
+                const bool qa = (pk_add_u16_n(u[0], thKV) & 0x80008000u) != 0, qb = (pk_add_u16_n(u[1], thKV) & 0x80008000u) != 0;
+                const unsigned long long bv = __ballot(valid), ba = __ballot(qa) & bv, bb = __ballot(qb) & bv;
+                // ring slot: ((head + cnt + rank among the queued lanes) mod 128) as a byte offset
+                const unsigned ra = __builtin_amdgcn_mbcnt_hi((unsigned)(ba >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ba, 0u));
+                const unsigned rb = __builtin_amdgcn_mbcnt_hi((unsigned)(bb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bb, 0u));
+                if (qa & valid) *lds_hw(((ra << 1) + (unsigned)(2 * (headA + cntA))) & (2 * F2_RING - 2)) = (uint16_t)a;
+                if (qb & valid) lds_hw(((rb << 1) + (unsigned)(2 * (headB + cntB))) & (2 * F2_RING - 2))[F2_RING] = (uint16_t)a;
+                cntA += __popcll(ba);
+                cntB += __popcll(bb);
+                if (!narrow) {
+                    x += xStep;
+                    x += ((x & 0xffu) >= (unsigned)nq) ? xWrapV : 0u;
+                } else {
+                    x = decode(base + WAVE);
+                }
+            }
+            __syncthreads();       // LDS operations of one wave execute in order; this only keeps the compiler from reordering
+            while (cntA >= WAVE || (!more && cntA > 0)) {
+                const int n = min(cntA, WAVE);
+                bstep(std::integral_constant<int, 0>(), ringA, headA, n);
+                headA = (headA + n) & (F2_RING - 1);
+                cntA -= n;
+            }
+            while (cntB >= WAVE || (!more && cntB > 0)) {
+                const int n = min(cntB, WAVE);
+                bstep(std::integral_constant<int, 1>(), ringB, headB, n);
+                headB = (headB + n) & (F2_RING - 1);
+                cntB -= n;
+            }
+            if (!more) break;
+        }
+        __syncthreads();
+    }
+    if (nCand == 0) return;
+    if (nCand > candCap) {                                         // redone by k_fast_strips_dense
+        if (lane == 0) {
+            ovfList[atomicAdd(ovfCount, 1)] = (int)(((unsigned)f << 16) | (unsigned)si);
+            atomicAdd(&ovfCount[8 + S.level], 1);
+        }
+        return;
+    }
+
+    // ---- the tile is dead: it becomes the score map (0 everywhere but at the candidates inside the zone)
+    {
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        uint4* t4 = reinterpret_cast<uint4*>(lds + TB - 16);       // one row of slack on both sides of the rows the NMS reads
+        const int n4 = (16 + S.h * ROWB + 16) >> 4;
+        for (int i = lane; i < n4; i += WAVE) t4[i] = z;
+    }
+    __syncthreads();
+    uint8_t* smap = lds + TB;
+    const int zLo = S.zLo, zHi = S.zHi, wCell = S.wCell;
+    for (int e = lane; e < nCand; e += WAVE) {
+        const unsigned ent = candPos[e];
+        const unsigned col = ent & 0xff;
+        if (col - (unsigned)zLo < (unsigned)(zHi - zLo)) smap[(ent >> 8) * ROWB + col] = candScore[e];
+        else candScore[e] = 0;                                     // pixel of the neighbouring strip inside an edge quad
+    }
+    __syncthreads();
+
+    // ---- cell-local 3x3 strict NMS over the candidate queue, both thresholds at once (as k_fast_strips)
+    unsigned long long keep0 = 0, keep1 = 0;                       // one bit per queue step (<= 64 steps)
+    unsigned has = 0;
+    {
+        int it = 0;
+        for (int base = 0; base < nCand; base += WAVE, it++) {
+            const int e = base + lane;
+            if (e < nCand) {
+                const unsigned ent = candPos[e];
+                const int row = ent >> 8, col = ent & 0xff;
+                const int c = (int)(((unsigned)(col - zLo) * S.invW) >> 16);
+                const int cs = zLo + c * wCell, ce = min(cs + wCell, zHi);
+                const int Sv = candScore[e];
+                const bool ok = fast_nms_ok(smap + row * ROWB + col, ROWB, col == cs, col == ce - 1, Sv);
+                const unsigned k0 = ok && Sv > iniTh, k1 = ok && Sv > minTh;
+                keep0 |= (unsigned long long)k0 << it;
+                keep1 |= (unsigned long long)k1 << it;
+                has |= k0 << c;
+            }
+        }
+    }
+    const unsigned fb = ~orb_wave_or(has);                         // cells without a keypoint at iniTh
+    unsigned long long keepF = 0;
+    int mine = 0;
+    for (unsigned long long mm = keep0 | keep1; mm;) {             // the few entries of this lane that passed the NMS
+        const int it = __ffsll((long long)mm) - 1;
+        mm &= mm - 1;
+        const int col = candPos[it * WAVE + lane] & 0xff;
+        const unsigned c = ((unsigned)(col - zLo) * S.invW) >> 16;
+        const unsigned long long k = ((((fb >> c) & 1u) ? keep1 : keep0) >> it) & 1ull;
+        keepF |= k << it;
+        mine += (int)k;
+    }
+    const int incl = orb_wave_scan_incl(mine);
+    const int total = __builtin_amdgcn_readlane(incl, WAVE - 1);
+    if (total == 0) return;
+    int base0 = 0;
+    if (lane == 0) base0 = atomicAdd(&candCount[f * ORB_MAX_LEVELS + S.level], total);
+    base0 = __builtin_amdgcn_readfirstlane(base0);
+    if (base0 + total > L.candCap) {                               // cannot happen: candCap is the NMS bound
+        if (lane == 0) orb_flag_error(errFlags, f, 1);
+        return;
+    }
+    const uint32_t* xtab = pathTab + L.pathXOff;
+    const uint32_t* ytab = pathTab + L.pathYOff;
+    unsigned long long* out = cand + (size_t)f * candSlab + L.candBase;
+    const int cy0 = S.ci * L.hCell;
+    int w = base0 + incl - mine;
+    while (keepF) {
+        const int it = __ffsll((long long)keepF) - 1;
+        keepF &= keepF - 1;
+        const unsigned ent = candPos[it * WAVE + lane];
+        const int row = ent >> 8, col = ent & 0xff;
+        const int c = (int)(((unsigned)(col - zLo) * S.invW) >> 16);
+        const int Sv = candScore[it * WAVE + lane];
+        out[w++] = FAST_KEY(row, col, c, Sv);
+    }
+}
+
 // The strips of ovfList ((frame << 16 | strip) entries) again, with a full score map next to the tile and
 // a dense scan of it, one cell at a time: any number of candidates.  One wave per workgroup, grid-stride over the list.
 __global__ __launch_bounds__(WAVE) void k_fast_strips_dense(const OrbGeom G, const uint8_t* __restrict__ pyr,
@@ -559,12 +884,21 @@ size_t orb_fast_dense_lds_bytes(int pdw, int rowsMax, int sdw)
 void orb_launch_fast_strips(hipStream_t st, const OrbGeom& G, const uint8_t* pyr, size_t pyrSlab,
                             const OrbStrip* strips, int nStrips, const uint32_t* pathTab, unsigned long long* cand,
                             size_t candSlab, int* candCount, int* errFlags, int* ovfCount, int* ovfList, int iniTh, int minTh,
-                            int pdw, int rowsMax, int sdw, int candCap, int nFrames)
+                            int pdw, int rowsMax, int sdw, int candCap, int nFrames, int fixedPitch)
 {
     if (nStrips == 0) return;
     unsigned inv = 0;
     const unsigned wgs = orb_xcd_grid((unsigned)nStrips, nFrames, &inv);
-    hipLaunchKernelGGL(k_fast_strips, wgs ? dim3(wgs) : dim3(nStrips, nFrames), dim3(WAVE),
+    const dim3 grid = wgs ? dim3(wgs) : dim3(nStrips, nFrames);
+    if (fixedPitch && orb_fast_p_lds_bytes(fixedPitch, rowsMax, candCap) > 64 * 1024) fixedPitch = 0;
+    if (fixedPitch == 28)
+        hipLaunchKernelGGL(k_fast_strips_p<28>, grid, dim3(WAVE), orb_fast_p_lds_bytes(28, rowsMax, candCap), st, G, pyr, pyrSlab, strips, pathTab,
+                           cand, candSlab, candCount, errFlags, ovfCount, ovfList, iniTh, minTh, rowsMax, candCap, nStrips, nFrames, inv);
+    else if (fixedPitch == 20)
+        hipLaunchKernelGGL(k_fast_strips_p<20>, grid, dim3(WAVE), orb_fast_p_lds_bytes(20, rowsMax, candCap), st, G, pyr, pyrSlab, strips, pathTab,
+                           cand, candSlab, candCount, errFlags, ovfCount, ovfList, iniTh, minTh, rowsMax, candCap, nStrips, nFrames, inv);
+    else
+    hipLaunchKernelGGL(k_fast_strips, grid, dim3(WAVE),
                        orb_fast_lds_bytes(pdw, rowsMax, candCap), st, G, pyr, pyrSlab, strips, pathTab, cand, candSlab,
                        candCount, errFlags, ovfCount, ovfList, iniTh, minTh, pdw, rowsMax, candCap, nStrips, nFrames, inv);
     const long long all = (long long)nStrips * nFrames;

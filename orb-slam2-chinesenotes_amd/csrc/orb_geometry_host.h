@@ -28,6 +28,7 @@ struct OrbGeomPlan {                        // everything build_geometry derives
     int stripsOfLevel[ORB_MAX_LEVELS];
     size_t pyrSlab = 0, candSlab = 0;
     int nodeCap = 0, maxKp = 0, fastPdw = 4, fastRows = 7, fastSdw = 1;
+    int fastMinNq = 255;                    // fewest zone quads of any strip (k_fast_strips_p wants >= 8)
     std::vector<uint32_t> pathTab;
     std::vector<int2> xt, yt;               // resize tables of all levels, back to back
     std::vector<uint32_t> xq;               // per-4-pixel column entries of k_resize_level4p
@@ -113,13 +114,15 @@ struct FastCellRow {
     std::vector<int> x0, w;     // ROI start / width of the cells that the reference runs cv::FAST on (cj = index)
 };
 
+// maxRowBytes > 0: no strip is staged wider than that (xoff <= 7 + ROI width), so that the fixed-pitch kernel fits
 static int make_strips(const FastCellRow& row, int wCell, int target, std::vector<OrbStrip>& out, int& maxPdw, int& maxRows,
-                       int& maxSdw)
+                       int& maxSdw, int& minNq, int maxRowBytes = 0)
 {
     const int J = (int)row.x0.size();
     if (J == 0) return ORB_OK;
     // columns are addressed with 8 bits inside the tile: xoff (<= 7) + strip ROI width <= 255
     int kMax = std::max(1, std::min(8, (248 - 6) / wCell));
+    if (maxRowBytes > 0) kMax = std::max(1, std::min(kMax, (maxRowBytes - 7 - 6) / wCell));
     const int K = std::max(1, std::min(target, kMax));
     const int nStrips = (J + K - 1) / K;
     for (int s = 0, j0 = 0; s < nStrips; s++) {
@@ -162,6 +165,7 @@ static int make_strips(const FastCellRow& row, int wCell, int target, std::vecto
         maxPdw = std::max(maxPdw, 2 * nx8);
         maxRows = std::max(maxRows, (int)S.h);
         maxSdw = std::max(maxSdw, nh);
+        minNq = std::min(minNq, nq);
         out.push_back(S);
         j0 += nc;
     }
@@ -170,7 +174,7 @@ static int make_strips(const FastCellRow& row, int wCell, int target, std::vecto
 
 // level sizes, FAST strips, quadtree boxes, resize tables, slab layout for a rows x cols input
 static int orb_plan_geometry(const orb_extractor_params& prm, const OrbHostTables& T, const int* stripK, int rows, int cols,
-                             OrbGeomPlan& P)
+                             OrbGeomPlan& P, int maxStripRowBytes = 0)
 {
     const int nl = prm.nlevels;
     OrbGeom& G = P.G;
@@ -185,7 +189,7 @@ static int orb_plan_geometry(const orb_extractor_params& prm, const OrbHostTable
     int kpOff = 0, nodeCap = 0;
     std::vector<uint32_t>& pathTab = P.pathTab;
     pathTab.clear();
-    int maxPdw = 4, maxRows = 7, maxSdw = 1;
+    int maxPdw = 4, maxRows = 7, maxSdw = 1, minNq = 255;
     int* stripsOfLevel = P.stripsOfLevel;
     std::memset(P.stripsOfLevel, 0, sizeof(P.stripsOfLevel));
     for (int l = 0; l < nl; l++) {
@@ -240,7 +244,7 @@ static int orb_plan_geometry(const orb_extractor_params& prm, const OrbHostTable
                     candCap += ((cw - 6 + 1) / 2) * ((row.h - 6 + 1) / 2);   // 3x3 strict NMS bound
                     nCells++;
                 }
-                const int rc = make_strips(row, wCell, stripK[l], strips, maxPdw, maxRows, maxSdw);
+                const int rc = make_strips(row, wCell, stripK[l], strips, maxPdw, maxRows, maxSdw, minNq, maxStripRowBytes);
                 if (rc != ORB_OK) return rc;
             }
         }
@@ -357,5 +361,6 @@ static int orb_plan_geometry(const orb_extractor_params& prm, const OrbHostTable
     P.fastPdw = maxPdw;
     P.fastRows = maxRows;
     P.fastSdw = maxSdw;
+    P.fastMinNq = minNq;
     return ORB_OK;
 }
