@@ -45,6 +45,32 @@ struct OrbGeom {
     OrbLevelGeom L[ORB_MAX_LEVELS];
 };
 
+// ---- pyramid chains (k_pyr_chain, orb_extract_kernels.hip): one launch produces up to ORB_PYR_MAXCHAIN consecutive levels.
+// A workgroup owns a BAND of rows of the chain's last level, stages the rows of the chain's source level that the band
+// draws on in LDS (coalesced 16-byte loads, no dependent address), and resamples level after level out of LDS: every
+// produced level is written to HBM once and never read back inside the chain.  The first chain of a batch reads the
+// caller's image and also writes level 0 (reference src/ORBextractor.cc:1173).
+#define ORB_PYR_MAXCHAIN 3
+struct OrbPyrStep {
+    int dstOff, dstPitch, dstH; // produced level inside one frame's pyramid slab
+    int x4;                     // pixel quads per row
+    unsigned invX4;             // ceil(2^32 / x4), 0 when x4 == 1
+    int xqOff, ytOff;           // the level's column table (uint4 units) and row table (int2 units)
+    int ldsOff, ldsPitchDw;     // where the level's band lives in LDS while it is the source of the next step (bytes, dwords)
+    int rpOff;                  // the step's row parameters in LDS (bytes): uint4 {source row A, source row B (LDS byte offsets), b0 << 16, b1 << 16}
+};
+struct OrbPyrChain {
+    int nSteps, copy0;          // levels produced; 1: the source is the caller's image and level 0 is written as well
+    int srcOff, srcPitch, srcW, srcH;   // source level inside the slab (copy0: where level 0 goes)
+    int srcLdsOff, srcLdsPitchDw;
+    int cpr;                    // 16-byte chunks per source row
+    unsigned invCpr;            // ceil(2^32 / cpr), 0 when cpr == 1
+    int bands, tabOff;          // workgroups per frame; offset (int2 units) of the band table [band][nSteps + 2]:
+                                //   [0] source rows (first, last), [1 + k] rows of step k, [nSteps + 1] level-0 rows to copy
+    int ldsBytes;
+    OrbPyrStep st[ORB_PYR_MAXCHAIN];
+};
+
 // One work item of k_fast_strips: a run of `nc` horizontally adjacent FAST cells of one cell row (reference
 // :826-861: cell (ci, cj) has the ROI [16 + cj*wCell, +wCell+6) x [16 + ci*hCell, +hCell+6), clipped).  The detection
 // zones of adjacent cells (ROI minus cv::FAST's 3-px rim) tile the plane without overlap, so the strip is ONE tile

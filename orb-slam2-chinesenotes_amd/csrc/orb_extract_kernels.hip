@@ -8,6 +8,8 @@
 //   (k_quadtree lives in orb_quadtree.hip)
 //   (k_orient_desc lives in orb_desc.hip)
 // Every kernel takes blockIdx.y (or .z) = frame: batched frames are independent.
+#include <cstdlib>
+
 #include "orb_kernels.h"
 
 #pragma clang fp contract(off)
@@ -281,6 +283,170 @@ __global__ __launch_bounds__(256) void k_resize_pair(uint8_t* __restrict__ pyr, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Chains of levels out of LDS (round 3; OrbPyrChain in orb_common.h).  k_resize_pair above spends its time waiting: table
+// loads -> window loads that depend on them -> compute -> barrier -> ..., a chain of dependent global round trips per
+// workgroup at 2.1 TB/s.  Here the only global loads a band waits for are issued at once from addresses that depend on
+// nothing but the workgroup index: the source rows (coalesced 16-byte chunks), the row tables (turned into LDS byte
+// offsets and pre-shifted coefficients, one uint4 per row) and the first column entries.  Every level is then resampled
+// out of LDS with the same fixed-point arithmetic (resize_px), written to HBM and kept for the next step.  The first
+// chain of a batch stages the caller's image (any alignment, any stride) and writes level 0 on the way, so the separate
+// copy pass and its 0.6 MB of traffic per frame are gone; it also clears the status block and spreads the BRIEF pattern
+// as k_copy_level0 does.
+typedef unsigned int orb_u32x4 __attribute__((ext_vector_type(4)));
+typedef orb_u32x4 __attribute__((aligned(1))) orb_u32x4_a1;
+#define PYR_STAGE_MAX 8            // 16-byte chunks a thread has in flight while staging
+
+template <int RG>
+__global__ __launch_bounds__(256) void k_pyr_chain(const OrbPyrChain C, const uint8_t* __restrict__ img, size_t rowStride,
+                                                   size_t frameStride, uint8_t* __restrict__ pyr, size_t pyrSlab,
+                                                   const uint4* __restrict__ xqAll, const int2* __restrict__ ytAll,
+                                                   const int2* __restrict__ bandTab, int* __restrict__ clr, int clrInts,
+                                                   const char4* __restrict__ pat8, float4* __restrict__ patF)
+{
+    extern __shared__ uint32_t ldsDw[];
+    uint8_t* lds = reinterpret_cast<uint8_t*>(ldsDw);
+    const int tid = threadIdx.x, f = blockIdx.y, b = blockIdx.x;
+    if (clr) {                                                     // first kernel of the batch (see k_copy_level0)
+        const unsigned g = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+        if (g < (unsigned)clrInts) clr[g] = 0;
+        if (g < 256u) {
+            const char4 q = pat8[g];
+            patF[g] = make_float4((float)q.x, (float)q.y, (float)q.z, (float)q.w);
+        }
+    }
+    const int2* bt = bandTab + C.tabOff + b * (C.nSteps + 2);
+    const int2 sr = bt[0];
+    uint8_t* slab = pyr + (size_t)f * pyrSlab;
+
+    // ---- row parameters: wave k fills those of step k (LDS byte offsets of the two source rows, coefficients << 16)
+    {
+        const int k = tid >> 6, t = tid & 63;
+        if (k < C.nSteps) {
+            const int2 mr = bt[1 + k];
+            const int n4 = (mr.y - mr.x + 4) & ~3;
+            if (t < n4) {
+                const int2 ty = ytAll[C.st[k].ytOff + min(mr.x + t, mr.y)];
+                const int srcRow0 = bt[k].x;                       // the step's source band: bt[0] or the band of step k - 1
+                const int pitchB = 4 * (k == 0 ? C.srcLdsPitchDw : C.st[k - 1].ldsPitchDw);
+                const int base = k == 0 ? C.srcLdsOff : C.st[k - 1].ldsOff;
+                uint4 e;
+                e.x = (unsigned)(base + ((ty.x & 0xffff) - srcRow0) * pitchB);
+                e.y = (unsigned)(base + ((int)((unsigned)ty.x >> 16) - srcRow0) * pitchB);
+                e.z = (unsigned)ty.y << 16;
+                e.w = (unsigned)ty.y & 0xffff0000u;
+                *reinterpret_cast<uint4*>(lds + C.st[k].rpOff + 16 * t) = e;
+            }
+        }
+    }
+    // ---- stage the source rows sr.x .. sr.y (and write the level-0 rows this band owns)
+    {
+        const int w = C.srcW, cpr = C.cpr, total = (sr.y - sr.x + 1) * cpr;
+        const uint8_t* src;
+        size_t stride;
+        if (C.copy0) { src = img + (size_t)f * frameStride + (size_t)sr.x * rowStride; stride = rowStride; }
+        else { src = slab + C.srcOff + (size_t)sr.x * C.srcPitch; stride = (size_t)C.srcPitch; }
+        const int2 cp = bt[C.nSteps + 1];
+        const int pitchB = 4 * C.srcLdsPitchDw;
+        uint8_t* dstL = lds + C.srcLdsOff;
+        uint8_t* l0 = slab + C.srcOff + (size_t)sr.x * C.srcPitch;
+        for (int base = 0; base < total; base += 256 * PYR_STAGE_MAX) {
+            orb_u32x4 v[PYR_STAGE_MAX];
+#pragma unroll
+            for (int i = 0; i < PYR_STAGE_MAX; i++) {
+                const int idx = base + i * 256 + tid;
+                if (idx < total) {
+                    const int r = C.invCpr ? (int)__umulhi((unsigned)idx, C.invCpr) : idx, c = idx - r * cpr;
+                    const uint8_t* s = src + (size_t)r * stride + 16 * c;
+                    if (16 * c + 16 <= w) {
+                        v[i] = *reinterpret_cast<const orb_u32x4_a1*>(s);
+                    } else {                                       // last chunk of a row whose width is not a multiple of 16
+                        const int n = w - 16 * c;
+                        unsigned t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+#pragma unroll
+                        for (int j = 0; j < 15; j++)
+                            if (j < n) {
+                                const unsigned by = (unsigned)s[j] << (8 * (j & 3));
+                                if (j < 4) t0 |= by; else if (j < 8) t1 |= by; else if (j < 12) t2 |= by; else t3 |= by;
+                            }
+                        v[i] = orb_u32x4{t0, t1, t2, t3};
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < PYR_STAGE_MAX; i++) {
+                const int idx = base + i * 256 + tid;
+                if (idx < total) {
+                    const int r = C.invCpr ? (int)__umulhi((unsigned)idx, C.invCpr) : idx, c = idx - r * cpr;
+                    *reinterpret_cast<orb_u32x4*>(dstL + r * pitchB + 16 * c) = v[i];
+                    if (C.copy0 && (unsigned)(sr.x + r - cp.x) < (unsigned)(cp.y - cp.x))
+                        *reinterpret_cast<orb_u32x4*>(l0 + (size_t)r * C.srcPitch + 16 * c) = v[i];   // (row padding up to the pitch gets zeros)
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- level after level out of LDS: one item = 4 pixels x RG rows (RG = 4 amortises the column entry best, RG = 1 / 2 leave
+    // fewer threads idle in the last pass over a band: the host picks per chain)
+    for (int k = 0; k < C.nSteps; k++) {
+        const OrbPyrStep& T = C.st[k];
+        const int2 mr = bt[1 + k];
+        const int nM = mr.y - mr.x + 1, gM = (nM + RG - 1) / RG;
+        const uint4* xq = xqAll + T.xqOff;
+        uint8_t* dst = slab + T.dstOff + (size_t)mr.x * T.dstPitch;
+        const bool keep = k + 1 < C.nSteps;
+        const uint8_t* rp = lds + T.rpOff;
+        uint8_t* keepL = lds + T.ldsOff;
+        const unsigned x4n = (unsigned)T.x4, inv = T.invX4, dpitch = (unsigned)T.dstPitch, kpitch = 4u * (unsigned)T.ldsPitchDw;
+        // the column entry of the NEXT item is requested before the current one is computed (an L2 round trip per item
+        // otherwise: the entry's selectors are needed by the item's first instructions)
+        const unsigned nItems = (unsigned)gM * x4n;
+        uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0;
+        uint2 q2 = make_uint2(0, 0);
+        unsigned g = 0, x4 = 0;
+        if ((unsigned)tid < nItems) {
+            g = inv ? __umulhi((unsigned)tid, inv) : (unsigned)tid;
+            x4 = (unsigned)tid - g * x4n;
+            q0 = xq[3 * x4]; q1 = xq[3 * x4 + 1];
+            q2 = *reinterpret_cast<const uint2*>(xq + 3 * x4 + 2);
+        }
+        for (unsigned idx = tid; idx < nItems; idx += 256) {
+            const unsigned idxN = idx + 256;
+            uint4 n0 = q0, n1 = q1;
+            uint2 n2 = q2;
+            unsigned gN = g, x4N = x4;
+            if (idxN < nItems) {
+                gN = inv ? __umulhi(idxN, inv) : idxN;
+                x4N = idxN - gN * x4n;
+                n0 = xq[3 * x4N]; n1 = xq[3 * x4N + 1];
+                n2 = *reinterpret_cast<const uint2*>(xq + 3 * x4N + 2);
+            }
+            uint4 e[RG];
+#pragma unroll
+            for (int r = 0; r < RG; r++) e[r] = *reinterpret_cast<const uint4*>(rp + 16 * (g * RG + r));
+#pragma unroll
+            for (int r = 0; r < RG; r++) {
+                const unsigned lr = g * RG + r;
+                const uint32_t* a0 = reinterpret_cast<const uint32_t*>(lds + e[r].x + q0.x);
+                const uint32_t* a1 = reinterpret_cast<const uint32_t*>(lds + e[r].x + q0.y);
+                const uint32_t* b0 = reinterpret_cast<const uint32_t*>(lds + e[r].y + q0.x);
+                const uint32_t* b1 = reinterpret_cast<const uint32_t*>(lds + e[r].y + q0.y);
+                const uint2 wA0 = make_uint2(a0[0], a0[1]), wA1 = make_uint2(a1[0], a1[1]);
+                const uint2 wB0 = make_uint2(b0[0], b0[1]), wB1 = make_uint2(b1[0], b1[1]);
+                const unsigned out = resize_px(wA0, wB0, q0.z, q1.z, e[r].z, e[r].w) | (resize_px(wA0, wB0, q0.w, q1.w, e[r].z, e[r].w) << 8) |
+                                     (resize_px(wA1, wB1, q1.x, q2.x, e[r].z, e[r].w) << 16) | (resize_px(wA1, wB1, q1.y, q2.y, e[r].z, e[r].w) << 24);
+                if (lr < (unsigned)nM) {
+                    *reinterpret_cast<uint32_t*>(dst + (lr * dpitch + x4 * 4)) = out;
+                    if (keep) *reinterpret_cast<uint32_t*>(keepL + (lr * kpitch + x4 * 4)) = out;
+                }
+            }
+            q0 = n0; q1 = n1; q2 = n2; g = gN; x4 = x4N;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // launch wrappers (keep <<<>>> syntax inside this translation unit)
 // exact division of idx < 2^31 by d via multiply-high: q = (idx * ceil(2^32/d)) >> 32 is exact while idx*d < 2^32
 // d == 1 has no 32-bit inverse: 0 tells the kernels that a row holds a single item (index == row)
@@ -321,6 +487,21 @@ void orb_launch_resize(hipStream_t st, uint8_t* pyr, size_t pyrSlab, const OrbLe
     else
         hipLaunchKernelGGL(k_resize_level, grid, dim3(64, 4), 0, st, pyr, pyrSlab, src.pyrOff, src.pitch,
                            dst.pyrOff, dst.pitch, dst.w, dst.h, xtab, ytab);
+}
+
+void orb_launch_pyr_chain(hipStream_t st, const OrbPyrChain& C, const uint8_t* img, size_t rowStride, size_t frameStride,
+                          uint8_t* pyr, size_t pyrSlab, const uint4* xqAll, const int2* ytAll, const int2* bandTab, int nFrames,
+                          int* clr, int clrInts, const int8_t* pat8, float* patF)
+{
+    static const int rg = std::getenv("ORB_PYR_RG") ? std::atoi(std::getenv("ORB_PYR_RG")) : 4;
+    auto go = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3(C.bands, nFrames), dim3(256), (size_t)C.ldsBytes, st, C, img, rowStride, frameStride, pyr,
+                           pyrSlab, xqAll, ytAll, bandTab, clr, clrInts, reinterpret_cast<const char4*>(pat8),
+                           reinterpret_cast<float4*>(patF));
+    };
+    if (rg == 1) go(k_pyr_chain<1>);
+    else if (rg == 2) go(k_pyr_chain<2>);
+    else go(k_pyr_chain<4>);
 }
 
 // Levels M and M+1 in one launch (k_resize_pair); returns false when the pair is not eligible (the caller then

@@ -85,6 +85,13 @@ static int build_geometry(orb_extractor* h, int rows, int cols)
             ORB_HIP_TRY(hipMemcpyAsync(h->dXq.p, xq.data(), xq.size() * 4, hipMemcpyHostToDevice, h->stream));
         }
     }
+    if (!P.bandTab.empty() && !std::getenv("ORB_PYR_LEGACY")) {
+        if ((rc = h->dBand.ensure(P.bandTab.size() * sizeof(int2))) != ORB_OK) return rc;
+        ORB_HIP_TRY(hipMemcpyAsync(h->dBand.p, P.bandTab.data(), P.bandTab.size() * sizeof(int2), hipMemcpyHostToDevice, h->stream));
+        h->pyrChains = P.chains;
+    } else {
+        h->pyrChains.clear();
+    }
     ORB_HIP_TRY(hipStreamSynchronize(h->stream));     // host vectors go out of scope
     // commit
     h->G = G;
@@ -215,7 +222,7 @@ extern "C" void orb_extractor_destroy(orb_extractor* h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    DevBuf* bufs[] = {&h->dPattern, &h->dPatternF, &h->dAngTab, &h->dCells, &h->dXtab, &h->dYtab, &h->dXq, &h->dPath, &h->dPyr, &h->dCand, &h->dKpl, &h->dOvf,
+    DevBuf* bufs[] = {&h->dPattern, &h->dPatternF, &h->dAngTab, &h->dCells, &h->dXtab, &h->dYtab, &h->dXq, &h->dPath, &h->dBand, &h->dPyr, &h->dCand, &h->dKpl, &h->dOvf,
                       &h->dStat, &h->dImgs, &h->dKps, &h->dDesc, &h->dCounts,
                       &h->dStereo, &h->dStereoIn};
     for (DevBuf* b : bufs) b->release();
@@ -395,6 +402,12 @@ extern "C" int orb_extract_batch_device(orb_extractor* h, const uint8_t* d_imgs,
     if (prof) ORB_HIP_TRY(hipEventRecord(pe[0], st));
     // (also clears the status block behind the sticky word -- error flags, counters, overflow list head -- and spreads the
     // int8 BRIEF pattern into the float table the descriptor kernel reads)
+    if (!h->pyrChains.empty()) {
+        for (size_t c = 0; c < h->pyrChains.size(); c++)
+            orb_launch_pyr_chain(st, h->pyrChains[c], d_imgs, rowStride, frameStride, pyr, h->pyrSlab, (const uint4*)h->dXq.p,
+                                 (const int2*)h->dYtab.p, (const int2*)h->dBand.p, n, c == 0 ? h->errP() : nullptr,
+                                 (int)orb_extractor::batchInts(n), h->patternPtr, (float*)h->dPatternF.p);
+    } else {
     orb_launch_copy_level0(st, d_imgs, rowStride, frameStride, pyr, h->pyrSlab, G.L[0].w, G.L[0].h, G.L[0].pitch, n, h->errP(),
                            (int)orb_extractor::batchInts(n), h->patternPtr, (float*)h->dPatternF.p);
     {
@@ -411,6 +424,7 @@ extern "C" int orb_extract_batch_device(orb_extractor* h, const uint8_t* d_imgs,
                               xq_of(l), n);
             l++;
         }
+    }
     }
     if (prof) ORB_HIP_TRY(hipEventRecord(pe[1], st));
     orb_launch_fast_strips(st, G, pyr, h->pyrSlab, (const OrbStrip*)h->dCells.p, (int)h->strips.size(),

@@ -70,7 +70,8 @@ struct orb_extractor {
     bool hostCall = false;                  // inside orb_extract_batch: status travels with the results, no feedback copy
 
     // device memory
-    DevBuf dPattern, dPatternF, dAngTab, dCells, dXtab, dYtab, dXq, dPath;   // constants
+    DevBuf dPattern, dPatternF, dAngTab, dCells, dXtab, dYtab, dXq, dPath, dBand;   // constants
+    std::vector<OrbPyrChain> pyrChains;         // empty: per-level pyramid kernels (k_copy_level0, k_resize_*)
     std::vector<size_t> xtabOff, ytabOff;       // per level offsets (in int2 units)
     std::vector<long long> xqOff;               // per level offset into dXq (uint4 units), -1 = level not eligible
     DevBuf dPyr, dCand, dKpl, dOvf;             // per-batch scratch (dOvf: FAST strips to redo densely)

@@ -34,6 +34,9 @@ struct OrbGeomPlan {                        // everything build_geometry derives
     std::vector<uint32_t> xq;               // per-4-pixel column entries of k_resize_level4p
     std::vector<size_t> xtabOff, ytabOff;
     std::vector<long long> xqOff;
+    // pyramid chains (k_pyr_chain): empty when some level is not eligible -- the per-level kernels are used then
+    std::vector<OrbPyrChain> chains;
+    std::vector<int2> bandTab;
 };
 
 static inline int cv_round_f(float v) { return (int)lrintf(v); }      // round-half-even
@@ -170,6 +173,100 @@ static int make_strips(const FastCellRow& row, int wCell, int target, std::vecto
         j0 += nc;
     }
     return ORB_OK;
+}
+
+// ---- pyramid chains.  Levels [first, first + nSteps) in one launch, bands of `bandRows` rows of the last one.  Walks the
+// row tables back from every band of the last level to the rows of each earlier level (and of the source) that the band
+// needs, and widens the ranges where the bands would otherwise leave a row of an intermediate level (or of level 0, for
+// the copying chain) unwritten.  Returns false when the chain is not eligible (no column table, a band too large for LDS).
+static bool plan_pyr_chain(const OrbGeom& G, const std::vector<int2>& yt, const std::vector<size_t>& ytabOff,
+                           const std::vector<long long>& xqOff, int first, int nSteps, bool copy0, int bandRows,
+                           size_t ldsLimit, OrbPyrChain& C, std::vector<int2>& tab)
+{
+    std::memset(&C, 0, sizeof(C));
+    if (first < 1 || nSteps < 1 || nSteps > ORB_PYR_MAXCHAIN || first + nSteps > G.nlevels) return false;
+    const OrbLevelGeom& S = G.L[first - 1];
+    for (int k = 0; k < nSteps; k++) {
+        const OrbLevelGeom& D = G.L[first + k];
+        if (xqOff[first + k] < 0) return false;
+        const int x4 = (D.w + 3) / 4;
+        if ((long long)x4 * x4 * 64 >= (1ll << 32)) return false;     // multiply-high decode of (row group, quad)
+        if (D.pitch >= (1 << 20) || D.h >= (1 << 15) || G.L[first + k - 1].h >= (1 << 15)) return false;
+    }
+    if (copy0 && first != 1) return false;
+    const OrbLevelGeom& Last = G.L[first + nSteps - 1];
+    const int bands = (Last.h + bandRows - 1) / bandRows;
+    const int ent = nSteps + 2;
+    const size_t tab0 = tab.size();
+    tab.resize(tab0 + (size_t)bands * ent);
+    std::vector<int> maxRows(nSteps + 1, 0);                         // [0] source, [1 + k] step k
+    for (int b = 0; b < bands; b++) {
+        int2* e = &tab[tab0 + (size_t)b * ent];
+        const int2* prev = b ? &tab[tab0 + (size_t)(b - 1) * ent] : nullptr;
+        int lo = b * bandRows, hi = std::min(lo + bandRows, Last.h) - 1;
+        for (int k = nSteps - 1; k >= 0; k--) {
+            const OrbLevelGeom& D = G.L[first + k];
+            if (k < nSteps - 1) {                                    // an intermediate level is an output: no row may be left out
+                if (b == 0) lo = 0;
+                else if (lo > prev[1 + k].y + 1) lo = prev[1 + k].y + 1;
+                if (b == bands - 1) hi = D.h - 1;
+            }
+            e[1 + k] = make_int2(lo, hi);
+            maxRows[1 + k] = std::max(maxRows[1 + k], hi - lo + 1);
+            const int2* t = &yt[ytabOff[first + k]];
+            const int srcH = G.L[first + k - 1].h;
+            const int nlo = t[lo].x & 0xffff, nhi = std::min((int)((unsigned)t[hi].x >> 16), srcH - 1);
+            lo = nlo; hi = nhi;
+        }
+        if (copy0) {                                                 // level 0 is written by the bands that stage it
+            if (b == 0) lo = 0;
+            else if (lo > prev[0].y + 1) lo = prev[0].y + 1;
+            if (b == bands - 1) hi = S.h - 1;
+        }
+        e[0] = make_int2(lo, hi);
+        maxRows[0] = std::max(maxRows[0], hi - lo + 1);
+    }
+    for (int b = 0; b < bands; b++) {                                // level-0 rows a band copies: from its first staged row up to the next band's
+        int2* e = &tab[tab0 + (size_t)b * ent];
+        e[nSteps + 1] = make_int2(b == 0 ? 0 : e[0].x, b == bands - 1 ? S.h : e[ent].x);
+    }
+    // LDS: [row parameters of every step | region R0 | region R1]; source and step 1 live in R0, step 0 in R1
+    C.nSteps = nSteps; C.copy0 = copy0 ? 1 : 0;
+    C.srcOff = S.pyrOff; C.srcPitch = S.pitch; C.srcW = S.w; C.srcH = S.h;
+    C.bands = bands; C.tabOff = (int)tab0;
+    size_t off = 0;
+    for (int k = 0; k < nSteps; k++) {
+        C.st[k].rpOff = (int)off;
+        off += (size_t)16 * (maxRows[1 + k] + 3);                    // uint4 per row (+ the clamped rows of the last group)
+    }
+    const size_t rowParamBytes = off;
+    C.srcLdsPitchDw = align_up((S.w + 3) / 4 + 2, 4);
+    C.cpr = (S.w + 15) / 16;
+    C.invCpr = C.cpr <= 1 ? 0u : (unsigned)(((1ull << 32) + C.cpr - 1) / C.cpr);
+    for (int k = 0; k <= nSteps; k++)
+        if (maxRows[k] + 3 > 64 || (long long)maxRows[0] * C.cpr * C.cpr >= (1ll << 32)) { tab.resize(tab0); return false; }   // one wave fills a step's row parameters
+    size_t r0 = (size_t)4 * C.srcLdsPitchDw * maxRows[0], r1 = 0;
+    for (int k = 0; k + 1 < nSteps; k++) {
+        OrbPyrStep& T = C.st[k];
+        T.ldsPitchDw = (G.L[first + k].w + 3) / 4 + 2;
+        const size_t bytes = (size_t)4 * T.ldsPitchDw * maxRows[1 + k];
+        if (k & 1) r0 = std::max(r0, bytes); else r1 = std::max(r1, bytes);
+    }
+    r0 = (r0 + 15) & ~(size_t)15; r1 = (r1 + 15) & ~(size_t)15;
+    C.srcLdsOff = (int)rowParamBytes;
+    for (int k = 0; k < nSteps; k++) {
+        const OrbLevelGeom& D = G.L[first + k];
+        OrbPyrStep& T = C.st[k];
+        T.dstOff = D.pyrOff; T.dstPitch = D.pitch; T.dstH = D.h;
+        T.x4 = (D.w + 3) / 4;
+        T.invX4 = T.x4 <= 1 ? 0u : (unsigned)(((1ull << 32) + T.x4 - 1) / T.x4);
+        T.xqOff = (int)xqOff[first + k];
+        T.ytOff = (int)ytabOff[first + k];
+        T.ldsOff = (int)(rowParamBytes + ((k & 1) ? 0 : r0));
+    }
+    C.ldsBytes = (int)(rowParamBytes + r0 + r1);
+    if ((size_t)C.ldsBytes > ldsLimit) { tab.resize(tab0); return false; }
+    return true;
 }
 
 // level sizes, FAST strips, quadtree boxes, resize tables, slab layout for a rows x cols input
@@ -352,6 +449,28 @@ static int orb_plan_geometry(const orb_extractor_params& prm, const OrbHostTable
     if (strips.size() > 65535) {                                       // the FAST overflow list packs (frame << 16 | strip)
         orb_set_error("%zu FAST strips per frame: more than the 65535 the overflow list can address", strips.size());
         return ORB_ERR_UNSUPPORTED;
+    }
+    // pyramid chains: (1, 2) with the level-0 copy, then pairs, the last three levels together when an odd one remains
+    P.chains.clear();
+    P.bandTab.clear();
+    if (nl >= 2) {
+        bool ok = true;
+        for (int l = 1; l < nl && ok;) {
+            int n = std::min(2, nl - l);
+            if (nl - (l + n) == 1) n = (l == 1) ? n : 3;          // never leave a single level for a launch of its own ...
+            if (l + n > nl) n = nl - l;
+            OrbPyrChain C;
+            bool done = false;
+            for (int tryN = n; tryN >= 1 && !done; tryN--)
+                for (int br = 16; br >= 8 && !done; br >>= 1)
+                    if (plan_pyr_chain(G, yt, P.ytabOff, P.xqOff, l, tryN, l == 1, br, (size_t)40 * 1024, C, P.bandTab)) {
+                        P.chains.push_back(C);
+                        l += tryN;
+                        done = true;
+                    }
+            ok = done;
+        }
+        if (!ok) { P.chains.clear(); P.bandTab.clear(); }
     }
     P.nCells = nCells;
     P.pyrSlab = (size_t)align_up((int)pyrOff, 256);

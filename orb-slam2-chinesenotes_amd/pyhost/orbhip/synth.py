@@ -50,6 +50,83 @@ def synth_frame(index: int, width: int = 640, height: int = 480,
     return np.clip(img, 0, 255).astype(np.uint8)
 
 
+def _value_noise(seed: int, stream: int, width: int, height: int, cell: int) -> np.ndarray:
+    """Bilinear interpolation (integer, 8 fractional bits of weight) of a seeded random lattice with `cell`-pixel
+    spacing: values 0..255 << 8."""
+    gw, gh = width // cell + 2, height // cell + 2
+    lat = (splitmix64(seed, stream, gw * gh) % np.uint64(256)).astype(np.int64).reshape(gh, gw)
+    ys, xs = np.arange(height, dtype=np.int64), np.arange(width, dtype=np.int64)
+    y0, x0 = ys // cell, xs // cell
+    fy = ((ys - y0 * cell) * 256) // cell
+    fx = ((xs - x0 * cell) * 256) // cell
+    a = lat[y0][:, x0]; b = lat[y0][:, x0 + 1]; c = lat[y0 + 1][:, x0]; d = lat[y0 + 1][:, x0 + 1]
+    top = a * (256 - fx) + b * fx
+    bot = c * (256 - fx) + d * fx
+    return (top * (256 - fy)[:, None] + bot * fy[:, None]) >> 8          # 0 .. 255 << 8
+
+
+def synth_natural(index: int, width: int = 640, height: int = 480) -> np.ndarray:
+    """Stand-in for camera frames (TUM / KITTI / EuRoC are absent): image statistics instead of drawn shapes.  Integer
+    arithmetic only, so the bytes do not depend on the FFT / libm of the machine:
+      * 1/f-like texture: value-noise octaves of cell size 2..128 px whose amplitude grows with the cell size
+        (amplitude ~ cell^0.75: a power spectrum close to 1/f^2.5, between clouds and man-made scenes);
+      * 60 occluding objects (rectangles and ellipses) that shift the local brightness by -50..50 and carry the texture
+        on: step edges and corners of moderate contrast, T-junctions where they overlap;
+      * two passes of a 3x3 binomial blur (lens / demosaicing), a linear illumination ramp of up to +-30 grey levels
+        across the frame, uniform sensor noise in [-2, 2]; clamped to u8."""
+    seed = SEED0 + 0x4E415400 + index                                 # 'NAT'
+    acc = np.zeros((height, width), np.int64)
+    stream = 0
+    wsum = 0
+    for o, cell in enumerate((2, 4, 8, 16, 32, 64, 128)):
+        wgt = (3, 5, 8, 14, 23, 39, 66)[o]                            # ~ cell^0.75
+        acc += wgt * (_value_noise(seed, stream, width, height, cell) - (128 << 8))
+        stream += (width // cell + 2) * (height // cell + 2)
+        wsum += wgt
+    img = 120 + (acc * 7) // (4 * (wsum << 8))                        # texture contrast: a standard deviation of about 40 grey levels
+    r = splitmix64(seed, 1 << 24, 60 * 6)
+    p = 0
+    yy, xx = np.mgrid[0:height, 0:width]
+    for k in range(60):
+        cx = int(r[p] % np.uint64(width)); cy = int(r[p + 1] % np.uint64(height))
+        hw = 6 + int(r[p + 2] % np.uint64(90)); hh = 6 + int(r[p + 3] % np.uint64(90))
+        dv = int(r[p + 4] % np.uint64(101)) - 50; kind = int(r[p + 5] % np.uint64(2)); p += 6
+        ya, yb, xa, xb = max(0, cy - hh), min(height, cy + hh + 1), max(0, cx - hw), min(width, cx + hw + 1)
+        if kind == 0:
+            img[ya:yb, xa:xb] += dv
+        else:
+            m = ((xx[ya:yb, xa:xb] - cx) * hh) ** 2 + ((yy[ya:yb, xa:xb] - cy) * hw) ** 2 <= (hw * hh) ** 2
+            img[ya:yb, xa:xb][m] += dv
+    for _ in range(2):                                                 # 3x3 binomial, edges replicated
+        q = np.pad(img, 1, mode="edge")
+        h = q[:, :-2] + 2 * q[:, 1:-1] + q[:, 2:]
+        img = (h[:-2] + 2 * h[1:-1] + h[2:] + 8) >> 4
+    g = splitmix64(seed, 1 << 25, 2)
+    gx = int(g[0] % np.uint64(61)) - 30; gy = int(g[1] % np.uint64(61)) - 30
+    img = img + (gx * (2 * xx - width)) // (2 * width) + (gy * (2 * yy - height)) // (2 * height)
+    nz = splitmix64(seed, 1 << 26, width * height) % np.uint64(5)
+    img = img + nz.astype(np.int64).reshape(height, width) - 2
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def synth_natural_batch(first: int, count: int, width: int = 640, height: int = 480) -> np.ndarray:
+    return np.stack([synth_natural(first + i, width, height) for i in range(count)])
+
+
+def synth_natural_stereo_right(left_index: int, width: int = 1241, height: int = 376) -> np.ndarray:
+    """Right view of a natural-statistics pair: the left frame shifted left by d(y) = 12 + 8 * floor(y / 94) px with fresh
+    sensor noise (the same disparity layout as synth_stereo_right)."""
+    base = synth_natural(left_index, width, height).astype(np.int16)
+    out = np.empty_like(base)
+    for y in range(height):
+        d = 12 + 8 * (y // 94)
+        out[y, : width - d] = base[y, d:]
+        out[y, width - d:] = base[y, width - 1]
+    nz = splitmix64(SEED0 + 0x4E415400 + left_index + 0x10000, 0, width * height) % np.uint64(5)
+    out += nz.astype(np.int16).reshape(height, width) - 2
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
 def synth_batch(first: int, count: int, width: int = 640, height: int = 480) -> np.ndarray:
     return np.stack([synth_frame(first + i, width, height) for i in range(count)])
 

@@ -74,6 +74,69 @@ static int one(const orb_extractor_params& prm, int rows, int cols, const int* s
         }
     }
     CHECK(strip == P.strips.size());
+    // pyramid chains (k_pyr_chain): the chains produce levels 1 .. nl-1 in order; inside a chain every band's row ranges stay
+    // inside their levels and inside the LDS regions planned for them, the rows a step reads are rows its source band holds,
+    // the bands of every produced level (and the level-0 copy partitions) cover the level without a gap
+    if (!P.chains.empty()) {
+        int next = 1;
+        for (const OrbPyrChain& C : P.chains) {
+            CHECK(C.nSteps >= 1 && C.nSteps <= ORB_PYR_MAXCHAIN && next + C.nSteps <= prm.nlevels);
+            const int first = next, ent = C.nSteps + 2;
+            CHECK(C.copy0 == (first == 1 ? 1 : 0));
+            CHECK(C.srcOff == G.L[first - 1].pyrOff && C.srcW == G.L[first - 1].w && C.srcH == G.L[first - 1].h);
+            CHECK((size_t)C.tabOff + (size_t)C.bands * ent <= P.bandTab.size() && C.ldsBytes <= 40 * 1024);
+            CHECK(C.cpr == (C.srcW + 15) / 16 && 16 * C.cpr <= 4 * C.srcLdsPitchDw && (C.srcLdsPitchDw % 4) == 0);
+            std::vector<int> covered(C.nSteps + 2, 0);                 // next uncovered row of [source copy, steps...]
+            for (int b = 0; b < C.bands; b++) {
+                const int2* e = &P.bandTab[C.tabOff + (size_t)b * ent];
+                CHECK(e[0].x >= 0 && e[0].x <= e[0].y && e[0].y < C.srcH);
+                size_t srcBytes = (size_t)4 * C.srcLdsPitchDw * (e[0].y - e[0].x + 1);
+                size_t srcOff = C.srcLdsOff;
+                int srcRow0 = e[0].x, srcRow1 = e[0].y;
+                for (int k = 0; k < C.nSteps; k++) {
+                    const OrbPyrStep& T = C.st[k];
+                    const OrbLevelGeom& D = G.L[first + k];
+                    CHECK(T.dstOff == D.pyrOff && T.dstPitch == D.pitch && T.dstH == D.h && T.x4 == (D.w + 3) / 4);
+                    CHECK(e[1 + k].x >= 0 && e[1 + k].x <= e[1 + k].y && e[1 + k].y < D.h);
+                    CHECK(e[1 + k].y - e[1 + k].x + 1 + 3 <= 64);
+                    CHECK((size_t)T.rpOff + 16 * (size_t)((e[1 + k].y - e[1 + k].x + 4) & ~3) <= (size_t)C.srcLdsOff);
+                    CHECK(srcOff + srcBytes <= (size_t)C.ldsBytes);
+                    for (int y = e[1 + k].x; y <= e[1 + k].y; y++) {       // rows read lie inside the source band
+                        const int2 t = P.yt[P.ytabOff[first + k] + y];
+                        CHECK((t.x & 0xffff) >= srcRow0 && (int)((unsigned)t.x >> 16) <= srcRow1);
+                    }
+                    // the 8-byte windows of the last pixel quad stay inside the source row's LDS pitch
+                    const int srcPitchDw = k == 0 ? C.srcLdsPitchDw : C.st[k - 1].ldsPitchDw;
+                    for (int q = 0; q < T.x4; q++) {
+                        const uint32_t* xe = &P.xq[(size_t)T.xqOff * 4 + (size_t)q * 12];
+                        CHECK(xe[0] / 4 + 1 < (unsigned)srcPitchDw && xe[1] / 4 + 1 < (unsigned)srcPitchDw);
+                    }
+                    if (b == 0) CHECK(e[1 + k].x == 0);
+                    else CHECK(e[1 + k].x <= covered[1 + k]);
+                    covered[1 + k] = std::max(covered[1 + k], e[1 + k].y + 1);
+                    if (k + 1 < C.nSteps) {
+                        CHECK(T.ldsPitchDw >= T.x4 + 2);
+                        srcOff = T.ldsOff; srcBytes = (size_t)4 * T.ldsPitchDw * (e[1 + k].y - e[1 + k].x + 1);
+                        CHECK((size_t)T.ldsOff >= (size_t)C.srcLdsOff);
+                        // ping-pong: the band kept by step k does not overlap the band step k reads
+                        const size_t rdOff = k == 0 ? (size_t)C.srcLdsOff : (size_t)C.st[k - 1].ldsOff;
+                        const size_t rdBytes = (size_t)4 * srcPitchDw * (srcRow1 - srcRow0 + 1);
+                        CHECK(srcOff + srcBytes <= rdOff || rdOff + rdBytes <= srcOff);
+                    }
+                    srcRow0 = e[1 + k].x; srcRow1 = e[1 + k].y;
+                }
+                if (C.copy0) {
+                    const int2 cp = e[C.nSteps + 1];
+                    CHECK(cp.x == covered[0] && cp.x >= e[0].x && cp.y <= e[0].y + 1 && cp.x <= cp.y);
+                    covered[0] = cp.y;
+                }
+            }
+            for (int k = 0; k < C.nSteps; k++) CHECK(covered[1 + k] == G.L[first + k].h);
+            if (C.copy0) CHECK(covered[0] == C.srcH);
+            next += C.nSteps;
+        }
+        CHECK(next == prm.nlevels);
+    }
     return 0;
 }
 

@@ -27,7 +27,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 N_SIMD, N_XCD = 1024, 8
 # load width (bytes per lane) of each kernel's dominant global reads -> which calibration factor applies
-LOAD_WIDTH = {"k_copy_level0": 16, "k_fast_strips": 16, "k_resize_pair": 8, "k_resize_level4p": 8, "k_orient_desc": "rows48_dword",
+LOAD_WIDTH = {"k_copy_level0": 16, "k_fast_strips": 16, "k_fast_strips_p": 16, "k_pyr_chain": 16, "k_resize_pair": 8, "k_resize_level4p": 8, "k_orient_desc": "rows48_dword",
               "k_quadtree": 8, "k_match_bow": 16, "k_bow_assign": 16, "k_vocab_transform": 16, "k_fill_sides": 4}
 
 
@@ -38,10 +38,10 @@ def kname(n):
 
 def first_batch_dispatch(d):
     """bench.py first extracts a handful of frames to train its vocabulary; the benchmark's own launches start with the
-    first k_copy_level0 of the full batch size.  Dispatches before that one are left out of every average."""
+    first k_copy_level0 / k_pyr_chain (the first kernel of a batch) of the full batch size.  Dispatches before that one are left out of every average."""
     rows = []
     for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
-        rows += [r for r in csv.DictReader(open(f)) if kname(r["Kernel_Name"]) == "k_copy_level0"]
+        rows += [r for r in csv.DictReader(open(f)) if kname(r["Kernel_Name"]) in ("k_copy_level0", "k_pyr_chain")]
     if not rows:
         return 0
     size = lambda r: int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
