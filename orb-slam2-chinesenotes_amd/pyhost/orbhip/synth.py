@@ -196,18 +196,24 @@ def synth_vocab_tree(k: int = 10, L: int = 3, seed: int = 0xB0CAB, prune: float 
     return dict(node_desc=node_desc, child_begin=child_begin, children=children, word_id=word_id, L=L, k=k)
 
 
-def synth_sequence(first: int, count: int, width: int = 640, height: int = 480, views: int = 8, noise: int = 6) -> np.ndarray:
+def synth_sequence(first: int, count: int, width: int = 640, height: int = 480, views: int = 8, noise: int = 6,
+                   content: str = "shapes") -> np.ndarray:
     """Frames that look like a slowly moving camera: frame i is view v = i % views of scene g = i // views, i.e. the
     noise-free synth_frame(views * g) rolled by (v, 2v) pixels (rows, columns) with fresh noise.  Consecutive frames of
     a scene share almost all corners, so SearchByBoW between frame i and i+1 finds hundreds of matches (unrelated
-    scenes give about 7) -- the accept / greedy-taken / rotation-histogram path of the matcher is exercised."""
+    scenes give about 7) -- the accept / greedy-taken / rotation-histogram path of the matcher is exercised.
+    content = "natural": the scenes are synth_natural frames (which carry their own sensor noise) and a view adds fresh
+    uniform noise in [-2, 2] only."""
+    if content == "natural":
+        noise = min(noise, 2)
     out = np.empty((count, height, width), np.uint8)
     base, base_g = None, -1
     for k in range(count):
         i = first + k
         g, v = divmod(i, views)
         if g != base_g:
-            base, base_g = synth_frame(views * g, width, height, noise=0).astype(np.int16), g
+            base = synth_natural(views * g, width, height) if content == "natural" else synth_frame(views * g, width, height, noise=0)
+            base, base_g = base.astype(np.int16), g
         img = np.roll(base, (v, 2 * v), axis=(0, 1))
         if noise > 0:
             nz = splitmix64(SEED0 + 0x20000 + i, 0, width * height) % np.uint64(2 * noise + 1)

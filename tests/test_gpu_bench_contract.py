@@ -34,9 +34,12 @@ def test_single_gpu_line_has_every_contract_field():
     # traffic is measured live (two rocprofv3 --pmc child runs).  At 32 frames the pyramids stay in the XCDs' L2s, so the
     # memory-side bytes are far below the algorithmic ones; at 512 frames they are the 0.94 MB/frame the kernel must read
     assert rf["traffic"] is not None and rf["traffic"] > 0 and "measured in this run" in rf["traffic_source"]
-    if "roofline_valu" in d:
-        rv = d["roofline_valu"]
-        assert rv["bound"] == "valu_issue" and abs(rv["frac"] - rv["achieved"] / rv["peak"]) < 1e-3
+    rv = d["roofline_valu"]                      # vector-instruction counters: measured live as well, not read from a file
+    assert rv["bound"] == "valu_issue" and abs(rv["frac"] - rv["achieved"] / rv["peak"]) < 1e-3
+    assert "measured in this run" in rv["source"] and rv["valu_insts_per_wave"] > 100 and 0 < rv["lds_conflict_frac"] < 1
+    assert d["config"]["prepared"].startswith("3 synchronised steps on every lane")
+    cs = d["config"]["content_stats"]
+    assert len(cs["fast_candidates_per_level"]) == 8 and 0 < cs["phase_a_surviving_pair_rate"] < 1
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["gpu_matches_oracle_on_sample"] is True
 
@@ -65,11 +68,25 @@ def test_two_ranks_gloo_rehearsal_on_one_gpu():
     d = _two_ranks([])
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
     assert d["config"]["frames_per_gpu"] == 16
+    o = d["config"]["other_scaling"]            # one N>1 run reports the strong figure of BASELINE configs[3] next to the weak one
+    assert o["scaling"] == "strong" and o["frames_per_gpu"] == 8 and o["frames_per_step_all_gpus"] == 16 and o["value"] > 0
+
+
+def test_natural_content_line():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--frames-per-gpu", "32",
+                        "--cpu-frames", "4", "--no-cpu-all-cores", "--content", "natural", "--no-live-traffic", "--no-host-path"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    assert "natural image statistics" in d["config"]["content"] and d["value"] > 0
+    assert d["cpu_baseline"]["gpu_matches_oracle_on_sample"] is True
+    assert d["config"]["mean_keypoints"] > 900 and d["config"]["mean_bow_matches"] > 30
 
 
 def test_two_ranks_strong_scaling_splits_one_batch():
     d = _two_ranks(["--scaling", "strong"])                     # BASELINE configs[3] as written: ONE batch over the GPUs
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["frames_per_gpu"] == 8
+    assert d["config"]["other_scaling"]["scaling"] == "weak" and d["config"]["other_scaling"]["frames_per_gpu"] == 16
 
 
 def test_gpus_flag_alone_starts_the_ranks_and_a_mismatch_is_refused():

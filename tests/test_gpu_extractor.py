@@ -54,6 +54,42 @@ def test_euroc_size_752x480():
     _cmp(synth.synth_frame(200, 752, 480))
 
 
+@pytest.mark.parametrize("w,h,nf,idx", [(640, 480, 1000, 0), (640, 480, 1000, 5), (752, 480, 1000, 1), (1241, 376, 2000, 2),
+                                         (1241, 376, 2000, 9), (333, 257, 300, 3)])
+def test_natural_statistics_content(w, h, nf, idx):
+    """every other input is drawn shapes + noise.  Frames with natural image statistics (1/f texture, occluding
+    objects, blur, illumination ramp, weak sensor noise: synth.synth_natural) at the sizes BASELINE's datasets have, stage by
+    stage and end to end against the oracle."""
+    n = _cmp(synth.synth_natural(idx, w, h), nfeatures=nf)
+    assert n > 0.8 * nf
+
+
+def test_natural_statistics_batch_and_strip_feedback():
+    """A device batch of 64 natural frames: per-frame results equal the oracle's, and after a few synchronised batches no FAST
+    strip overflows its candidate queue any more (the self-tuning strip lengths settle on this content too)."""
+    import torch
+    B, W, H = 64, 640, 480
+    imgs = synth.synth_sequence(8000, B, W, H, content="natural")
+    ex, ref = capi.Extractor(), oracle.Extractor()
+    cap = ex.max_keypoints
+    d_img = torch.from_numpy(imgs).cuda()
+    d_kps = torch.zeros((B, cap, 28), dtype=torch.uint8, device="cuda")
+    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+    d_cnt = torch.zeros(B, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(4):
+        ex.extract_batch_device(d_img.data_ptr(), B, H, W, W, W * H, d_kps.data_ptr(), d_desc.data_ptr(), cap, d_cnt.data_ptr())
+        ex.sync()
+    assert int(ex.fast_overflows()[0].sum()) == 0
+    cnt = d_cnt.cpu().numpy()
+    for f in (0, 1, 17, 63):
+        rk, rd = ref.extract(imgs[f])
+        assert cnt[f] == len(rk)
+        assert d_kps[f, :cnt[f]].cpu().numpy().tobytes() == rk.tobytes()
+        assert np.array_equal(d_desc[f, :cnt[f]].cpu().numpy(), rd)
+    ex.close()
+
+
 def test_small_and_odd_sizes():
     _cmp(synth.synth_frame(5, 320, 240), nfeatures=500)
     _cmp(synth.synth_frame(6, 333, 257), nfeatures=300)

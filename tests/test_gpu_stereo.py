@@ -11,9 +11,9 @@ MBF = 386.1448                      # KITTI-00-like constants
 MB = MBF / 718.856
 
 
-def _pair(idx, w, h, nf):
-    left = synth.synth_frame(idx, w, h)
-    right = synth.synth_stereo_right(idx, w, h)
+def _pair(idx, w, h, nf, natural=False):
+    left = synth.synth_natural(idx, w, h) if natural else synth.synth_frame(idx, w, h)
+    right = synth.synth_natural_stereo_right(idx, w, h) if natural else synth.synth_stereo_right(idx, w, h)
     exl, exr = capi.Extractor(nf), capi.Extractor(nf)
     kl, dl = exl.extract(left)
     kr, dr = exr.extract(right)
@@ -38,6 +38,20 @@ def test_stereo_matches_bit_exact(idx, w, h, nf):
     disp = kl["x"][ok] - got_u[ok]
     band = 12 + 8 * np.floor(kl["y"][ok] / 94.0)
     assert np.mean(np.abs(disp - band) < 1.5) > 0.8
+
+
+def test_stereo_on_natural_statistics_pair():
+    """KITTI-sized pair with natural image statistics (synth.synth_natural): extraction of both views and the stereo search
+    equal the oracle's bit for bit, and the recovered disparities sit on the synthetic disparity bands."""
+    (exl, exr, kl, dl, kr, dr), (rl, rr) = _pair(2, 1241, 376, 2000, natural=True)
+    want_u, want_z = oracle.stereo_matches(rl, rr, kl, dl, kr, dr, MB, MBF)
+    got_u, got_z = capi.stereo_match(exl, exr, kl, dl, kr, dr, MB, MBF)
+    assert got_u.tobytes() == want_u.tobytes() and got_z.tobytes() == want_z.tobytes()
+    ok = got_u >= 0
+    assert ok.sum() > 0.2 * len(kl)
+    disp = kl["x"][ok] - got_u[ok]
+    band = 12 + 8 * np.floor(kl["y"][ok] / 94.0)
+    assert np.mean(np.abs(disp - band) < 1.5) > 0.7
 
 
 def test_stereo_no_right_features_and_swapped_baseline():
