@@ -392,6 +392,23 @@ int orb_multi_extract_batch(orb_multi* m, const uint8_t* imgs, int n_frames, int
 /* the partition rule: rank r of `world` owns frames [first, first + count) of `total` (host only, no device needed) */
 void orb_shard_range(int total, int world, int rank, int* first, int* count);
 
+/* BASELINE configs[4] over several GPUs: a keyframe descriptor database sharded BY KEYFRAME over `devices`
+ * (contiguous blocks, orb_shard_range), the query frame replicated, no exchange between the GPUs -- every (keyframe, frame)
+ * result of the candidate loop of reference src/Tracking.cc:1471-1492 / src/ORBmatcher.cc:552-687 is independent; each
+ * shard's host thread writes its keyframes' rows of the caller's result arrays.  Arrays are laid out like an orb_featstore
+ * (host pointers): frame f owns rows [f*cap, (f+1)*cap); valid may be NULL (= all valid); node_of = compact vocabulary
+ * node per feature (orb_bow_transform*).  The same device may be listed more than once.  UNMEASURED on more than one
+ * physical GPU (the build's GPU boxes have one). */
+typedef struct orb_multi_db orb_multi_db;
+int orb_multi_db_create(const int* devices, int n_devices, const uint8_t* desc, const orb_keypoint* kps, const uint8_t* valid,
+                        const int32_t* counts, const uint16_t* node_of, int n_kf, int cap, int n_nodes, orb_multi_db** out);
+void orb_multi_db_destroy(orb_multi_db* db);
+int orb_multi_db_shards(const orb_multi_db* db);
+/* one query frame (q_count <= cap features) against every keyframe of the database: match[kf*cap + iF] = keyframe feature
+ * matched to query feature iF or -1, nmatches[kf] = the reference's return value for that keyframe */
+int orb_multi_match_bow_batch(orb_multi_db* db, const uint8_t* q_desc, const orb_keypoint* q_kps, int q_count,
+                              const uint16_t* q_node_of, float ratio, int check_ori, int32_t* match, int32_t* nmatches);
+
 /* Batch of stereo pairs in ONE launch: pair p = frames (first_frame_l + p, first_frame_r + p) of the two handles' last
  * batches, its keypoints / descriptors / results at rows [p * cap, (p + 1) * cap) of the arrays orb_extract_batch_device
  * wrote, its keypoint counts read on the device from the extractors' d_counts (no host round trip between extraction

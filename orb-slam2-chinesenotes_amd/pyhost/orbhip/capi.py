@@ -66,7 +66,8 @@ SYMBOLS = [
     "orb_match_bow", "orb_match_bow_kk", "orb_match_init", "orb_match_projection", "orb_match_projection_best", "orb_match_triangulation", "orb_vocab_create", "orb_vocab_destroy", "orb_vocab_level_nodes", "orb_bow_transform",
     "orb_bow_transform_device", "orb_distinctive_descriptors", "orb_distinctive_descriptors_device", "orb_bow_assign_device", "orb_match_bow_batch_device", "orb_bow_build_csr_device",
     "orb_matcher_stream", "orb_stereo_match", "orb_stereo_match_device", "orb_stereo_match_batch_device", "orb_extractor_wait_for", "orb_matcher_wait_for", "orb_last_error", "orb_version", "orb_abi_version", "orb_sizeof_featstore", "orb_multi_create", "orb_multi_destroy", "orb_multi_devices", "orb_multi_handle",
-    "orb_multi_set_pattern", "orb_multi_extract_batch", "orb_shard_range",
+    "orb_multi_set_pattern", "orb_multi_extract_batch", "orb_shard_range", "orb_multi_db_create", "orb_multi_db_destroy",
+    "orb_multi_db_shards", "orb_multi_match_bow_batch",
 ]
 
 
@@ -143,6 +144,11 @@ def lib():
     L.orb_matcher_wait_for.argtypes = [vp, vp]
     L.orb_multi_create.argtypes = [C.POINTER(Params), vp, ci, C.POINTER(vp)]
     L.orb_multi_destroy.argtypes = [vp]
+    L.orb_multi_db_create.argtypes = [vp, ci, vp, vp, vp, vp, vp, ci, ci, ci, C.POINTER(vp)]
+    L.orb_multi_db_destroy.argtypes = [vp]
+    L.orb_multi_db_destroy.restype = None
+    L.orb_multi_db_shards.argtypes = [vp]
+    L.orb_multi_match_bow_batch.argtypes = [vp, vp, vp, ci, vp, cf, ci, vp, vp]
     L.orb_multi_destroy.restype = None
     L.orb_multi_devices.argtypes = [vp]
     L.orb_multi_handle.argtypes = [vp, ci]
@@ -352,6 +358,47 @@ class MultiExtractor:
         _check(self.L.orb_multi_extract_batch(self.h, _p(imgs), f, rows, cols, imgs.strides[1], imgs.strides[0], _p(kps), _p(desc),
                                               cap, _p(counts)))
         return [(kps[i, :counts[i]].copy(), desc[i, :counts[i]].copy()) for i in range(f)]
+
+
+class MultiKeyframeDB:
+    """A keyframe database sharded by keyframe over `devices` (orb_multi_db_*): host arrays desc (n_kf, cap, 32) u8,
+    kps (n_kf, cap) KP_DTYPE, valid (n_kf, cap) u8 or None, counts (n_kf) i32, node_of (n_kf, cap) u16."""
+
+    def __init__(self, devices, desc, kps, valid, counts, node_of, n_nodes):
+        self.L = lib()
+        desc = np.ascontiguousarray(desc, np.uint8); kps = np.ascontiguousarray(kps)
+        counts = np.ascontiguousarray(counts, np.int32); node_of = np.ascontiguousarray(node_of, np.uint16)
+        valid = None if valid is None else np.ascontiguousarray(valid, np.uint8)
+        self.n_kf, self.cap = desc.shape[0], desc.shape[1]
+        devs = np.asarray(devices, np.int32)
+        h = C.c_void_p()
+        _check(self.L.orb_multi_db_create(_p(devs), len(devs), _p(desc), _p(kps), _p(valid) if valid is not None else None,
+                                          _p(counts), _p(node_of), self.n_kf, self.cap, n_nodes, C.byref(h)))
+        self.h = h
+
+    @property
+    def shards(self):
+        return self.L.orb_multi_db_shards(self.h)
+
+    def match(self, q_desc, q_kps, q_node_of, ratio=0.7, check_ori=True):
+        q_desc = np.ascontiguousarray(q_desc, np.uint8); q_kps = np.ascontiguousarray(q_kps)
+        q_node_of = np.ascontiguousarray(q_node_of, np.uint16)
+        match = np.full((self.n_kf, self.cap), -7, np.int32)
+        nm = np.full(self.n_kf, -7, np.int32)
+        _check(self.L.orb_multi_match_bow_batch(self.h, _p(q_desc), _p(q_kps), len(q_kps), _p(q_node_of), ratio, int(check_ori),
+                                                _p(match), _p(nm)))
+        return match, nm
+
+    def close(self):
+        if self.h:
+            self.L.orb_multi_db_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def _fv(node_ids, offsets, indices):

@@ -652,6 +652,57 @@ def test_c5_full_size_1000_keyframe_db():
             assert wn == n0[kf] and np.array_equal(wm, m0[kf, :nqf]), (q, kf)
 
 
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0, 0, 0]])
+def test_keyframe_db_sharded_by_keyframe(devices):
+    """orb_multi_db_* / orb_multi_match_bow_batch (BASELINE configs[4]): the keyframe DB cut into contiguous
+    blocks of keyframes, one shard (matcher handle, store slice, host thread) per listed device, the query replicated, results
+    written in place.  On the one-GPU box the device is listed several times (partition, threads, merge; no second GPU is
+    exercised).  Every keyframe's result equals the single-store batch matcher's and, on a sample, the oracle's."""
+    import torch
+    W, H, n_kf = 400, 300, 37
+    dev = torch.device("cuda", 0)
+    ex, mt = capi.Extractor(600), capi.Matcher(0.75, True)
+    cap = ex.max_keypoints
+    F = n_kf + 2
+    z = lambda n, dt: torch.zeros(n, dtype=dt, device=dev)
+    d_kps, d_desc, d_counts, d_node = z(F * cap * 28, torch.uint8), z(F * cap * 32, torch.uint8), z(F, torch.int32), z(F * cap, torch.int16)
+    frames = np.concatenate([synth.synth_sequence(0, n_kf, W, H), synth.synth_sequence(11, 1, W, H, noise=5), synth.synth_sequence(26, 1, W, H, noise=4)])
+    d_b = torch.from_numpy(frames).to(dev)
+    ex.extract_batch_device(d_b.data_ptr(), F, H, W, W, W * H, d_kps.data_ptr(), d_desc.data_ptr(), cap, d_counts.data_ptr())
+    ex.sync()
+    tree = synth.synth_vocab_tree_balanced(10, 4, seed=9)
+    voc = capi.Vocabulary(tree)
+    nn = voc.level_nodes(2)
+    voc.transform_device(mt, d_desc.data_ptr(), d_counts.data_ptr(), F, cap, 2, d_node_of=d_node.data_ptr())
+    mt.sync()
+    counts = d_counts.cpu().numpy()
+    kps = d_kps.cpu().numpy().view(capi.KP_DTYPE).reshape(F, cap)
+    desc = d_desc.cpu().numpy().reshape(F, cap, 32)
+    node = d_node.cpu().numpy().view(np.uint16).reshape(F, cap)
+    valid = np.stack([synth.synth_valid_flags(cap, 900 + i) for i in range(n_kf)])
+    db = capi.MultiKeyframeDB(devices, desc[:n_kf], kps[:n_kf], valid, counts[:n_kf], node[:n_kf], nn)
+    assert db.shards == len(devices)
+    rng = np.random.default_rng(3)
+    for q in (n_kf, n_kf + 1):
+        nq = int(counts[q])
+        match, nm = db.match(desc[q, :nq], kps[q, :nq], node[q, :nq], 0.75, True)
+        assert nm.min() >= 0 and nm.max() > 60                               # the query's own scene is in the DB
+        for kf in list(rng.choice(n_kf, 8, replace=False)) + [int(nm.argmax())]:
+            n = int(counts[kf])
+            fvk = oracle.featvec_from_nodes(oracle.vocab_transform(tree, desc[kf, :n], 2)[1])
+            fvq = oracle.featvec_from_nodes(oracle.vocab_transform(tree, desc[q, :nq], 2)[1])
+            wn, wm = oracle.search_by_bow(desc[kf, :n], kps[kf, :n]["angle"], valid[kf][:n], fvk, desc[q, :nq], kps[q, :nq]["angle"], fvq, 0.75, True)
+            assert wn == nm[kf] and np.array_equal(wm, match[kf, :nq]), (devices, q, kf)
+        assert np.all(nm == (match[:, :nq] >= 0).sum(axis=1))
+    # valid = NULL means every keyframe feature has a good MapPoint; an empty query gives no matches
+    db2 = capi.MultiKeyframeDB(devices, desc[:n_kf], kps[:n_kf], None, counts[:n_kf], node[:n_kf], nn)
+    m2, n2 = db2.match(desc[n_kf, :int(counts[n_kf])], kps[n_kf, :int(counts[n_kf])], node[n_kf, :int(counts[n_kf])], 0.75, True)
+    assert n2.sum() >= db.match(desc[n_kf, :int(counts[n_kf])], kps[n_kf, :int(counts[n_kf])], node[n_kf, :int(counts[n_kf])], 0.75, True)[1].sum()
+    m3, n3 = db2.match(desc[n_kf, :0], kps[n_kf, :0], node[n_kf, :0])
+    assert np.all(n3 == 0)
+    db.close(); db2.close()
+
+
 def test_search_by_bow_frames_of_6000_features():
     """Frames as large as the 2 x nFeatures initialisation extractor produces (reference src/Tracking.cc:121): more than
     64 KB of LDS per pair in k_match_bow (the CU's whole 160 KB is available to one workgroup)."""
