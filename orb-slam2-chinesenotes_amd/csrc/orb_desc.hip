@@ -8,6 +8,10 @@
 // the patch with v_dot4_u32_u8 on funnel-shifted byte windows (8.8 fixed-point taps fit a byte), the
 // vertical pass only at the 512 sampled points.  The blurred level is never written to HBM.
 // Four __ballot()s of 64 comparisons ARE the 256-bit descriptor.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+
 #include "orb_kernels.h"
 #include "orb_wave.h"
 
@@ -17,6 +21,8 @@
 
 #define WAVE 64
 typedef unsigned short orb_u16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int orb_u32x4 __attribute__((ext_vector_type(4)));
+typedef orb_u32x4 __attribute__((aligned(4))) orb_u32x4_a4;
 #define PR 21                  // patch radius
 #define PW 43                  // patch rows / useful columns
 #define PB 48                  // LDS row pitch in bytes (12 aligned dwords cover xoff + 43 <= 46 bytes)
@@ -70,6 +76,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
                                                       const int* __restrict__ kpCount,
                                                       const float4* __restrict__ patF,
                                                       const uint4* __restrict__ angTab,
+                                                      const uint32_t* __restrict__ hbTab,
                                                       orb_keypoint* __restrict__ kpsOut,
                                                       uint8_t* __restrict__ descOut, int cap,
                                                       int32_t* __restrict__ countsOut, int* __restrict__ errFlags,
@@ -78,9 +85,9 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     // ONE LDS region: first the raw patch (2 KB, dword rows with one dword of slack on both sides), later the
     // row-blurred patch H (4 KB, u16) written over it once every lane holds its blur outputs in registers.
     // 4.1 KB per workgroup instead of 6.2 KB lets the wave-slot limit (32 per CU), not LDS, set the occupancy.
-    __shared__ uint32_t ldsBuf[1032];
-    static_assert(1032 >= 1 + 48 * PDW + 2 && 1032 * 4 >= HT_COLS * HT_RP * 2, "raw patch rows 0..47 (43..47: slack that is read, never used) and H");
-    uint32_t* Pdw = ldsBuf + 1;
+    __shared__ __attribute__((aligned(16))) uint32_t ldsBuf[1032];
+    static_assert(1032 >= 4 + 48 * PDW + 2 && 1032 * 4 >= HT_COLS * HT_RP * 2, "raw patch rows 0..47 (43..47: slack that is read, never used) and H");
+    uint32_t* Pdw = ldsBuf + 4;                        // 16-byte aligned rows (48-byte pitch): staged with 16-byte stores
     const int lane = threadIdx.x;
     int slot, f;
     if (invPerFrame) {                                 // 1-D XCD-aware grid: a frame's keypoints share one L2
@@ -122,13 +129,26 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     const int xl = x0 - PR;                            // image column of patch column 0 (may be < 0)
     const int xa = xl & ~3, xoff = xl - xa;            // (two's complement: floor to a multiple of 4)
     const bool interior = xl >= 0 && x0 + PR < L.w && y0 - PR >= 0 && y0 + PR < L.h;
+    // horizontal-blur work items of this lane (see below): requested now, used after the staging
+    const uint32_t* hbt = hbTab + xoff * 192 + lane;
+    const unsigned hb0 = hbt[0], hb1 = hbt[64], hb2 = hbt[128];
     if (interior) {
-        const int rp = lane / PDW, c = lane - rp * PDW;     // 5 rows x 12 dwords per pass
-        if (rp < 5) {
-            const uint8_t* src = img + (size_t)(y0 - PR + rp) * L.pitch + xa + 4 * c;
-            for (int r = rp; r < PW; r += 5, src += (size_t)5 * L.pitch)
-                Pdw[r * PDW + c] = *reinterpret_cast<const uint32_t*>(src);
+        // 43 rows x 3 chunks of 16 bytes (the patch row starts at a 4-byte aligned column: unaligned 16-byte global loads),
+        // 21 rows per pass, all three passes in flight
+        const int row = (lane * 171) >> 9, c = lane - row * 3;     // lane / 3 for lane < 64
+        const uint8_t* src = img + (size_t)(y0 - PR + row) * L.pitch + xa + 16 * c;
+        uint8_t* dst = reinterpret_cast<uint8_t*>(Pdw) + row * PB + 16 * c;
+        orb_u32x4 v0 = {0, 0, 0, 0}, v1 = v0, v2 = v0;
+        if (lane < 63) {
+            v0 = *reinterpret_cast<const orb_u32x4_a4*>(src);
+            v1 = *reinterpret_cast<const orb_u32x4_a4*>(src + (size_t)21 * L.pitch);
         }
+        if (lane < 3) v2 = *reinterpret_cast<const orb_u32x4_a4*>(src + (size_t)42 * L.pitch);
+        if (lane < 63) {
+            *reinterpret_cast<orb_u32x4*>(dst) = v0;
+            *reinterpret_cast<orb_u32x4*>(dst + 21 * PB) = v1;
+        }
+        if (lane < 3) *reinterpret_cast<orb_u32x4*>(dst + 42 * PB) = v2;
     } else if (lane < PB) {                            // BORDER_REFLECT_101, byte by byte
         uint8_t* Pb = reinterpret_cast<uint8_t*>(Pdw);
         const int gx = reflect101(xa + lane, L.w);
@@ -172,26 +192,31 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     // ds_read2_b32 + 4 v_alignbit + 4 v_dot2_u32_u16.
     const int qFirst = (xoff + 3) >> 2;
     {
-        const int rp = lane / 10, ql = lane - rp * 10;         // 6 row phases x 10 quads = 60 lanes
-        uint32_t hv[4][4];                                     // [row pair][column of the quad]
-        if (rp < 6) {
-            const uint32_t* p = Pdw + 2 * rp * PDW + qFirst + ql - 1;
+        // Work items = (row pair, quad) that the rotated pattern can reach: a sample lies within 18.4 px of the keypoint
+        // (|x|, |y| <= 13 for every pattern point, checked by orb_extractor_set_pattern), so the row pairs near the top and
+        // the bottom of the patch need 4..9 of the 10 quads -- 189 / 190 items instead of 240, three per lane instead of four.
+        // The host tabulates them per xoff (orb_desc_hblur_table): source dword (relative to Pdw) | destination dword << 16.
+        const unsigned items[3] = {hb0, hb1, hb2};
+        uint32_t hv[3][4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < 3; i++) {
+            if (items[i] != 0xffffffffu) {
+                const uint32_t* p = Pdw + (items[i] & 0xffffu);
                 unsigned o0[4], o1[4];
-                hblur4(p[12 * i * PDW], p[12 * i * PDW + 1], p[12 * i * PDW + 2], o0);
-                hblur4(p[(12 * i + 1) * PDW], p[(12 * i + 1) * PDW + 1], p[(12 * i + 1) * PDW + 2], o1);
+                hblur4(p[0], p[1], p[2], o0);
+                hblur4(p[PDW], p[PDW + 1], p[PDW + 2], o1);
 #pragma unroll
                 for (int j = 0; j < 4; j++) hv[i][j] = o0[j] | (o1[j] << 16);
             }
         }
         __syncthreads();                                       // every read of the raw patch is done: H may overwrite it
-        if (rp < 6) {
-            uint32_t* col = ldsBuf + 4 * ql * (HT_RP / 2) + rp;  // dword (column 4 ql, rows 2 rp / 2 rp + 1)
 #pragma unroll
-            for (int i = 0; i < 4; i++)
+        for (int i = 0; i < 3; i++) {
+            if (items[i] != 0xffffffffu) {
+                uint32_t* col = ldsBuf + (items[i] >> 16);      // dword (column 4 ql, rows 2 p / 2 p + 1)
 #pragma unroll
-                for (int j = 0; j < 4; j++) col[j * (HT_RP / 2) + 6 * i] = hv[i][j];
+                for (int j = 0; j < 4; j++) col[j * (HT_RP / 2)] = hv[i][j];
+            }
         }
     }
     __syncthreads();
@@ -252,17 +277,48 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     }
 }
 
+// The horizontal-blur work items of k_orient_desc for xoff = 0..3: [4][3][64] entries, source dword offset (relative to the
+// raw patch) | destination dword offset << 16, 0xffffffff = none.  Row offset dy (from the keypoint) of the row-blurred
+// patch is read by samples of rows dy-3 .. dy+3; a sample (ic, ir) is the rounding of a point within R = sqrt(13^2 + 13^2)
+// of the keypoint, so |ic| <= round(sqrt(R^2 - (|ir| - 0.5)^2)).
+void orb_desc_hblur_table(uint32_t* tab768)
+{
+    const double R2 = 13.0 * 13.0 + 13.0 * 13.0;
+    int cmax[43];
+    for (int r = 0; r < 43; r++) {
+        const int ady = r > PR ? r - PR : PR - r, ir = ady > 3 ? ady - 3 : 0;
+        const double m = ir > 0 ? ir - 0.5 : 0.0;
+        int c = (int)(std::sqrt(R2 - m * m) + 0.5);
+        cmax[r] = c > 18 ? 18 : c;
+    }
+    for (int xoff = 0; xoff < 4; xoff++) {
+        uint32_t* t = tab768 + xoff * 192;
+        for (int i = 0; i < 192; i++) t[i] = 0xffffffffu;
+        const int qFirst = (xoff + 3) >> 2;
+        int n = 0;
+        for (int p = 0; p < 22; p++) {
+            const int c = std::max(cmax[2 * p], 2 * p + 1 < 43 ? cmax[2 * p + 1] : 0);
+            const int lo = (xoff + PR - c) >> 2, hi = (xoff + PR + c) >> 2;
+            for (int q = lo; q <= hi; q++, n++) {
+                const unsigned src = (unsigned)(2 * p * PDW + q - 1), dst = (unsigned)(4 * (q - qFirst) * (HT_RP / 2) + p);
+                if (n < 192) t[(n >> 6) * 64 + (n & 63)] = src | (dst << 16);      // item n -> pass n / 64, lane n % 64
+            }
+        }
+        if (n > 192) std::abort();                         // 189 / 190 by construction
+    }
+}
+
 void orb_launch_orient_desc(hipStream_t st, const OrbGeom& G, const uint8_t* pyr, size_t pyrSlab,
-                            const uint32_t* kpl, const int* kpCount, const float* patternF, const uint4* angTab,
+                            const uint32_t* kpl, const int* kpCount, const float* patternF, const uint4* angTab, const uint32_t* hbTab,
                             orb_keypoint* kps, uint8_t* desc, int cap, int32_t* counts, int* errFlags,
                             int nFrames)
 {
     unsigned inv = 0;
     const unsigned wgs = orb_xcd_grid((unsigned)G.kpSlab, nFrames, &inv);
     if (wgs)
-        hipLaunchKernelGGL(k_orient_desc, dim3(wgs), dim3(WAVE), 0, st, G, pyr, pyrSlab, kpl, kpCount, reinterpret_cast<const float4*>(patternF), angTab, kps,
+        hipLaunchKernelGGL(k_orient_desc, dim3(wgs), dim3(WAVE), 0, st, G, pyr, pyrSlab, kpl, kpCount, reinterpret_cast<const float4*>(patternF), angTab, hbTab, kps,
                            desc, cap, counts, errFlags, nFrames, inv);
     else
         hipLaunchKernelGGL(k_orient_desc, dim3(G.kpSlab, nFrames), dim3(WAVE), 0, st, G, pyr, pyrSlab, kpl, kpCount,
-                           reinterpret_cast<const float4*>(patternF), angTab, kps, desc, cap, counts, errFlags, nFrames, 0u);
+                           reinterpret_cast<const float4*>(patternF), angTab, hbTab, kps, desc, cap, counts, errFlags, nFrames, 0u);
 }

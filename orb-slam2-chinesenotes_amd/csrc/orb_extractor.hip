@@ -196,7 +196,7 @@ extern "C" int orb_extractor_create(const orb_extractor_params* p, int device_id
         if (hipMemcpy(h->dPattern.p, ORB_BRIEF_PATTERN_XY, 1024, hipMemcpyHostToDevice) != hipSuccess) rc = ORB_ERR_HIP;
     }
     if (rc == ORB_OK) rc = h->dPatternF.ensure(256 * 16);
-    if (rc == ORB_OK) rc = h->dAngTab.ensure(16 * 2 * 32);
+    if (rc == ORB_OK) rc = h->dAngTab.ensure(16 * 2 * 32 + 768 * 4);     // + the descriptor kernel's horizontal-blur item table
     if (rc == ORB_OK) {
         // IC_Angle tables (k_orient_desc): per (|v|, half row) 16 mask bytes (1 inside |u| <= umax[|v|]) and
         // 16 weight bytes (u + 15 inside, 0 outside) for u = -15 + 16*half + byte
@@ -210,6 +210,9 @@ extern "C" int orb_extractor_create(const orb_extractor_params* p, int device_id
                     tab[a][hh][16 + b] = in ? (uint8_t)(u + 15) : 0;
                 }
         if (hipMemcpy(h->dAngTab.p, tab, sizeof(tab), hipMemcpyHostToDevice) != hipSuccess) rc = ORB_ERR_HIP;
+        uint32_t hb[768];
+        orb_desc_hblur_table(hb);
+        if (rc == ORB_OK && hipMemcpy((uint8_t*)h->dAngTab.p + sizeof(tab), hb, sizeof(hb), hipMemcpyHostToDevice) != hipSuccess) rc = ORB_ERR_HIP;
     }
     if (rc != ORB_OK) { orb_extractor_destroy(h); return rc; }
     h->patternPtr = (const int8_t*)h->dPattern.p;
@@ -265,6 +268,11 @@ extern "C" int orb_extractor_max_keypoints(const orb_extractor* h)
 extern "C" int orb_extractor_set_pattern(orb_extractor* h, const int8_t* pat)
 {
     if (!h || !pat) return ORB_ERR_INVALID;
+    for (int i = 0; i < 1024; i++)
+        if (pat[i] < -13 || pat[i] > 13) {                     // the reference's table stays within +-13 (src/ORBextractor.cc:175-432);
+            orb_set_error("BRIEF pattern coordinate %d outside [-13, 13]: the descriptor kernel's patch covers 18 px around a keypoint", (int)pat[i]);
+            return ORB_ERR_UNSUPPORTED;                         // the kernel's patch / blur extent is sized for it
+        }
     ORB_HIP_TRY(hipSetDevice(h->device));
     ORB_HIP_TRY(hipMemcpyAsync(h->dPattern.p, pat, 1024, hipMemcpyHostToDevice, h->stream));
     ORB_HIP_TRY(hipStreamSynchronize(h->stream));
@@ -433,7 +441,7 @@ extern "C" int orb_extract_batch_device(orb_extractor* h, const uint8_t* d_imgs,
     if (prof) ORB_HIP_TRY(hipEventRecord(pe[2], st));
     orb_launch_quadtree(st, G, scand, h->candSlab, scc, skpl, skc, serr, h->sortCap, h->nodeCap, n, h->ovfCountP());
     if (prof) ORB_HIP_TRY(hipEventRecord(pe[3], st));
-    orb_launch_orient_desc(st, G, pyr, h->pyrSlab, skpl, skc, (const float*)h->dPatternF.p, (const uint4*)h->dAngTab.p, d_kps, d_desc, cap,
+    orb_launch_orient_desc(st, G, pyr, h->pyrSlab, skpl, skc, (const float*)h->dPatternF.p, (const uint4*)h->dAngTab.p, (const uint32_t*)((const uint8_t*)h->dAngTab.p + 16 * 2 * 32), d_kps, d_desc, cap,
                            d_counts, serr, n);
     if (prof) {
         ORB_HIP_TRY(hipEventRecord(pe[4], st));
