@@ -89,8 +89,10 @@ static int build_geometry(orb_extractor* h, int rows, int cols)
         if ((rc = h->dBand.ensure(P.bandTab.size() * sizeof(int2))) != ORB_OK) return rc;
         ORB_HIP_TRY(hipMemcpyAsync(h->dBand.p, P.bandTab.data(), P.bandTab.size() * sizeof(int2), hipMemcpyHostToDevice, h->stream));
         h->pyrChains = P.chains;
+        h->pyrChainsLat = P.chainsLat;
     } else {
         h->pyrChains.clear();
+        h->pyrChainsLat.clear();
     }
     ORB_HIP_TRY(hipStreamSynchronize(h->stream));     // host vectors go out of scope
     // commit
@@ -411,8 +413,10 @@ extern "C" int orb_extract_batch_device(orb_extractor* h, const uint8_t* d_imgs,
     // (also clears the status block behind the sticky word -- error flags, counters, overflow list head -- and spreads the
     // int8 BRIEF pattern into the float table the descriptor kernel reads)
     if (!h->pyrChains.empty()) {
-        for (size_t c = 0; c < h->pyrChains.size(); c++)
-            orb_launch_pyr_chain(st, h->pyrChains[c], d_imgs, rowStride, frameStride, pyr, h->pyrSlab, (const uint4*)h->dXq.p,
+        // a handful of frames cannot fill the chip with 16-row bands (21 workgroups per frame at 640x480): 4-row bands
+        const std::vector<OrbPyrChain>& chains = n <= 8 ? h->pyrChainsLat : h->pyrChains;
+        for (size_t c = 0; c < chains.size(); c++)
+            orb_launch_pyr_chain(st, chains[c], d_imgs, rowStride, frameStride, pyr, h->pyrSlab, (const uint4*)h->dXq.p,
                                  (const int2*)h->dYtab.p, (const int2*)h->dBand.p, n, c == 0 ? h->errP() : nullptr,
                                  (int)orb_extractor::batchInts(n), h->patternPtr, (float*)h->dPatternF.p);
     } else {

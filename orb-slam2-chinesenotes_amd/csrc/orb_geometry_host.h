@@ -35,7 +35,8 @@ struct OrbGeomPlan {                        // everything build_geometry derives
     std::vector<size_t> xtabOff, ytabOff;
     std::vector<long long> xqOff;
     // pyramid chains (k_pyr_chain): empty when some level is not eligible -- the per-level kernels are used then
-    std::vector<OrbPyrChain> chains;
+    std::vector<OrbPyrChain> chains;        // bands of 16 rows: batches (throughput)
+    std::vector<OrbPyrChain> chainsLat;     // bands of 4 rows: a few frames (4x the workgroups, each a quarter as long: latency)
     std::vector<int2> bandTab;
 };
 
@@ -452,25 +453,28 @@ static int orb_plan_geometry(const orb_extractor_params& prm, const OrbHostTable
     }
     // pyramid chains: (1, 2) with the level-0 copy, then pairs, the last three levels together when an odd one remains
     P.chains.clear();
+    P.chainsLat.clear();
     P.bandTab.clear();
-    if (nl >= 2) {
-        bool ok = true;
-        for (int l = 1; l < nl && ok;) {
+    auto plan_set = [&](std::vector<OrbPyrChain>& set, int bandHi, int bandLo) -> bool {
+        for (int l = 1; l < nl;) {
             int n = std::min(2, nl - l);
             if (nl - (l + n) == 1) n = (l == 1) ? n : 3;          // never leave a single level for a launch of its own ...
             if (l + n > nl) n = nl - l;
             OrbPyrChain C;
             bool done = false;
             for (int tryN = n; tryN >= 1 && !done; tryN--)
-                for (int br = 16; br >= 8 && !done; br >>= 1)
+                for (int br = bandHi; br >= bandLo && !done; br >>= 1)
                     if (plan_pyr_chain(G, yt, P.ytabOff, P.xqOff, l, tryN, l == 1, br, (size_t)40 * 1024, C, P.bandTab)) {
-                        P.chains.push_back(C);
+                        set.push_back(C);
                         l += tryN;
                         done = true;
                     }
-            ok = done;
+            if (!done) return false;
         }
-        if (!ok) { P.chains.clear(); P.bandTab.clear(); }
+        return true;
+    };
+    if (nl >= 2) {
+        if (!plan_set(P.chains, 16, 8) || !plan_set(P.chainsLat, 4, 2)) { P.chains.clear(); P.chainsLat.clear(); P.bandTab.clear(); }
     }
     P.nCells = nCells;
     P.pyrSlab = (size_t)align_up((int)pyrOff, 256);

@@ -1,57 +1,200 @@
-// TEST DOUBLE of the reference's include/ORBmatcher.h interface (only what the four replaced member
-// functions need) plus minimal Frame / KeyFrame / MapPoint / DBoW2::FeatureVector stand-ins with the
-// members those functions touch.  Used only to compile and run orb-slam2-chinesenotes_amd/host/
-// ORBmatcherHip.cc in tests; in a real ORB-SLAM2 tree the reference's own headers are used instead.
+// TEST DOUBLE of the reference's include/ORBmatcher.h interface plus minimal Frame / KeyFrame / MapPoint /
+// DBoW2 stand-ins with the members the replaced member functions touch (reference include/Frame.h, KeyFrame.h,
+// MapPoint.h; Thirdparty/DBoW2 is absent from the tree).  Used only to compile and run
+// orb-slam2-chinesenotes_amd/host/{ORBmatcherHip,ORBmatcherHipExtra,FrameHip}.cc in tests; in a real ORB-SLAM2
+// tree the reference's own headers are used instead.  Behaviour that the shims only CALL (PredictScale, IsInImage,
+// Replace, AddObservation ...) is written here from the reference's definitions in the simplest form; none of it is
+// under test.
 #pragma once
+#include <cmath>
 #include <map>
+#include <set>
 #include <vector>
 #include <opencv2/core/core.hpp>
 
+namespace ORB_SLAM2 { class ORBextractor; }
+
 namespace DBoW2 {
 typedef unsigned int NodeId;
-class FeatureVector : public std::map<NodeId, std::vector<unsigned int> > {};
-}
+typedef unsigned int WordId;
+typedef double WordValue;
+class FeatureVector : public std::map<NodeId, std::vector<unsigned int> > {
+public:
+    void addFeature(NodeId id, unsigned int i_feature)           // DBoW2/FeatureVector.cpp
+    {
+        iterator vit = this->lower_bound(id);
+        if (vit != this->end() && vit->first == id) vit->second.push_back(i_feature);
+        else {
+            vit = this->insert(vit, value_type(id, std::vector<unsigned int>()));
+            vit->second.push_back(i_feature);
+        }
+    }
+};
+class BowVector : public std::map<WordId, WordValue> {
+public:
+    void addWeight(WordId id, WordValue v)                        // DBoW2/BowVector.cpp
+    {
+        iterator vit = this->lower_bound(id);
+        if (vit != this->end() && !(this->key_comp()(id, vit->first))) vit->second += v;
+        else this->insert(vit, value_type(id, v));
+    }
+    void normalizeL1()
+    {
+        double norm = 0.0;
+        for (iterator it = begin(); it != end(); ++it) norm += std::fabs(it->second);
+        if (norm > 0.0)
+            for (iterator it = begin(); it != end(); ++it) it->second /= norm;
+    }
+};
+// The slice of DBoW2::TemplatedVocabulary<TDescriptor, F> the ComputeBoW replacement needs: the node table is a
+// PROTECTED member there too (m_nodes: id, weight, children, parent, descriptor, word_id), so the shim reaches it
+// through a derived accessor class, exactly as it would in a real tree.
+class Vocabulary {
+public:
+    struct Node {
+        NodeId id;
+        WordValue weight;
+        std::vector<NodeId> children;
+        NodeId parent;
+        cv::Mat descriptor;
+        WordId word_id;
+        Node() : id(0), weight(0), parent(0), word_id(0) {}
+        bool isLeaf() const { return children.empty(); }
+    };
+    int getDepthLevels() const { return m_L; }
+    int getBranchingFactor() const { return m_k; }
+    int m_k = 10, m_L = 6;
+    std::vector<Node> m_nodes_public_for_the_test_driver;          // the driver fills the tree through this alias
+protected:
+    std::vector<Node>& m_nodes = m_nodes_public_for_the_test_driver;
+};
+}  // namespace DBoW2
 
 namespace ORB_SLAM2 {
+
+typedef DBoW2::Vocabulary ORBVocabulary;
+class KeyFrame;
+class Frame;
 
 class MapPoint {
 public:
     explicit MapPoint(bool bad = false) : mbBad(bad) {}
     bool isBad() { return mbBad; }
+    int Observations() { return nObs; }
+    cv::Mat GetWorldPos() { return mWorldPos.clone(); }
+    cv::Mat GetNormal() { return mNormalVector.clone(); }
+    cv::Mat GetDescriptor() { return mDescriptor.clone(); }
+    float GetMinDistanceInvariance() { return 0.8f * mfMinDistance; }
+    float GetMaxDistanceInvariance() { return 1.2f * mfMaxDistance; }
+    int PredictScale(const float& currentDist, KeyFrame* pKF);
+    int PredictScale(const float& currentDist, Frame* pF);
+    bool IsInKeyFrame(KeyFrame* pKF) { return mObservations.count(pKF) != 0; }
+    int GetIndexInKeyFrame(KeyFrame* pKF) { return mObservations.count(pKF) ? (int)mObservations[pKF] : -1; }
+    void AddObservation(KeyFrame* pKF, size_t idx) { if (!mObservations.count(pKF)) { mObservations[pKF] = idx; nObs++; } }
+    void Replace(MapPoint* pMP) { if (pMP != this) { mbBad = true; mpReplaced = pMP; } }
     bool mbBad;
+    int nObs = 0;
+    cv::Mat mWorldPos, mNormalVector, mDescriptor;
+    float mfMinDistance = 0, mfMaxDistance = 0;
+    std::map<KeyFrame*, size_t> mObservations;
+    MapPoint* mpReplaced = nullptr;
+    // tracking fields (include/MapPoint.h:95-101)
+    float mTrackProjX = 0, mTrackProjY = 0, mTrackProjXR = 0;
+    bool mbTrackInView = false;
+    int mnTrackScaleLevel = 0;
+    float mTrackViewCos = 1;
 };
 
 class Frame {
 public:
     int N = 0;
-    std::vector<cv::KeyPoint> mvKeys, mvKeysUn;
-    cv::Mat mDescriptors;
+    std::vector<cv::KeyPoint> mvKeys, mvKeysRight, mvKeysUn;
+    std::vector<float> mvuRight, mvDepth;
+    cv::Mat mDescriptors, mDescriptorsRight;
+    DBoW2::BowVector mBowVec;
     DBoW2::FeatureVector mFeatVec;
-    static float mnMinX, mnMinY, mfGridElementWidthInv, mfGridElementHeightInv;
+    std::vector<MapPoint*> mvpMapPoints;
+    std::vector<bool> mvbOutlier;
+    cv::Mat mTcw;
+    float fx = 0, fy = 0, cx = 0, cy = 0, mb = 0, mbf = 0;
+    int mnScaleLevels = 8;
+    float mfLogScaleFactor = 0;
+    std::vector<float> mvScaleFactors, mvInvLevelSigma2;
+    ORBextractor* mpORBextractorLeft = nullptr;
+    ORBextractor* mpORBextractorRight = nullptr;
+    ORBVocabulary* mpORBvocabulary = nullptr;
+    static float mnMinX, mnMaxX, mnMinY, mnMaxY, mfGridElementWidthInv, mfGridElementHeightInv;
+    void ComputeStereoMatches();                                   // host/FrameHip.cc
+    void ComputeBoW();                                             // host/FrameHip.cc
 };
 
 class KeyFrame {
 public:
+    int N = 0;
     std::vector<cv::KeyPoint> mvKeysUn;
+    std::vector<float> mvuRight;
     cv::Mat mDescriptors;
     DBoW2::FeatureVector mFeatVec;
     std::vector<MapPoint*> mvpMapPoints;
+    cv::Mat Tcw;                                                   // 4x4 float
+    float fx = 0, fy = 0, cx = 0, cy = 0, mbf = 0;
+    int mnScaleLevels = 8;
+    float mfLogScaleFactor = 0;
+    std::vector<float> mvScaleFactors, mvLevelSigma2, mvInvLevelSigma2;
+    int mnMinX = 0, mnMinY = 0, mnMaxX = 0, mnMaxY = 0;            // (ints in include/KeyFrame.h:214-217)
+    float mfGridElementWidthInv = 0, mfGridElementHeightInv = 0;
     std::vector<MapPoint*> GetMapPointMatches() { return mvpMapPoints; }
+    MapPoint* GetMapPoint(const size_t& idx) { return mvpMapPoints[idx]; }
+    void AddMapPoint(MapPoint* pMP, const size_t& idx) { mvpMapPoints[idx] = pMP; }
+    cv::Mat GetRotation() { return Tcw.rowRange(0, 3).colRange(0, 3).clone(); }
+    cv::Mat GetTranslation() { return Tcw.rowRange(0, 3).col(3).clone(); }
+    cv::Mat GetCameraCenter() { return -(Tcw.rowRange(0, 3).colRange(0, 3).t() * Tcw.rowRange(0, 3).col(3)); }
+    bool IsInImage(const float& x, const float& y) const { return (x >= mnMinX && x < mnMaxX && y >= mnMinY && y < mnMaxY); }
 };
+
+inline int MapPoint::PredictScale(const float& currentDist, KeyFrame* pKF)          // src/MapPoint.cc:433-447
+{
+    const float ratio = mfMaxDistance / currentDist;
+    int nScale = (int)std::ceil(std::log(ratio) / pKF->mfLogScaleFactor);
+    if (nScale < 0) nScale = 0;
+    else if (nScale >= pKF->mnScaleLevels) nScale = pKF->mnScaleLevels - 1;
+    return nScale;
+}
+inline int MapPoint::PredictScale(const float& currentDist, Frame* pF)
+{
+    const float ratio = mfMaxDistance / currentDist;
+    int nScale = (int)std::ceil(std::log(ratio) / pF->mfLogScaleFactor);
+    if (nScale < 0) nScale = 0;
+    else if (nScale >= pF->mnScaleLevels) nScale = pF->mnScaleLevels - 1;
+    return nScale;
+}
 
 class ORBmatcher {
 public:
     ORBmatcher(float nnratio = 0.6, bool checkOri = true) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
     static int DescriptorDistance(const cv::Mat& a, const cv::Mat& b);
+    int SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMapPoints, const float th = 3);
+    int SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool bMono);
+    int SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const std::set<MapPoint*>& sAlreadyFound, const float th,
+                           const int ORBdist);
+    int SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& vpPoints, std::vector<MapPoint*>& vpMatched,
+                           int th);
     int SearchByBoW(KeyFrame* pKF, Frame& F, std::vector<MapPoint*>& vpMapPointMatches);
     int SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12);
     int SearchForInitialization(Frame& F1, Frame& F2, std::vector<cv::Point2f>& vbPrevMatched,
                                 std::vector<int>& vnMatches12, int windowSize = 10);
+    int SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, cv::Mat F12, std::vector<std::pair<size_t, size_t> >& vMatchedPairs,
+                               const bool bOnlyStereo);
+    int SearchBySim3(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12, const float& s12, const cv::Mat& R12,
+                     const cv::Mat& t12, const float th);
+    int Fuse(KeyFrame* pKF, const std::vector<MapPoint*>& vpMapPoints, const float th = 3.0);
+    int Fuse(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& vpPoints, float th, std::vector<MapPoint*>& vpReplacePoint);
     static const int TH_LOW;
     static const int TH_HIGH;
     static const int HISTO_LENGTH;
 
 protected:
+    float RadiusByViewingCos(const float& viewCos);
     float mfNNratio;
     bool mbCheckOrientation;
 };

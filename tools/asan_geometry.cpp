@@ -77,9 +77,10 @@ static int one(const orb_extractor_params& prm, int rows, int cols, const int* s
     // pyramid chains (k_pyr_chain): the chains produce levels 1 .. nl-1 in order; inside a chain every band's row ranges stay
     // inside their levels and inside the LDS regions planned for them, the rows a step reads are rows its source band holds,
     // the bands of every produced level (and the level-0 copy partitions) cover the level without a gap
-    if (!P.chains.empty()) {
+    CHECK(P.chains.empty() == P.chainsLat.empty());
+    for (const std::vector<OrbPyrChain>* set : {&P.chains, &P.chainsLat}) if (!set->empty()) {
         int next = 1;
-        for (const OrbPyrChain& C : P.chains) {
+        for (const OrbPyrChain& C : *set) {
             CHECK(C.nSteps >= 1 && C.nSteps <= ORB_PYR_MAXCHAIN && next + C.nSteps <= prm.nlevels);
             const int first = next, ent = C.nSteps + 2;
             CHECK(C.copy0 == (first == 1 ? 1 : 0));
