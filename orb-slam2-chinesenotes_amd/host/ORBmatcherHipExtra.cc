@@ -84,11 +84,6 @@ orb_proj_query deadQuery()
     q.flags = 0;
     return q;
 }
-void appendDescriptor(std::vector<unsigned char>& rows, MapPoint* pMP)
-{
-    const cv::Mat d = pMP->GetDescriptor();
-    rows.insert(rows.end(), d.ptr<unsigned char>(0), d.ptr<unsigned char>(0) + 32);
-}
 struct FlatFeatVec {
     std::vector<uint32_t> ids;
     std::vector<int32_t> offs, idx;

@@ -2,18 +2,22 @@
 // in tests/support/.  It calls the classes exactly the way the reference's Frame.cc / Tracking.cc do.
 //   shim_driver extract <in.raw> <W> <H> <stride> <nfeatures> <outprefix>
 //   shim_driver match   <scene.bin> <outprefix>
+//   shim_driver extra   <scene.bin> <outprefix>      the eight other ORBmatcher routines + Frame::ComputeBoW
+//   shim_driver stereo  <left.raw> <right.raw> <W> <H> <nfeatures> <mb> <mbf> <outprefix>   Frame::ComputeStereoMatches
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <set>
 #include <string>
 #include <vector>
 
 #include "ORBextractor.h"
 #include "ORBmatcher.h"
+#include "ORBmatcherHipDebug.h"
 
 using namespace ORB_SLAM2;
 
-float Frame::mnMinX, Frame::mnMinY, Frame::mfGridElementWidthInv, Frame::mfGridElementHeightInv;
+float Frame::mnMinX, Frame::mnMinY, Frame::mnMaxX, Frame::mnMaxY, Frame::mfGridElementWidthInv, Frame::mfGridElementHeightInv;
 const int ORBmatcher::TH_HIGH = 100;
 const int ORBmatcher::TH_LOW = 50;
 const int ORBmatcher::HISTO_LENGTH = 30;
@@ -60,6 +64,243 @@ static void loadSide(Reader& r, int n, std::vector<cv::KeyPoint>& kps, cv::Mat& 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------- extra mode
+struct Scene {
+    int nA, nB, nMP;
+    float fx, fy, cx, cy, mbf, mb, minX, maxX, minY, maxY, gwi, ghi, logSF;
+    std::vector<float> sf, sig2, isig2;
+    std::vector<cv::KeyPoint> kpA, kpB;
+    cv::Mat dA, dB;
+    std::vector<float> urA, urB;
+    std::vector<int> nodeA, nodeB;
+    cv::Mat TcwA, TcwB, Scw, F12, R12, t12;
+    float s12;
+    struct MP { float pos[3], nrm[3]; unsigned char desc[32]; float minD, maxD; int nObs, bad, inView; float px, py, pxr; int lvl; float vcos; int idxA, idxB; };
+    std::vector<MP> mps;
+    std::vector<unsigned char> outlierA;
+};
+static cv::Mat readMat(Reader& r, int rows, int cols)
+{
+    cv::Mat m(rows, cols, CV_32F);
+    for (int i = 0; i < rows; i++)
+        for (int j = 0; j < cols; j++) m.at<float>(i, j) = r.get<float>();
+    return m;
+}
+static Scene loadScene(const std::vector<unsigned char>& buf)
+{
+    Reader r{buf.data()};
+    Scene S;
+    S.nA = r.get<int>(); S.nB = r.get<int>(); S.nMP = r.get<int>();
+    float* f13[] = {&S.fx, &S.fy, &S.cx, &S.cy, &S.mbf, &S.mb, &S.minX, &S.maxX, &S.minY, &S.maxY, &S.gwi, &S.ghi, &S.logSF};
+    for (float* p : f13) *p = r.get<float>();
+    for (std::vector<float>* v : {&S.sf, &S.sig2, &S.isig2}) { v->resize(8); for (int i = 0; i < 8; i++) (*v)[i] = r.get<float>(); }
+    auto side = [&](int n, std::vector<cv::KeyPoint>& k, cv::Mat& d, std::vector<float>& ur, std::vector<int>& node) {
+        k.resize(n);
+        memcpy(static_cast<void*>(k.data()), r.bytes((size_t)n * 28), (size_t)n * 28);
+        d.create(n, 32, CV_8U);
+        memcpy(d.data, r.bytes((size_t)n * 32), (size_t)n * 32);
+        ur.resize(n); node.resize(n);
+        for (int i = 0; i < n; i++) ur[i] = r.get<float>();
+        for (int i = 0; i < n; i++) node[i] = r.get<int>();
+    };
+    side(S.nA, S.kpA, S.dA, S.urA, S.nodeA);
+    side(S.nB, S.kpB, S.dB, S.urB, S.nodeB);
+    S.TcwA = readMat(r, 4, 4); S.TcwB = readMat(r, 4, 4); S.Scw = readMat(r, 4, 4); S.F12 = readMat(r, 3, 3);
+    S.s12 = r.get<float>(); S.R12 = readMat(r, 3, 3); S.t12 = readMat(r, 3, 1);
+    S.mps.resize(S.nMP);
+    for (int i = 0; i < S.nMP; i++) {
+        Scene::MP& m = S.mps[i];
+        for (float& v : m.pos) v = r.get<float>();
+        for (float& v : m.nrm) v = r.get<float>();
+        memcpy(m.desc, r.bytes(32), 32);
+        m.minD = r.get<float>(); m.maxD = r.get<float>();
+        m.nObs = r.get<int>(); m.bad = r.get<int>(); m.inView = r.get<int>();
+        m.px = r.get<float>(); m.py = r.get<float>(); m.pxr = r.get<float>();
+        m.lvl = r.get<int>(); m.vcos = r.get<float>(); m.idxA = r.get<int>(); m.idxB = r.get<int>();
+    }
+    const unsigned char* o = r.bytes(S.nA);
+    S.outlierA.assign(o, o + S.nA);
+    return S;
+}
+// a fresh world (MapPoints, two Frames, two KeyFrames) from the scene: every routine mutates its arguments
+struct World {
+    std::vector<MapPoint*> mp;
+    Frame fA, fB;
+    KeyFrame kA, kB;
+    explicit World(const Scene& S)
+    {
+        Frame::mnMinX = S.minX; Frame::mnMaxX = S.maxX; Frame::mnMinY = S.minY; Frame::mnMaxY = S.maxY;
+        Frame::mfGridElementWidthInv = S.gwi; Frame::mfGridElementHeightInv = S.ghi;
+        for (const Scene::MP& m : S.mps) {
+            MapPoint* p = new MapPoint(m.bad != 0);
+            p->mWorldPos = cv::Mat(3, 1, CV_32F); p->mNormalVector = cv::Mat(3, 1, CV_32F);
+            for (int k = 0; k < 3; k++) { p->mWorldPos.at<float>(k) = m.pos[k]; p->mNormalVector.at<float>(k) = m.nrm[k]; }
+            p->mDescriptor = cv::Mat(1, 32, CV_8U);
+            memcpy(p->mDescriptor.data, m.desc, 32);
+            p->mfMinDistance = m.minD; p->mfMaxDistance = m.maxD; p->nObs = m.nObs;
+            p->mbTrackInView = m.inView != 0; p->mTrackProjX = m.px; p->mTrackProjY = m.py; p->mTrackProjXR = m.pxr;
+            p->mnTrackScaleLevel = m.lvl; p->mTrackViewCos = m.vcos;
+            mp.push_back(p);
+        }
+        auto frame = [&](Frame& f, int n, const std::vector<cv::KeyPoint>& k, const cv::Mat& d, const std::vector<float>& ur,
+                         const std::vector<int>& node, const cv::Mat& T) {
+            f.N = n; f.mvKeys = f.mvKeysUn = k; f.mDescriptors = d.clone(); f.mvuRight = ur; f.mvDepth.assign(n, -1.f);
+            f.mvpMapPoints.assign(n, nullptr); f.mvbOutlier.assign(n, false); f.mTcw = T.clone();
+            f.fx = S.fx; f.fy = S.fy; f.cx = S.cx; f.cy = S.cy; f.mb = S.mb; f.mbf = S.mbf; f.mfLogScaleFactor = S.logSF;
+            f.mvScaleFactors = S.sf; f.mvInvLevelSigma2 = S.isig2;
+            for (int i = 0; i < n; i++)
+                if (node[i] >= 0) f.mFeatVec[(unsigned)node[i]].push_back((unsigned)i);
+        };
+        auto keyframe = [&](KeyFrame& kf, const Frame& f) {
+            kf.N = f.N; kf.mvKeysUn = f.mvKeysUn; kf.mvuRight = f.mvuRight; kf.mDescriptors = f.mDescriptors.clone(); kf.mFeatVec = f.mFeatVec;
+            kf.mvpMapPoints.assign(f.N, nullptr); kf.Tcw = f.mTcw.clone();
+            kf.fx = S.fx; kf.fy = S.fy; kf.cx = S.cx; kf.cy = S.cy; kf.mbf = S.mbf; kf.mfLogScaleFactor = S.logSF;
+            kf.mvScaleFactors = S.sf; kf.mvLevelSigma2 = S.sig2; kf.mvInvLevelSigma2 = S.isig2;
+            kf.mnMinX = (int)S.minX; kf.mnMinY = (int)S.minY; kf.mnMaxX = (int)S.maxX; kf.mnMaxY = (int)S.maxY;
+            kf.mfGridElementWidthInv = S.gwi; kf.mfGridElementHeightInv = S.ghi;
+        };
+        frame(fA, S.nA, S.kpA, S.dA, S.urA, S.nodeA, S.TcwA);
+        frame(fB, S.nB, S.kpB, S.dB, S.urB, S.nodeB, S.TcwB);
+        keyframe(kA, fA);
+        keyframe(kB, fB);
+        for (int i = 0; i < S.nA; i++) fA.mvbOutlier[i] = S.outlierA[i] != 0;
+        for (int i = 0; i < S.nMP; i++) {
+            const Scene::MP& m = S.mps[i];
+            if (m.idxA >= 0) { fA.mvpMapPoints[m.idxA] = mp[i]; kA.mvpMapPoints[m.idxA] = mp[i]; mp[i]->mObservations[&kA] = m.idxA; }
+            if (m.idxB >= 0) { fB.mvpMapPoints[m.idxB] = mp[i]; kB.mvpMapPoints[m.idxB] = mp[i]; mp[i]->mObservations[&kB] = m.idxB; }
+        }
+    }
+    int indexOf(MapPoint* p) const
+    {
+        if (!p) return -1;
+        for (size_t i = 0; i < mp.size(); i++)
+            if (mp[i] == p) return (int)i;
+        return -2;
+    }
+    std::vector<int> indices(const std::vector<MapPoint*>& v) const
+    {
+        std::vector<int> o(v.size());
+        for (size_t i = 0; i < v.size(); i++) o[i] = indexOf(v[i]);
+        return o;
+    }
+};
+static void dumpQueries(const std::string& p)
+{
+    const std::vector<orb_proj_query>& q = hipshim::LastProjectionQueries();
+    dump(p, q.data(), q.size() * sizeof(orb_proj_query));
+}
+static void dumpInts(const std::string& p, const std::vector<int>& v) { dump(p, v.data(), v.size() * 4); }
+
+static int runExtra(const std::string& scenePath, const std::string& out)
+{
+    const Scene S = loadScene(slurp(scenePath));
+    std::vector<int> counts;
+    {   // 1: local-map tracking, src/ORBmatcher.cc:73-157
+        World W(S);
+        ORBmatcher m(0.8f, true);
+        counts.push_back(m.SearchByProjection(W.fB, W.mp, 3.0f));
+        dumpQueries(out + ".q1");
+        dumpInts(out + ".r1", W.indices(W.fB.mvpMapPoints));
+    }
+    {   // 2: motion model, :160-300
+        World W(S);
+        ORBmatcher m(0.9f, true);
+        counts.push_back(m.SearchByProjection(W.fB, W.fA, 15.0f, false));
+        dumpQueries(out + ".q2");
+        dumpInts(out + ".r2", W.indices(W.fB.mvpMapPoints));
+    }
+    {   // 3: relocalisation, :303-440 (MapPoints 0, 3, 6, ... already found)
+        World W(S);
+        ORBmatcher m(0.9f, true);
+        std::set<MapPoint*> found;
+        for (size_t i = 0; i < W.mp.size(); i += 3) found.insert(W.mp[i]);
+        counts.push_back(m.SearchByProjection(W.fB, &W.kA, found, 10.0f, 90));
+        dumpQueries(out + ".q3");
+        dumpInts(out + ".r3", W.indices(W.fB.mvpMapPoints));
+    }
+    {   // 4: loop closing, :443-550
+        World W(S);
+        ORBmatcher m(0.75f, true);
+        std::vector<MapPoint*> matched = W.kB.mvpMapPoints;
+        counts.push_back(m.SearchByProjection(&W.kB, S.Scw, W.mp, matched, 10));
+        dumpQueries(out + ".q4");
+        dumpInts(out + ".r4", W.indices(matched));
+    }
+    {   // 5: Fuse, :1364-1480
+        World W(S);
+        ORBmatcher m;
+        counts.push_back(m.Fuse(&W.kB, W.mp, 3.0f));
+        dumpQueries(out + ".q5");
+        dumpInts(out + ".r5", W.indices(W.kB.mvpMapPoints));
+        std::vector<int> rep(W.mp.size());
+        for (size_t i = 0; i < W.mp.size(); i++) rep[i] = W.indexOf(W.mp[i]->mpReplaced);
+        dumpInts(out + ".r5rep", rep);
+    }
+    {   // 6: Fuse with a Sim3 pose, :1483-1633
+        World W(S);
+        ORBmatcher m;
+        std::vector<MapPoint*> rep(W.mp.size(), nullptr);
+        counts.push_back(m.Fuse(&W.kB, S.Scw, W.mp, 4.0f, rep));
+        dumpQueries(out + ".q6");
+        dumpInts(out + ".r6", W.indices(W.kB.mvpMapPoints));
+        dumpInts(out + ".r6rep", W.indices(rep));
+    }
+    {   // 7: SearchBySim3, :835-1025
+        World W(S);
+        ORBmatcher m(0.75f, true);
+        std::vector<MapPoint*> m12(W.kA.N, nullptr);
+        for (int i = 0; i < W.kA.N; i += 11)                                   // a few matches known beforehand (:862-873)
+            if (W.kA.mvpMapPoints[i]) m12[i] = W.kA.mvpMapPoints[i];
+        counts.push_back(m.SearchBySim3(&W.kA, &W.kB, m12, S.s12, S.R12, S.t12, 7.5f));
+        dumpQueries(out + ".q7");                                             // (the second direction's queries)
+        dumpInts(out + ".r7", W.indices(m12));
+    }
+    {   // 8: SearchForTriangulation, :1183-1359
+        World W(S);
+        ORBmatcher m(0.6f, false);
+        std::vector<std::pair<size_t, size_t> > pairs;
+        counts.push_back(m.SearchForTriangulation(&W.kA, &W.kB, S.F12, pairs, false));
+        std::vector<int> flat;
+        for (size_t i = 0; i < pairs.size(); i++) { flat.push_back((int)pairs[i].first); flat.push_back((int)pairs[i].second); }
+        dumpInts(out + ".r8", flat);
+        float e[2];
+        hipshim::LastEpipole(&e[0], &e[1]);
+        dump(out + ".epi", e, 8);
+    }
+    {   // 9: Frame::ComputeBoW, src/Frame.cc:425-433, on a k = 3, L = 5 vocabulary built from the scene's descriptors
+        World W(S);
+        ORBVocabulary voc;
+        voc.m_k = 3; voc.m_L = 5;
+        std::vector<DBoW2::Vocabulary::Node>& nodes = voc.m_nodes_public_for_the_test_driver;
+        const int nInner = 1 + 3 + 9 + 27 + 81, nNodes = nInner + 243;
+        nodes.resize(nNodes);
+        unsigned word = 0;
+        for (int i = 0; i < nNodes; i++) {
+            nodes[i].id = (unsigned)i;
+            nodes[i].descriptor = cv::Mat(1, 32, CV_8U);
+            memcpy(nodes[i].descriptor.data, S.dA.ptr<unsigned char>((i * 7) % S.nA), 32);
+            if (i >= 1) nodes[i].parent = (unsigned)((i - 1) / 3);
+            if (i < nInner) for (int c = 0; c < 3; c++) nodes[i].children.push_back((unsigned)(3 * i + 1 + c));
+            else { nodes[i].word_id = word++; nodes[i].weight = (word % 5 == 0) ? 0.0 : 0.25 + 0.01 * (word % 17); }
+        }
+        W.fB.mpORBvocabulary = &voc;
+        W.fB.mFeatVec.clear();                                               // a new Frame: ComputeBoW fills both containers
+        W.fB.ComputeBoW();
+        std::vector<int> bowIds, fvFlat;
+        std::vector<double> bowVals;
+        for (DBoW2::BowVector::const_iterator it = W.fB.mBowVec.begin(); it != W.fB.mBowVec.end(); ++it) { bowIds.push_back((int)it->first); bowVals.push_back(it->second); }
+        for (DBoW2::FeatureVector::const_iterator it = W.fB.mFeatVec.begin(); it != W.fB.mFeatVec.end(); ++it)
+            for (size_t k = 0; k < it->second.size(); k++) { fvFlat.push_back((int)it->first); fvFlat.push_back((int)it->second[k]); }
+        dumpInts(out + ".bowids", bowIds);
+        dump(out + ".bowvals", bowVals.data(), bowVals.size() * 8);
+        dumpInts(out + ".fv", fvFlat);
+        counts.push_back((int)bowIds.size());
+    }
+    dumpInts(out + ".counts", counts);
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
     if (argc < 2) return 2;
@@ -89,6 +330,28 @@ int main(int argc, char** argv)
         cv::Mat d2;
         (*ex)(none, cv::Mat(), k2, d2);                                    // empty image: silent return
         delete ex;
+        return 0;
+    }
+    if (mode == "extra") return runExtra(argv[2], argv[3]);
+    if (mode == "stereo") {
+        std::vector<unsigned char> rawL = slurp(argv[2]), rawR = slurp(argv[3]);
+        const int W = atoi(argv[4]), H = atoi(argv[5]), nf = atoi(argv[6]);
+        const std::string out = argv[9];
+        Frame f;
+        f.mb = (float)atof(argv[7]); f.mbf = (float)atof(argv[8]);
+        f.mpORBextractorLeft = new ORBextractor(nf, 1.2f, 8, 20, 7);          // Tracking.cc:117-120
+        f.mpORBextractorRight = new ORBextractor(nf, 1.2f, 8, 20, 7);
+        cv::Mat imL(H, W, CV_8UC1, rawL.data(), (size_t)W), imR(H, W, CV_8UC1, rawR.data(), (size_t)W);
+        (*f.mpORBextractorLeft)(imL, cv::Mat(), f.mvKeys, f.mDescriptors);     // Frame.cc:82-85 (two threads there)
+        (*f.mpORBextractorRight)(imR, cv::Mat(), f.mvKeysRight, f.mDescriptorsRight);
+        f.N = (int)f.mvKeys.size();
+        f.ComputeStereoMatches();                                              // Frame.cc:91
+        dump(out + ".kl", f.mvKeys.data(), f.mvKeys.size() * 28);
+        dump(out + ".kr", f.mvKeysRight.data(), f.mvKeysRight.size() * 28);
+        dump(out + ".dl", f.mDescriptors.data, (size_t)f.mDescriptors.rows * 32);
+        dump(out + ".dr", f.mDescriptorsRight.data, (size_t)f.mDescriptorsRight.rows * 32);
+        dump(out + ".ur", f.mvuRight.data(), f.mvuRight.size() * 4);
+        dump(out + ".depth", f.mvDepth.data(), f.mvDepth.size() * 4);
         return 0;
     }
     if (mode == "match") {

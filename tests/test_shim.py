@@ -23,7 +23,8 @@ def build_driver():
     cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-I" + SUP, "-I" + os.path.join(SUP, "mini_slam"),
            "-I" + os.path.join(PKG, "host"), "-I" + os.path.join(ROOT, "include"),
            os.path.join(SUP, "shim_driver.cpp"), os.path.join(PKG, "host", "ORBextractor.cc"),
-           os.path.join(PKG, "host", "ORBmatcherHip.cc"), "-L" + PKG, "-lorbhip", "-Wl,-rpath," + PKG, "-o", DRIVER]
+           os.path.join(PKG, "host", "ORBmatcherHip.cc"), os.path.join(PKG, "host", "ORBmatcherHipExtra.cc"),
+           os.path.join(PKG, "host", "FrameHip.cc"), "-L" + PKG, "-lorbhip", "-Wl,-rpath," + PKG, "-o", DRIVER]
     subprocess.check_call(cmd)
     return DRIVER
 
@@ -161,3 +162,260 @@ def test_matcher_shim_matches_oracle(tmp_path):
     assert np.array_equal(np.fromfile(out + ".bowkk", dtype=np.int32), mb)
     assert np.array_equal(np.fromfile(out + ".init", dtype=np.int32), mc)
     assert np.fromfile(out + ".prev", dtype=np.float32).tobytes() == prev.tobytes()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The optional bindings as COMPILED code: host/ORBmatcherHipExtra.cc (SearchByProjection x4, Fuse x2,
+# SearchBySim3, SearchForTriangulation) and host/FrameHip.cc (Frame::ComputeStereoMatches, Frame::ComputeBoW), built
+# against the extended test doubles and driven by tests/support/shim_driver.cpp the way Tracking / LocalMapping / LoopClosing
+# call them.  The shims keep the reference's projection arithmetic on the host and hand one orb_proj_query per MapPoint to
+# the GPU; the driver dumps those queries, and the oracle -- fed the same queries -- must give the same assignments.
+def _extra_scene(tmp_path, seed=1):
+    rng = np.random.default_rng(seed)
+    W, H, nf = 640, 480, 800
+    ex = capi.Extractor(nf)
+    imgs = synth.synth_sequence(40, 2, W, H)                       # view 0 and view 1 of one scene (shift of (1, 2) px)
+    (kA, dA), (kB, dB) = ex.extract(imgs[0]), ex.extract(imgs[1])
+    ex.close()
+    nA, nB = len(kA), len(kB)
+    fx, fy, cx, cy = 520.0, 520.0, 320.0, 240.0
+    mbf, mb = 40.0, 40.0 / 520.0
+    sf = (np.float32(1.2) ** np.arange(8)).astype(np.float32)
+    sig2, isig2 = (sf * sf).astype(np.float32), (np.float32(1.0) / (sf * sf)).astype(np.float32)
+    grid = (0.0, 0.0, 64.0 / W, 48.0 / H)
+    urA = np.where(rng.random(nA) < 0.5, kA["x"] - rng.uniform(3, 30, nA), -1).astype(np.float32)
+    urB = np.where(rng.random(nB) < 0.5, kB["x"] - rng.uniform(3, 30, nB), -1).astype(np.float32)
+    tree = synth.synth_vocab_tree_balanced(6, 3, seed=4)
+    nodeA = oracle.vocab_transform(tree, dA, 2)[1].astype(np.int32)
+    nodeB = oracle.vocab_transform(tree, dB, 2)[1].astype(np.int32)
+    TcwA = np.eye(4, dtype=np.float32)
+    TcwB = np.eye(4, dtype=np.float32)
+    TcwB[:3, 3] = [-0.02, -0.01, 0.15]                              # camera centre of B at z = -0.15, more than the baseline behind A: bBackward
+    Scw = TcwB.copy()
+    Scw[:3, :] *= np.float32(1.05)
+    F12 = np.array([[0, 0, 0.0004], [0, 0, -1.0], [-0.0003, 1.0, 0.2]], np.float32)
+    s12, R12, t12 = np.float32(0.97), np.eye(3, dtype=np.float32), np.array([0.02, 0.01, -0.1], np.float32)
+    # MapPoints: two thirds of A's features back-projected at random depths (so they project near their counterpart in B)
+    sel = np.nonzero(rng.random(nA) < 0.66)[0]
+    mps = []
+    idxB_used = set()
+    for j, i in enumerate(sel):
+        z = float(rng.uniform(2.0, 12.0))
+        pos = np.array([(kA["x"][i] - cx) * z / fx, (kA["y"][i] - cy) * z / fy, z], np.float32)
+        nrm = pos / np.linalg.norm(pos)                              # mean viewing direction, camera -> point (src/MapPoint.cc:376-386)
+        lvl = int(kA["octave"][i])
+        mind, maxd = z / 1.2 ** (7 - lvl) * 0.7, z * 1.2 ** lvl * 1.3
+        if rng.random() < 0.05:
+            mind, maxd = 50.0, 60.0                                  # fails the distance gate
+        idxB = -1
+        if rng.random() < 0.25:                                      # also observed in B (some feature of B)
+            c = int(rng.integers(0, nB))
+            if c not in idxB_used:
+                idxB, _ = c, idxB_used.add(c)
+        mps.append(dict(pos=pos, nrm=nrm.astype(np.float32), desc=dA[i], minD=mind, maxD=maxd, nObs=int(rng.integers(0, 4)),
+                        bad=int(rng.random() < 0.04), inView=int(rng.random() < 0.9),
+                        px=float(kA["x"][i] + 2 + rng.uniform(-2, 2)), py=float(kA["y"][i] + 1 + rng.uniform(-2, 2)),
+                        pxr=float(kA["x"][i] - rng.uniform(3, 30)), lvl=lvl, vcos=float(rng.choice([0.9995, 0.9])),
+                        idxA=int(i), idxB=idxB))
+    outlierA = (rng.random(nA) < 0.05).astype(np.uint8)
+    b = struct.pack("<3i13f", nA, nB, len(mps), fx, fy, cx, cy, mbf, mb, 0.0, float(W), 0.0, float(H), grid[2], grid[3],
+                    float(np.log(np.float32(1.2))))
+    b += sf.tobytes() + sig2.tobytes() + isig2.tobytes()
+    for k, d, ur, node in ((kA, dA, urA, nodeA), (kB, dB, urB, nodeB)):
+        b += k.tobytes() + np.ascontiguousarray(d).tobytes() + ur.tobytes() + node.tobytes()
+    b += TcwA.tobytes() + TcwB.tobytes() + Scw.tobytes() + F12.tobytes() + struct.pack("<f", float(s12)) + R12.tobytes() + t12.tobytes()
+    for m in mps:
+        b += m["pos"].tobytes() + m["nrm"].tobytes() + np.ascontiguousarray(m["desc"]).tobytes()
+        b += struct.pack("<2f3i3fif2i", m["minD"], m["maxD"], m["nObs"], m["bad"], m["inView"], m["px"], m["py"], m["pxr"], m["lvl"],
+                         m["vcos"], m["idxA"], m["idxB"])
+    b += outlierA.tobytes()
+    path = tmp_path / "extra_scene.bin"
+    path.write_bytes(b)
+    return dict(path=str(path), kA=kA, dA=dA, kB=kB, dB=dB, urA=urA, urB=urB, nodeA=nodeA, nodeB=nodeB, mps=mps, grid=grid, sf=sf,
+                sig2=sig2, isig2=isig2, F12=F12, outlierA=outlierA, tree=tree)
+
+
+@pytest.mark.gpu
+def test_optional_matcher_bindings_against_the_oracle(tmp_path):
+    build_driver()
+    S = _extra_scene(tmp_path)
+    out = str(tmp_path / "x")
+    subprocess.check_call([DRIVER, "extra", S["path"], out])
+    rd = lambda ext, dt=np.int32: np.fromfile(out + ext, dtype=dt)
+    counts = rd(".counts")
+    mps, kA, dA, kB, dB, urB, grid = S["mps"], S["kA"], S["dA"], S["kB"], S["dB"], S["urB"], S["grid"]
+    nMP, nA, nB = len(mps), len(kA), len(kB)
+    mp_desc = np.stack([m["desc"] for m in mps])
+    nobs = np.array([m["nObs"] for m in mps])
+    bad = np.array([m["bad"] for m in mps])
+    mpB = np.full(nB, -1)                                            # MapPoint attached to feature i of B
+    for j, m in enumerate(mps):
+        if m["idxB"] >= 0:
+            mpB[m["idxB"]] = j
+    mpA = np.full(nA, -1)
+    for j, m in enumerate(mps):
+        mpA[m["idxA"]] = j
+
+    def apply(cur, initial, q_to_mp):
+        res = initial.copy()
+        for i, c in enumerate(cur):
+            if c >= 0:
+                res[i] = q_to_mp[c]
+            elif c == -2:
+                res[i] = -1
+        return res
+
+    # 1: SearchByProjection(Frame, MapPoints): mode 1, ratio 0.8
+    q = rd(".q1", oracle.PROJ_DTYPE)
+    assert len(q) == nMP and (q["flags"] & 1).sum() > 0.6 * nMP
+    occ = np.array([mpB[i] >= 0 and nobs[mpB[i]] > 0 for i in range(nB)], np.uint8)
+    wn, w = oracle.search_by_projection(1, q, mp_desc, np.zeros(nMP, np.float32), kB, dB, urB, occ, grid, 0.8, False, 100)
+    assert counts[0] == wn and wn > 100
+    assert np.array_equal(rd(".r1"), apply(w, mpB, np.arange(nMP)))
+    # the projection handed over is the MapPoint's tracked projection and the window of :91-98
+    live = np.nonzero(q["flags"] & 1)[0]
+    assert np.allclose(q["x"][live], [mps[i]["px"] for i in live]) and np.all(q["max_level"][live] == [mps[i]["lvl"] for i in live])
+
+    # 2: SearchByProjection(CurrentFrame, LastFrame): mode 0, queries indexed by LastFrame feature
+    q = rd(".q2", oracle.PROJ_DTYPE)
+    assert len(q) == nA
+    qd = np.zeros((nA, 32), np.uint8); qd[mpA >= 0] = mp_desc[mpA[mpA >= 0]]
+    wn, w = oracle.search_by_projection(0, q, qd, kA["angle"], kB, dB, urB, occ, grid, 0.9, True, 100)
+    assert counts[1] == wn and wn > 100
+    assert np.array_equal(rd(".r2"), apply(w, mpB, mpA))
+    live = np.nonzero(q["flags"] & 1)[0]
+    assert np.all(q["min_level"][live] == 0) and np.all(q["max_level"][live] == kA["octave"][live])       # bBackward (:221-222)
+    assert not np.any(S["outlierA"][live]) and np.all(bad[mpA[live]] >= 0)
+    # the camera moved back by 0.15: a point at depth z projects to (x - cx) * z / (z + 0.15) ... within a few px
+    assert np.abs(q["x"][live] - kA["x"][live]).max() < 40 and np.abs(q["y"][live] - kA["y"][live]).max() < 40
+
+    # 3: SearchByProjection(CurrentFrame, KeyFrame, sAlreadyFound): mode 0, no stereo gate, ORBdist 90, every assignment blocks
+    q = rd(".q3", oracle.PROJ_DTYPE)
+    occ3 = (mpB >= 0).astype(np.uint8)
+    wn, w = oracle.search_by_projection(0, q, qd, kA["angle"], kB, dB, None, occ3, grid, 0.9, True, 90)
+    assert counts[2] == wn and wn > 50
+    assert np.array_equal(rd(".r3"), apply(w, mpB, mpA))
+    for i in np.nonzero(q["flags"] & 1)[0]:
+        assert mpA[i] % 3 != 0 and not bad[mpA[i]]                 # sAlreadyFound / isBad MapPoints never become queries
+
+    # 4: SearchByProjection(KeyFrame, Scw, points, matched): mode 0, TH_LOW, no orientation check
+    q = rd(".q4", oracle.PROJ_DTYPE)
+    wn, w = oracle.search_by_projection(0, q, mp_desc, np.zeros(nMP, np.float32), kB, dB, None, occ3, grid, 0.75, False, 50)
+    assert counts[3] == wn and wn > 30
+    assert np.array_equal(rd(".r4"), apply(w, mpB, np.arange(nMP)))
+    for i in np.nonzero(q["flags"] & 1)[0]:
+        assert not bad[i] and mps[i]["idxB"] < 0                   # points already matched in the KeyFrame are skipped (:461-470)
+
+    # 5: Fuse(KeyFrame, MapPoints): independent best candidates with the chi-square gates, then the map surgery
+    q = rd(".q5", oracle.PROJ_DTYPE)
+    bi, _ = oracle.search_by_projection_best(q, mp_desc, kB, dB, urB, grid, 50, True, S["isig2"])
+    assert counts[4] == (bi >= 0).sum() > 30
+    kf = mpB.copy(); rep = np.full(nMP, -1); obs = nobs.copy(); isbad = bad.copy()
+    for i in range(nMP):
+        if bi[i] < 0:
+            continue
+        other = kf[bi[i]]
+        if other >= 0:
+            if not isbad[other]:
+                if obs[other] > obs[i]:
+                    rep[i], isbad[i] = other, 1
+                else:
+                    rep[other], isbad[other] = i, 1
+        else:
+            kf[bi[i]] = i
+            obs[i] += 1
+    assert np.array_equal(rd(".r5"), kf) and np.array_equal(rd(".r5rep"), rep)
+
+    # 6: Fuse(KeyFrame, Scw, points, replace)
+    q = rd(".q6", oracle.PROJ_DTYPE)
+    bi, _ = oracle.search_by_projection_best(q, mp_desc, kB, dB, None, grid, 50, False, None)
+    assert counts[5] == (bi >= 0).sum() > 30
+    kf = mpB.copy(); rep = np.full(nMP, -1)
+    for i in range(nMP):
+        if bi[i] < 0:
+            continue
+        other = kf[bi[i]]
+        if other >= 0:
+            if not bad[other]:
+                rep[i] = other
+        else:
+            kf[bi[i]] = i
+    assert np.array_equal(rd(".r6"), kf) and np.array_equal(rd(".r6rep"), rep)
+
+    # 7: SearchBySim3: the dumped queries are the second direction's (MapPoints of KF2 into KF1); its result feeds the mutual check
+    q = rd(".q7", oracle.PROJ_DTYPE)
+    assert len(q) == nB
+    qd7 = np.zeros((nB, 32), np.uint8); qd7[mpB >= 0] = mp_desc[mpB[mpB >= 0]]
+    b21, _ = oracle.search_by_projection_best(q, qd7, kA, dA, None, grid, 100, False, None)
+    r7 = rd(".r7")
+    pre = np.full(nA, -1)
+    pre[::11] = np.where(mpA[::11] >= 0, mpA[::11], -1)
+    assert counts[6] == ((r7 >= 0) & (pre < 0)).sum()
+    for i1 in np.nonzero((r7 >= 0) & (pre < 0))[0]:                # every new match is mutual: KF2's feature points back at i1
+        i2 = np.nonzero(mpB == r7[i1])[0]
+        assert len(i2) == 1 and b21[i2[0]] == i1
+
+    # 8: SearchForTriangulation
+    fv1, fv2 = oracle.featvec_from_nodes(S["nodeA"]), oracle.featvec_from_nodes(S["nodeB"])
+    epi = rd(".epi", np.float32)
+    wn, wm = oracle.search_for_triangulation(kA, dA, (mpA >= 0).astype(np.uint8), S["urA"], fv1, kB, dB, (mpB >= 0).astype(np.uint8), urB,
+                                             fv2, S["F12"], epi[0], epi[1], S["sf"], S["sig2"], False, False)
+    pairs = rd(".r8").reshape(-1, 2)
+    assert counts[7] == wn == len(pairs)
+    assert np.array_equal(pairs[:, 0], np.nonzero(wm >= 0)[0]) and np.array_equal(pairs[:, 1], wm[wm >= 0])
+
+    # 9: Frame::ComputeBoW: words / nodes from the oracle's descent of the same k = 3, L = 5 tree, weights and L1 norm as DBoW2
+    n_inner = 1 + 3 + 9 + 27 + 81
+    nn = n_inner + 243
+    node_desc = np.stack([dA[(i * 7) % nA] for i in range(nn)])
+    child_begin = np.zeros(nn + 1, np.int32)
+    children = []
+    word_id = np.full(nn, -1, np.int32)
+    weight = {}
+    wcount = 0
+    for i in range(nn):
+        if i < n_inner:
+            children += [3 * i + 1 + c for c in range(3)]
+        else:
+            word_id[i] = wcount
+            wcount += 1
+            weight[word_id[i]] = 0.0 if wcount % 5 == 0 else 0.25 + 0.01 * (wcount % 17)
+        child_begin[i + 1] = len(children)
+    tree = dict(node_desc=node_desc, child_begin=child_begin, children=np.array(children, np.int32), word_id=word_id, L=5)
+    words, nodes = oracle.vocab_transform(tree, dB, 4)             # levelsup = 4 (Frame.cc:431): the level-1 nodes
+    bow, fv = {}, []
+    for i in range(nB):
+        w = weight[int(words[i])]
+        if w > 0:
+            bow[int(words[i])] = bow.get(int(words[i]), 0.0) + w
+            fv.append((int(nodes[i]), i))
+    tot = sum(bow.values())
+    ids = rd(".bowids")
+    vals = rd(".bowvals", np.float64)
+    assert counts[8] == len(ids) == len(bow) and list(ids) == sorted(bow)
+    assert np.allclose(vals, [bow[k] / tot for k in sorted(bow)], rtol=1e-12)
+    got_fv = rd(".fv").reshape(-1, 2)
+    assert sorted(map(tuple, got_fv.tolist())) == sorted(fv) and np.all(np.diff(got_fv[:, 0]) >= 0)
+
+
+@pytest.mark.gpu
+def test_frame_compute_stereo_matches_binding(tmp_path):
+    """host/FrameHip.cc: Frame::ComputeStereoMatches through the two extractor shims' device-resident pyramids."""
+    build_driver()
+    W, H, nf = 640, 480, 700
+    left, right = synth.synth_frame(21, W, H), synth.synth_stereo_right(21, W, H)
+    (tmp_path / "l.raw").write_bytes(left.tobytes())
+    (tmp_path / "r.raw").write_bytes(right.tobytes())
+    out = str(tmp_path / "s")
+    mbf, mb = 386.1448, 386.1448 / 718.856
+    subprocess.check_call([DRIVER, "stereo", str(tmp_path / "l.raw"), str(tmp_path / "r.raw"), str(W), str(H), str(nf), repr(mb), repr(mbf), out])
+    kl, kr = np.fromfile(out + ".kl", oracle.KP_DTYPE), np.fromfile(out + ".kr", oracle.KP_DTYPE)
+    dl, dr = np.fromfile(out + ".dl", np.uint8).reshape(-1, 32), np.fromfile(out + ".dr", np.uint8).reshape(-1, 32)
+    rl, rr = oracle.Extractor(nf), oracle.Extractor(nf)
+    okl, odl = rl.extract(left)
+    okr, odr = rr.extract(right)
+    assert kl.tobytes() == okl.tobytes() and kr.tobytes() == okr.tobytes() and np.array_equal(dl, odl) and np.array_equal(dr, odr)
+    wu, wz = oracle.stereo_matches(rl, rr, okl, odl, okr, odr, np.float32(mb), np.float32(mbf))
+    assert np.fromfile(out + ".ur", np.float32).tobytes() == wu.tobytes()
+    assert np.fromfile(out + ".depth", np.float32).tobytes() == wz.tobytes()
+    assert (wu >= 0).sum() > 100
