@@ -413,8 +413,9 @@ extern "C" int orb_extract_batch_device(orb_extractor* h, const uint8_t* d_imgs,
     // (also clears the status block behind the sticky word -- error flags, counters, overflow list head -- and spreads the
     // int8 BRIEF pattern into the float table the descriptor kernel reads)
     if (!h->pyrChains.empty()) {
-        // a handful of frames cannot fill the chip with 16-row bands (21 workgroups per frame at 640x480): 4-row bands
-        const std::vector<OrbPyrChain>& chains = n <= 8 ? h->pyrChainsLat : h->pyrChains;
+        // small batches cannot fill the chip with 16-row bands (21 workgroups per frame at 640x480, 5 resident per CU):
+        // below ~10 workgroups per CU the 4-row bands (4x the workgroups, each a quarter as long) finish sooner
+        const std::vector<OrbPyrChain>& chains = (long long)h->pyrChains[0].bands * n < 2560 ? h->pyrChainsLat : h->pyrChains;
         for (size_t c = 0; c < chains.size(); c++)
             orb_launch_pyr_chain(st, chains[c], d_imgs, rowStride, frameStride, pyr, h->pyrSlab, (const uint4*)h->dXq.p,
                                  (const int2*)h->dYtab.p, (const int2*)h->dBand.p, n, c == 0 ? h->errP() : nullptr,
