@@ -285,8 +285,8 @@ typedef struct orb_featstore {
 int orb_bow_build_csr_device(orb_matcher* m, const uint16_t* d_node_of, const int32_t* d_counts, int n_frames, int cap,
                              int n_nodes, uint32_t* d_keys, uint16_t* d_start, uint16_t* d_cnt);
 
-/* Vocabulary stand-in (DBoW2 transform(...,4) of reference src/Frame.cc:431 is
- * OUT OF SCOPE this round): 2-level k=10 tree, centroids = 110 x 32 bytes (device pointer).
+/* Vocabulary stand-in of SURVEY 8d (the full DBoW2 descent is orb_bow_transform* below): 2-level k=10 tree,
+ * centroids = 110 x 32 bytes (device pointer).
  * Fills node_of[f*cap + i] = 11 + 10*c1 + c2 for every feature of every frame. */
 int orb_bow_assign_device(orb_matcher* m, const uint8_t* d_desc, const int32_t* d_counts, int n_frames,
                           int cap, const uint8_t* d_centroids_110x32, uint16_t* d_node_of);
@@ -355,7 +355,8 @@ int orb_stereo_match_device(orb_extractor* left, orb_extractor* right, int frame
  * redone by the dense kernel (same results, more time), and how many strips a frame has on that level.  The library
  * shortens the strips of a level that overflows: at every orb_extractor_sync / host call, and -- for device pipelines
  * that never synchronise the handle -- from counters that every fourth orb_extract_batch_device leaves in pinned memory
- * behind an event and a later call picks up once they have arrived (no blocking). */
+ * behind an event and a later call picks up once they have arrived (picking them up never waits; a call that thereby
+ * shortens a level's strips rebuilds the strip table, which ends in one hipStreamSynchronize of the handle's stream). */
 int orb_get_fast_overflows(orb_extractor* h, int32_t* overflowed, int32_t* strips_per_frame);
 
 /* The whole pyramid of device-resident frame `frame` of the last batch with ONE device-to-host copy and one
