@@ -94,6 +94,13 @@ def parse():
     ap.add_argument("--content", default="shapes", choices=["shapes", "natural"],
                     help="synthetic frame content: drawn rectangles + discs + noise (SURVEY 8d, default) or natural image statistics "
                          "(1/f texture, occluding objects, blur, illumination ramp: orbhip.synth.synth_natural)")
+    ap.add_argument("--c3-one-handle", action="store_true",
+                    help="config c3: ONE batch of 2 S frames (left views, then right views) through one extractor handle instead of two "
+                         "handles on two streams (the default, the shape of the reference's two threads, src/Frame.cc:82-85; measured: "
+                         "156 k frames/s with two handles, 144 k with one -- the two chains overlap each other's latency-bound kernels)")
+    ap.add_argument("--stream-frames", type=int, default=256,
+                    help="config c5: distinct stream frames resident in HBM that the timed steps walk through (3682 = the whole "
+                         "EuRoC MH01-sized sequence of BASELINE configs[4]; generating them on the host takes about a minute)")
     ap.add_argument("--no-match", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=200, help="timed frames of the single-thread cpu_baseline (+10 warm-up)")
@@ -609,7 +616,22 @@ def run_c3(args, rank, local_rank, world, dev, comm_dev, dist):
     ur, dp = buf(S * cap, torch.float32), buf(S * cap, torch.float32)
     torch.cuda.synchronize()
 
+    one = args.c3_one_handle
+    if one:
+        # ONE batch [L0 .. L(S-1), R0 .. R(S-1)] through one handle; pair p = frames (p, S + p) of that batch
+        d_lr = torch.cat([d_l, d_r])
+        k2, d2, c2 = buf(2 * S * cap * 28, torch.uint8), buf(2 * S * cap * 32, torch.uint8), buf(2 * S, torch.int32)
+        kl, kr = k2[:S * cap * 28], k2[S * cap * 28:]
+        dl, dr = d2[:S * cap * 32], d2[S * cap * 32:]
+        cl, cr = c2[:S], c2[S:]
+        exr = exl
+
     def step():
+        if one:
+            exl.extract_batch_device(d_lr.data_ptr(), 2 * S, H, W, W, W * H, k2.data_ptr(), d2.data_ptr(), cap, c2.data_ptr())
+            capi.stereo_match_batch_device(exl, exl, 0, S, S, kl.data_ptr(), dl.data_ptr(), cl.data_ptr(), kr.data_ptr(), dr.data_ptr(),
+                                           cr.data_ptr(), cap, MB, MBF, ur.data_ptr(), dp.data_ptr())
+            return
         exl.extract_batch_device(d_l.data_ptr(), S, H, W, W, W * H, kl.data_ptr(), dl.data_ptr(), cap, cl.data_ptr())
         exr.extract_batch_device(d_r.data_ptr(), S, H, W, W, W * H, kr.data_ptr(), dr.data_ptr(), cap, cr.data_ptr())
         # all S pairs in one launch; the keypoint counts stay on the device (no host round trip inside a step)
@@ -647,15 +669,15 @@ def run_c3(args, rank, local_rank, world, dev, comm_dev, dist):
     bytes_img = algorithmic_bytes_per_frame(W, H, pyr_px, mean_kp)
     # per pair: both extractions + the stereo search's reads (both keypoint/descriptor sets, 11x(2L+11)-px SAD bands)
     bytes_pair = 2 * bytes_img + int(nl.mean() + nr.mean()) * 60 + int(nl.mean()) * 2 * 11 * 21
-    rf, rv = roofline_blocks(stage_ms, S, bytes_img, float(stage_ms[4]))
+    rf, rv = roofline_blocks(stage_ms, 2 * S if one else S, bytes_img, float(stage_ms[4]))
     rf["algorithmic_bytes_per_pair"] = int(bytes_pair)
     out = {"metric": "frames/sec ORB extract + stereo search, 1241x376 stereo pairs, 8-level 2000-feat; HBM GB/s vs peak",
            "value": round(2 * pairs / elapsed, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "u8", "data": "synthetic",
            "config": {"workload": "BASELINE configs[2]: %d synthetic KITTI-sized stereo pairs (1241x376, disparity 12+8*floor(y/94), "
-                                  "nFeatures 2000) per step: extract left + right, ComputeStereoMatches of all pairs (one launch) on the "
-                                  "device pyramids" % S, "pairs_per_step": S, "pairs_per_s": round(pairs / elapsed, 2),
+                                  "nFeatures 2000) per step: extract left + right%s, ComputeStereoMatches of all pairs (one launch) on the "
+                                  "device pyramids" % (S, " as ONE batch of 2 S frames through one handle" if one else " through two handles on two streams"), "pairs_per_step": S, "pairs_per_s": round(pairs / elapsed, 2),
                       "ms_per_pair": round(elapsed / (pairs / world) * 1e3, 4), "mean_keypoints_left": round(mean_kp, 1),
                       "mean_stereo_matches": round(float((u[:, :] >= 0).sum() / S), 1),
                       "stage_ms_per_launch_left_handle": {n: round(float(v), 4) for n, v in zip(STAGES + ["extract_total"], stage_ms)}},
@@ -721,9 +743,11 @@ def run_c5(args, rank, local_rank, world, dev, comm_dev, dist):
     mt.build_csr_device(d_node.data_ptr(), d_counts.data_ptr(), n_kf, cap, n_nodes, d_ckeys.data_ptr(), d_cstart.data_ptr(),
                         d_ccnt.data_ptr())
     mt.sync()
-    n_q = 16
+    n_q = max(16, args.stream_frames)
     q_first = 3 + 8 * (rank % 100)
-    stream_np = np.stack([synth.synth_sequence(q_first + 61 * i, 1, W, H, noise=5)[0] for i in range(n_q)])
+    # the stream: 8 consecutive views of a scene of the DB (other noise), then a hop to another scene
+    stream_np = np.concatenate([synth.synth_sequence(8 * ((q_first + 61 * g) % (n_kf // 8)), 8, W, H, noise=5)
+                                for g in range((n_q + 7) // 8)])[:n_q]
     stream = torch.from_numpy(stream_np).to(dev)
     Q = [1]                                                       # stream frames per step (1 = the per-frame configuration)
     kf_idx = torch.arange(n_kf, dtype=torch.int32, device=dev).repeat(QMAX)
@@ -738,7 +762,7 @@ def run_c5(args, rank, local_rank, world, dev, comm_dev, dist):
     def extract(i):                                # stream frames i*Q .. i*Q+Q-1 -> query slot i % 2
         s, q = i % 2, Q[0]
         f0 = n_kf + s * QMAX
-        ex.extract_batch_device(stream.data_ptr() + ((i * q) % n_q) * W * H, q, H, W, W, W * H, d_kps.data_ptr() + f0 * cap * 28,
+        ex.extract_batch_device(stream.data_ptr() + ((i * q) % (n_q - q + 1)) * W * H, q, H, W, W, W * H, d_kps.data_ptr() + f0 * cap * 28,
                                 d_desc.data_ptr() + f0 * cap * 32, cap, d_counts.data_ptr() + f0 * 4)
 
     def match(i):
@@ -809,6 +833,7 @@ def run_c5(args, rank, local_rank, world, dev, comm_dev, dist):
                                   "a %d-keyframe DB in HBM (moving-camera sequence of 125 scenes x 8 views; the stream revisits "
                                   "them)" % n_kf, "pair_matchings_per_s": round(n_kf * done / elapsed, 0),
                       "mean_matches_per_pair": round(float(nm.mean()), 2), "max_matches_per_pair": int(nm.max()),
+                      "distinct_stream_frames": n_q,
                       "frames_per_s_in_mini_batches_of_%d" % QMAX: round(mini_fps, 1),
                       "transform_plus_match_ms_alone": round(match_ms, 4)},
            "roofline": {"bound": "hbm", "kernel": "k_match_bow (+ k_vocab_transform of the query)", "achieved": round(ach, 2),
