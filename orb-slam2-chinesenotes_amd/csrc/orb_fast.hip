@@ -583,17 +583,31 @@ __global__ __launch_bounds__(WAVE) void k_fast_strips_p(const OrbGeom G, const u
         const unsigned aEnd = (unsigned)(TB + zh * ROWB - 4);       // windows of zone rows start below this address (quad - 1 >= -1)
         int cntA = 0, cntB = 0, headA = 0, headB = 0;               // wave-uniform ring state
         constexpr unsigned kRowMagic = (unsigned)(((1ull << 32) + ROWB - 1) / ROWB);   // floor(a / ROWB) for a < 2^16
-        auto bstep = [&](auto Htag, const uint16_t* ring, int head, int n) {
+        // Htag 0 / 1: n entries of ring A (left pairs of their quads) / ring B (right pairs).  Htag 2: the LAST step of a strip,
+        // the remainders of both rings at once -- lanes [0, n) take ring A, lanes [n, n + nB2) ring B with their windows
+        // shifted down by two bytes, so that every lane scores the pair at window bytes 4, 5 (21 extra instructions once per
+        // strip instead of a second, mostly empty step of ~124)
+        auto bstep = [&](auto Htag, const uint16_t* ring, int head, int n, int nB2) {
             constexpr int H = decltype(Htag)::value;
-            const bool act = lane < n;
+            const bool fromB = H == 2 && lane >= n;
+            const bool act = lane < n + (H == 2 ? nB2 : 0);
             unsigned s2 = 0, a = 0;
             if (act) {
-                a = ring[(head + lane) & (F2_RING - 1)];
+                a = fromB ? ringB[(headB + lane - n) & (F2_RING - 1)] : ring[(head + lane) & (F2_RING - 1)];
                 const orb_lds_u32* p = lds_dw(a);
                 unsigned W[7][3];
 #pragma unroll
                 for (int r = 0; r < 7; r++) { W[r][0] = p[r * P]; W[r][1] = p[r * P + 1]; W[r][2] = p[r * P + 2]; }
-                s2 = H ? fast_pair<6>(W) : fast_pair<4>(W);         // two scores, one per 16-bit half
+                if (H == 2) {
+                    const unsigned shB = fromB ? 2u : 0u;
+#pragma unroll
+                    for (int r = 0; r < 7; r++) {
+                        W[r][0] = __builtin_amdgcn_alignbyte(W[r][1], W[r][0], shB);
+                        W[r][1] = __builtin_amdgcn_alignbyte(W[r][2], W[r][1], shB);
+                        W[r][2] >>= 8u * shB;
+                    }
+                }
+                s2 = H == 1 ? fast_pair<6>(W) : fast_pair<4>(W);    // two scores, one per 16-bit half
             }
             const int sLo = (int)(s2 & 0xffffu), sHi = (int)(s2 >> 16);
             const bool pLo = sLo > lowTh, pHi = sHi > lowTh;
@@ -603,7 +617,8 @@ __global__ __launch_bounds__(WAVE) void k_fast_strips_p(const OrbGeom G, const u
             if (nCand + nLo + nHi <= candCap) {
                 // (row, col) of the pair's first pixel: a + 4 = TB + zoneRow * ROWB + 4 quad
                 const unsigned a4 = a + 4u, rowAbs = __umulhi(a4, kRowMagic);
-                const unsigned e = ((rowAbs + (unsigned)(3 - TB / ROWB)) << 8) + (a4 - rowAbs * (unsigned)ROWB) + (unsigned)(2 * H);
+                const unsigned e = ((rowAbs + (unsigned)(3 - TB / ROWB)) << 8) + (a4 - rowAbs * (unsigned)ROWB) +
+                                   (H == 2 ? (fromB ? 2u : 0u) : (unsigned)(2 * H));
                 if (pLo) {
                     const int w = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bLo >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bLo, (unsigned)nCand));
                     candPos[w] = (uint16_t)e;
@@ -664,19 +679,25 @@ __global__ __launch_bounds__(WAVE) void k_fast_strips_p(const OrbGeom G, const u
                 }
             }
             __syncthreads();       // LDS operations of one wave execute in order; this only keeps the compiler from reordering
-            while (cntA >= WAVE || (!more && cntA > 0)) {
-                const int n = min(cntA, WAVE);
-                bstep(std::integral_constant<int, 0>(), ringA, headA, n);
-                headA = (headA + n) & (F2_RING - 1);
-                cntA -= n;
+            while (cntA >= WAVE) {
+                bstep(std::integral_constant<int, 0>(), ringA, headA, WAVE, 0);
+                headA = (headA + WAVE) & (F2_RING - 1);
+                cntA -= WAVE;
             }
-            while (cntB >= WAVE || (!more && cntB > 0)) {
-                const int n = min(cntB, WAVE);
-                bstep(std::integral_constant<int, 1>(), ringB, headB, n);
-                headB = (headB + n) & (F2_RING - 1);
-                cntB -= n;
+            while (cntB >= WAVE) {
+                bstep(std::integral_constant<int, 1>(), ringB, headB, WAVE, 0);
+                headB = (headB + WAVE) & (F2_RING - 1);
+                cntB -= WAVE;
             }
-            if (!more) break;
+            if (!more) {                                           // the remainders (< 64 each)
+                if (cntA > 0 && cntB > 0 && cntA + cntB <= WAVE) {
+                    bstep(std::integral_constant<int, 2>(), ringA, headA, cntA, cntB);
+                } else {
+                    if (cntA > 0) bstep(std::integral_constant<int, 0>(), ringA, headA, cntA, 0);
+                    if (cntB > 0) bstep(std::integral_constant<int, 1>(), ringB, headB, cntB, 0);
+                }
+                break;
+            }
         }
         __syncthreads();
     }
