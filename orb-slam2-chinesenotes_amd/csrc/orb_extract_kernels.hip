@@ -155,6 +155,13 @@ __device__ __forceinline__ unsigned resize_px(uint2 wa, uint2 wb, unsigned sel, 
     return (__umulhi(h0 >> 4, bs0) + __umulhi(h1 >> 4, bs1) + 2) >> 2;                        // <= 255
 }
 
+// the horizontal pass alone, in the form the vertical pass consumes: (p0 a0 + p1 a1) >> 4
+__device__ __forceinline__ unsigned resize_h(uint2 w, unsigned sel, unsigned co)
+{
+    const unsigned p = __builtin_amdgcn_perm(w.y, w.x, sel);
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(orb_u16x2, p), __builtin_bit_cast(orb_u16x2, co), 0u, false) >> 4;
+}
+
 #define RESIZE_ROWS 4      // output rows per thread: the 40-byte column entry and the index decode are paid once
 
 __global__ __launch_bounds__(256) void k_resize_level4p(uint8_t* __restrict__ pyr, size_t pyrSlab, int srcOff,
@@ -424,17 +431,29 @@ __global__ __launch_bounds__(256) void k_pyr_chain(const OrbPyrChain C, const ui
             uint4 e[RG];
 #pragma unroll
             for (int r = 0; r < RG; r++) e[r] = *reinterpret_cast<const uint4*>(rp + 16 * (g * RG + r));
+            // horizontal pass of a source row for the item's 4 pixels: (S[sx] a0 + S[sx + 1] a1) >> 4, the form the vertical
+            // pass consumes.  At scale 1.2 the lower source row of an output row is the upper source row of the next output row
+            // four times in five: its horizontal pass (2 LDS reads, 4 x (v_perm, v_dot2, shift)) is then reused, not redone.
+            auto hrow = [&](unsigned rowOff, unsigned (&h)[4]) {
+                const uint32_t* w0 = reinterpret_cast<const uint32_t*>(lds + rowOff + q0.x);
+                const uint32_t* w1 = reinterpret_cast<const uint32_t*>(lds + rowOff + q0.y);
+                const uint2 wa = make_uint2(w0[0], w0[1]), wb = make_uint2(w1[0], w1[1]);
+                h[0] = resize_h(wa, q0.z, q1.z); h[1] = resize_h(wa, q0.w, q1.w);
+                h[2] = resize_h(wb, q1.x, q2.x); h[3] = resize_h(wb, q1.y, q2.y);
+            };
+            unsigned hA[4], hB[4];
 #pragma unroll
             for (int r = 0; r < RG; r++) {
                 const unsigned lr = g * RG + r;
-                const uint32_t* a0 = reinterpret_cast<const uint32_t*>(lds + e[r].x + q0.x);
-                const uint32_t* a1 = reinterpret_cast<const uint32_t*>(lds + e[r].x + q0.y);
-                const uint32_t* b0 = reinterpret_cast<const uint32_t*>(lds + e[r].y + q0.x);
-                const uint32_t* b1 = reinterpret_cast<const uint32_t*>(lds + e[r].y + q0.y);
-                const uint2 wA0 = make_uint2(a0[0], a0[1]), wA1 = make_uint2(a1[0], a1[1]);
-                const uint2 wB0 = make_uint2(b0[0], b0[1]), wB1 = make_uint2(b1[0], b1[1]);
-                const unsigned out = resize_px(wA0, wB0, q0.z, q1.z, e[r].z, e[r].w) | (resize_px(wA0, wB0, q0.w, q1.w, e[r].z, e[r].w) << 8) |
-                                     (resize_px(wA1, wB1, q1.x, q2.x, e[r].z, e[r].w) << 16) | (resize_px(wA1, wB1, q1.y, q2.y, e[r].z, e[r].w) << 24);
+                if (r == 0 || e[r].x != e[r - 1].y) hrow(e[r].x, hA);
+                else {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) hA[j] = hB[j];
+                }
+                hrow(e[r].y, hB);
+                unsigned out = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) out |= ((__umulhi(hA[j], e[r].z) + __umulhi(hB[j], e[r].w) + 2) >> 2) << (8 * j);
                 if (lr < (unsigned)nM) {
                     *reinterpret_cast<uint32_t*>(dst + (lr * dpitch + x4 * 4)) = out;
                     if (keep) *reinterpret_cast<uint32_t*>(keepL + (lr * kpitch + x4 * 4)) = out;

@@ -474,7 +474,8 @@ static int orb_plan_geometry(const orb_extractor_params& prm, const OrbHostTable
         return true;
     };
     if (nl >= 2) {
-        if (!plan_set(P.chains, 16, 8) || !plan_set(P.chainsLat, 4, 2)) { P.chains.clear(); P.chainsLat.clear(); P.bandTab.clear(); }
+        const int bandRows = std::getenv("ORB_PYR_BAND") ? std::max(2, std::min(64, std::atoi(std::getenv("ORB_PYR_BAND")))) : 16;
+        if (!plan_set(P.chains, bandRows, std::min(bandRows, 8)) || !plan_set(P.chainsLat, 4, 2)) { P.chains.clear(); P.chainsLat.clear(); P.bandTab.clear(); }
     }
     P.nCells = nCells;
     P.pyrSlab = (size_t)align_up((int)pyrOff, 256);
