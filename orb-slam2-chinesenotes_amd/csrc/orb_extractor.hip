@@ -539,31 +539,51 @@ extern "C" int orb_extract_batch(orb_extractor* h, const uint8_t* imgs, int nFra
     h->frameBase = 0;
     int rc;
     const size_t imgBytes = (size_t)rows * cols;
-    if ((rc = h->dImgs.ensure(imgBytes * nFrames)) != ORB_OK) return rc;
-    if ((rc = h->dKps.ensure(sizeof(orb_keypoint) * (size_t)cap * nFrames)) != ORB_OK) return rc;
-    if ((rc = h->dDesc.ensure((size_t)ORB_DESC_BYTES * cap * nFrames)) != ORB_OK) return rc;
-    if ((rc = h->dCounts.ensure((size_t)4 * nFrames)) != ORB_OK) return rc;
-    if (rowStride == (size_t)cols && (frameStride == imgBytes || nFrames == 1)) {
-        // contiguous frames: one linear copy (a 2-D copy of an odd width such as 1241 takes a slow row-wise path)
-        ORB_HIP_TRY(hipMemcpyAsync(h->dImgs.p, imgs, imgBytes * nFrames, hipMemcpyHostToDevice, h->stream));
-    } else {
-        for (int f = 0; f < nFrames; f++) {
-            if (rowStride == (size_t)cols)
-                ORB_HIP_TRY(hipMemcpyAsync((uint8_t*)h->dImgs.p + imgBytes * f, imgs + frameStride * f, imgBytes,
-                                           hipMemcpyHostToDevice, h->stream));
-            else
-                ORB_HIP_TRY(hipMemcpy2DAsync((uint8_t*)h->dImgs.p + imgBytes * f, cols, imgs + frameStride * f, rowStride,
-                                             cols, rows, hipMemcpyHostToDevice, h->stream));
-        }
-    }
     const size_t kStageLimit = (size_t)96 << 20;
     const size_t statB = orb_extractor::statInts(nFrames) * 4, cntB = (size_t)4 * nFrames;
     const size_t kpB = sizeof(orb_keypoint) * (size_t)cap * nFrames, dsB = (size_t)ORB_DESC_BYTES * cap * nFrames;
     const bool whole = statB + cntB + kpB + dsB <= kStageLimit;
-    if ((rc = ensure_stage(h, whole ? statB + cntB + kpB + dsB : statB + cntB)) != ORB_OK) return rc;
+    // Single frames (the reference's operator() path) skip both DMA legs: the image is copied by the CPU into the handle's
+    // pinned staging and the first pyramid kernel reads it from there over PCIe; keypoints, descriptors and the count are
+    // written by the descriptor kernel straight into pinned staging.  What is left on the copy engines is the 200-byte
+    // status block.  (A pageable hipMemcpyAsync of 307 KB costs more than the CPU copy + the kernel's reads.)
+    const bool zero = nFrames == 1 && whole && !std::getenv("ORB_NO_ZEROCOPY");
+    const size_t imgOff = (statB + cntB + kpB + dsB + 255) & ~(size_t)255;
+    if ((rc = ensure_stage(h, whole ? (zero ? imgOff + imgBytes + 256 : statB + cntB + kpB + dsB) : statB + cntB)) != ORB_OK) return rc;
     uint8_t* stg = (uint8_t*)h->hStage;
+    if (zero) {
+        uint8_t* dst = stg + imgOff;
+        if (rowStride == (size_t)cols) std::memcpy(dst, imgs, imgBytes);
+        else
+            for (int y = 0; y < rows; y++) std::memcpy(dst + (size_t)y * cols, imgs + (size_t)y * rowStride, (size_t)cols);
+    } else {
+        if ((rc = h->dImgs.ensure(imgBytes * nFrames)) != ORB_OK) return rc;
+        if ((rc = h->dKps.ensure(sizeof(orb_keypoint) * (size_t)cap * nFrames)) != ORB_OK) return rc;
+        if ((rc = h->dDesc.ensure((size_t)ORB_DESC_BYTES * cap * nFrames)) != ORB_OK) return rc;
+        if ((rc = h->dCounts.ensure((size_t)4 * nFrames)) != ORB_OK) return rc;
+        if (rowStride == (size_t)cols && (frameStride == imgBytes || nFrames == 1)) {
+            // contiguous frames: one linear copy (a 2-D copy of an odd width such as 1241 takes a slow row-wise path)
+            ORB_HIP_TRY(hipMemcpyAsync(h->dImgs.p, imgs, imgBytes * nFrames, hipMemcpyHostToDevice, h->stream));
+        } else {
+            for (int f = 0; f < nFrames; f++) {
+                if (rowStride == (size_t)cols)
+                    ORB_HIP_TRY(hipMemcpyAsync((uint8_t*)h->dImgs.p + imgBytes * f, imgs + frameStride * f, imgBytes,
+                                               hipMemcpyHostToDevice, h->stream));
+                else
+                    ORB_HIP_TRY(hipMemcpy2DAsync((uint8_t*)h->dImgs.p + imgBytes * f, cols, imgs + frameStride * f, rowStride,
+                                                 cols, rows, hipMemcpyHostToDevice, h->stream));
+            }
+        }
+    }
     // the chain and the copies back; issued eagerly, or (single frames, the reference's per-call path) as one graph
     auto chain = [&]() -> int {
+        if (zero) {
+            int r = orb_extract_batch_device(h, stg + imgOff, 1, rows, cols, cols, imgBytes, (orb_keypoint*)(stg + statB + cntB),
+                                             stg + statB + cntB + kpB, cap, (int32_t*)(stg + statB));
+            if (r != ORB_OK) return r;
+            ORB_HIP_TRY(hipMemcpyAsync(stg, h->dStat.p, statB, hipMemcpyDeviceToHost, h->stream));
+            return ORB_OK;
+        }
         int r = orb_extract_batch_device(h, (const uint8_t*)h->dImgs.p, nFrames, rows, cols, cols, imgBytes,
                                          (orb_keypoint*)h->dKps.p, (uint8_t*)h->dDesc.p, cap, (int32_t*)h->dCounts.p);
         if (r != ORB_OK) return r;

@@ -21,7 +21,7 @@ for r in rows:
         calls.append(cur); cur = []                      # the first kernel of a call: k_copy_level0 or the first k_pyr_chain
     cur.append((n, int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
 calls.append(cur)
-calls = calls[20:60]
+calls = calls[len(calls) // 3: len(calls) // 3 + 40] if len(calls) > 60 else calls[-max(1, len(calls) // 2):]
 agg = collections.defaultdict(list)
 spans, busy = [], []
 for c in calls:
