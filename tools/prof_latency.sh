@@ -16,7 +16,7 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # first size only (640x480): calls = groups starting at k_copy_level0
 calls, cur = [], []
 for r in rows:
-    n = r["Kernel_Name"].replace("void ", "").split("(")[0]
+    n = r["Kernel_Name"].replace("void ", "").split("(")[0].split("<")[0]
     if n in ("k_copy_level0", "k_pyr_chain") and cur and (n == "k_copy_level0" or cur[-1][0] != "k_pyr_chain"):
         calls.append(cur); cur = []                      # the first kernel of a call: k_copy_level0 or the first k_pyr_chain
     cur.append((n, int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
