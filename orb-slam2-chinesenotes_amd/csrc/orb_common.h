@@ -98,12 +98,17 @@ static_assert(sizeof(OrbStrip) == 48, "OrbStrip is loaded as one scalar record")
 
 
 // Candidate key layout (64 bit), sorted ascending by the quadtree kernel:
-//   [61:58] quadtree root   [57:34] 12 x 2-bit quadrant path (depth 0 in the top bits)
-//   [33:27] cell row  [26:20] cell col  [19:14] y in ROI  [13:8] x in ROI   [7:0] FAST score
+//   [63:60] quadtree root   [59:36] 12 x 2-bit quadrant path (depth 0 in the top bits)
+//   [35:28] cell row  [27:20] cell col  [19:14] y in ROI  [13:8] x in ROI   [7:0] FAST score
+// (round 3: cell row / column are 8 bits -- 256 cells of >= 30 px per axis, i.e. levels of up to 4112 px such as a
+// 4096 x 2160 frame; they were 7 bits, 3870 px)
 // (cell row, cell col, y, x) ascending == the order in which the reference appends candidates
 // (src/ORBextractor.cc:826-871), so ties resolve exactly as its "first maximum wins" scan.
-#define ORB_KEY_ROOT_SHIFT 58
-#define ORB_KEY_PATH_SHIFT 34
+#define ORB_KEY_ROOT_SHIFT 60
+#define ORB_KEY_PATH_SHIFT 36
+#define ORB_KEY_CI_SHIFT 28
+#define ORB_KEY_CJ_SHIFT 20
+#define ORB_KEY_ORD_MASK 0xFFFFFFFu      // (cell row, cell col, y, x): the order the reference appends candidates in
 #define ORB_KEY_PATH_LEVELS 12
 
 // XCD-aware decode of a 1-D grid (frames x items).  Workgroups are dealt round-robin over the 8 XCDs of an

@@ -52,10 +52,10 @@ static int build_geometry(orb_extractor* h, int rows, int cols)
     // per-workgroup LDS budget: 60 KB (several workgroups per CU) unless the node arrays alone need more
     const size_t qtBudget = orb_quadtree_lds_bytes(256, nodeCap) > 60 * 1024 ? (size_t)ORB_QT_LDS_MAX : (size_t)60 * 1024;
     while (sortCap > 256 && orb_quadtree_lds_bytes(sortCap, nodeCap) > qtBudget) sortCap >>= 1;
-    if (orb_quadtree_lds_bytes(sortCap, nodeCap) > ORB_QT_LDS_MAX) {
-        orb_set_error("nfeatures too large for the quadtree kernel's LDS budget");
-        return ORB_ERR_UNSUPPORTED;
-    }
+    // quotas whose node lists do not fit one workgroup's LDS (nFeatures >~ 12 000): the lists go to a global scratch slab
+    // (k_quadtree_gnodes: same results, every step a round trip to L2)
+    const bool qtGlobal = orb_quadtree_lds_bytes(sortCap, nodeCap) > ORB_QT_LDS_MAX;
+    if (qtGlobal) sortCap = 4096;
     if (orb_fast_lds_bytes(maxPdw, maxRows, 4096) > 64 * 1024 || orb_fast_dense_lds_bytes(maxPdw, maxRows, maxSdw) > 64 * 1024) {
         orb_set_error("FAST strip tile needs more than 64 KB of LDS");
         return ORB_ERR_UNSUPPORTED;
@@ -103,6 +103,7 @@ static int build_geometry(orb_extractor* h, int rows, int cols)
     h->pyrSlab = P.pyrSlab;
     h->candSlab = P.candSlab;
     h->nodeCap = nodeCap;
+    h->qtGlobal = qtGlobal;
     h->maxKp = P.maxKp;
     h->fastPdw = maxPdw;
     h->fastRows = maxRows;
@@ -133,6 +134,7 @@ static int ensure_scratch(orb_extractor* h, int nFrames)
     if ((rc = h->dCand.ensure(h->candSlab * 8 * nFrames)) != ORB_OK) return rc;
     if ((rc = h->dKpl.ensure((size_t)h->G.kpSlab * 4 * nFrames)) != ORB_OK) return rc;
     if ((rc = h->dOvf.ensure((size_t)4 * std::max<size_t>(1, h->strips.size()) * nFrames)) != ORB_OK) return rc;
+    if (h->qtGlobal && (rc = h->dQt.ensure(orb_quadtree_scratch_stride(h->nodeCap) * h->G.nlevels * nFrames)) != ORB_OK) return rc;
     if (orb_extractor::statInts(nFrames) * 4 > h->dStat.bytes) {
         // a larger status block: the sticky words (error flags of batches that were never synchronised) move with it
         DevBuf nb;
@@ -227,7 +229,7 @@ extern "C" void orb_extractor_destroy(orb_extractor* h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    DevBuf* bufs[] = {&h->dPattern, &h->dPatternF, &h->dAngTab, &h->dCells, &h->dXtab, &h->dYtab, &h->dXq, &h->dPath, &h->dBand, &h->dPyr, &h->dCand, &h->dKpl, &h->dOvf,
+    DevBuf* bufs[] = {&h->dPattern, &h->dPatternF, &h->dAngTab, &h->dCells, &h->dXtab, &h->dYtab, &h->dXq, &h->dPath, &h->dBand, &h->dPyr, &h->dCand, &h->dKpl, &h->dOvf, &h->dQt,
                       &h->dStat, &h->dImgs, &h->dKps, &h->dDesc, &h->dCounts,
                       &h->dStereo, &h->dStereoIn};
     for (DevBuf* b : bufs) b->release();
@@ -340,6 +342,7 @@ extern "C" void* orb_extractor_stream(orb_extractor* h) { return h ? (void*)h->s
 // the quadtree's LDS sort capacity follows the largest candidate count seen (within the LDS budget)
 static void grow_sort_cap(orb_extractor* h, int maxCandidates)
 {
+    if (h->qtGlobal) return;                           // (the keys alone: 4096 of them in LDS, fixed)
     int want = 1024;
     while (want < maxCandidates && want < 4096) want <<= 1;
     const size_t budget = orb_quadtree_lds_bytes(256, h->nodeCap) > 60 * 1024 ? (size_t)ORB_QT_LDS_MAX : (size_t)60 * 1024;
@@ -444,7 +447,8 @@ extern "C" int orb_extract_batch_device(orb_extractor* h, const uint8_t* d_imgs,
                            (const uint32_t*)h->dPath.p, scand, h->candSlab, scc, serr, h->ovfCountP(), (int*)h->dOvf.p,
                            h->prm.ini_th_fast, h->prm.min_th_fast, h->fastPdw, h->fastRows, h->fastSdw, h->fastCandCap, n, h->fastP);
     if (prof) ORB_HIP_TRY(hipEventRecord(pe[2], st));
-    orb_launch_quadtree(st, G, scand, h->candSlab, scc, skpl, skc, serr, h->sortCap, h->nodeCap, n, h->ovfCountP());
+    orb_launch_quadtree(st, G, scand, h->candSlab, scc, skpl, skc, serr, h->sortCap, h->nodeCap, n, h->ovfCountP(),
+                        h->qtGlobal ? (unsigned char*)h->dQt.p : nullptr);
     if (prof) ORB_HIP_TRY(hipEventRecord(pe[3], st));
     orb_launch_orient_desc(st, G, pyr, h->pyrSlab, skpl, skc, (const float*)h->dPatternF.p, (const uint4*)h->dAngTab.p, (const uint32_t*)((const uint8_t*)h->dAngTab.p + 16 * 2 * 32), d_kps, d_desc, cap,
                            d_counts, serr, n);

@@ -76,6 +76,8 @@ struct orb_extractor {
     std::vector<size_t> xtabOff, ytabOff;       // per level offsets (in int2 units)
     std::vector<long long> xqOff;               // per level offset into dXq (uint4 units), -1 = level not eligible
     DevBuf dPyr, dCand, dKpl, dOvf;             // per-batch scratch (dOvf: FAST strips to redo densely)
+    DevBuf dQt;                                 // node lists of k_quadtree_gnodes (quotas beyond one workgroup's LDS)
+    bool qtGlobal = false;
     // per-batch status words, ONE allocation so that one memset clears it and one copy fetches it:
     // [err: n][FAST candidates per level: 16n][keypoints per level: 16n][FAST overflow: list length, 7 pad, 16 per-level
     // counts] for the n frames of the current batch
@@ -115,7 +117,7 @@ struct orb_extractor {
     int geomVersion = 0;                        // bumped by every geometry build
     void graph_bufs(const void* (&b)[10]) const
     {
-        const void* cur[10] = {dPyr.p, dCand.p, dKpl.p, dOvf.p, dStat.p, dImgs.p, dKps.p, dDesc.p, dCounts.p, dPatternF.p};
+        const void* cur[10] = {dPyr.p, dCand.p, dKpl.p, dOvf.p, dStat.p, dImgs.p, dKps.p, dDesc.p, dCounts.p, dQt.p ? dQt.p : dPatternF.p};
         for (int i = 0; i < 10; i++) b[i] = cur[i];
     }
 

@@ -324,7 +324,7 @@ __device__ __forceinline__ void fast_detect(const OrbStrip& S, const uint32_t* t
 // key of the candidate at tile (row, col) in cell c of the strip; S1 = score + 1
 #define FAST_KEY(row, col, c, S1)                                                                                         \
     (((unsigned long long)(xtab[(col) + S.cxBase] | ytab[(row) + cy0]) << ORB_KEY_PATH_SHIFT) |                           \
-     ((unsigned long long)S.ci << 27) | ((unsigned long long)(S.cj0 + (c)) << 20) | ((unsigned long long)(row) << 14) |   \
+     ((unsigned long long)S.ci << ORB_KEY_CI_SHIFT) | ((unsigned long long)(S.cj0 + (c)) << ORB_KEY_CJ_SHIFT) | ((unsigned long long)(row) << 14) |   \
      ((unsigned long long)((col) - S.xoff - (c) * wCell) << 8) | (unsigned long long)((S1) - 1))
 
 __global__ __launch_bounds__(WAVE) void k_fast_strips(const OrbGeom G, const uint8_t* __restrict__ pyr,

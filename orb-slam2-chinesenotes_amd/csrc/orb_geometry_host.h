@@ -294,8 +294,9 @@ static int orb_plan_geometry(const orb_extractor_params& prm, const OrbHostTable
         OrbLevelGeom& L = G.L[l];
         L.w = cv_round_f((float)cols * T.invScale[l]);                 // :1158
         L.h = cv_round_f((float)rows * T.invScale[l]);
-        if (L.w < 1 || L.h < 1 || L.w > 4095 || L.h > 4095) {
-            orb_set_error("level %d of a %dx%d image is %dx%d: outside the supported 1..4095 px", l, cols, rows, L.w, L.h);
+        // (keypoint coordinates are packed in 12 bits: x <= w - 17 < 4096)
+        if (L.w < 1 || L.h < 1 || L.w > 4112 || L.h > 4112) {
+            orb_set_error("level %d of a %dx%d image is %dx%d: outside the supported 1..4112 px", l, cols, rows, L.w, L.h);
             return ORB_ERR_UNSUPPORTED;
         }
         L.pitch = align_up(L.w, 64);
@@ -316,7 +317,7 @@ static int orb_plan_geometry(const orb_extractor_params& prm, const OrbHostTable
         const int firstCell = nCells;
         if (nCols > 0 && nRows > 0) {
             const int wCell = (int)std::ceil(width / nCols), hCell = (int)std::ceil(height / nRows);
-            if (wCell > 60 || hCell > 60 || nCols > 128 || nRows > 128) {
+            if (wCell > 60 || hCell > 60 || nCols > 256 || nRows > 256) {
                 orb_set_error("FAST cell grid %dx%d cells of %dx%d px unsupported", nCols, nRows, wCell, hCell);
                 return ORB_ERR_UNSUPPORTED;
             }
@@ -356,7 +357,8 @@ static int orb_plan_geometry(const orb_extractor_params& prm, const OrbHostTable
         int nIni = 0;
         if (L.boxW > 0 && L.boxH > 0) nIni = (int)std::round((float)L.boxW / L.boxH);
         if (nIni > 15) { orb_set_error("aspect ratio %d:1 unsupported", nIni); return ORB_ERR_UNSUPPORTED; }
-        if (std::max(nIni > 0 ? L.boxW / std::max(nIni, 1) : 0, L.boxH) > 2048) {
+        // (12 ceil-halvings bring a box of up to 4096 px down to single pixels: 4096, 2048, ..., 2, 1)
+        if (std::max(nIni > 0 ? (L.boxW + std::max(nIni, 1) - 1) / std::max(nIni, 1) + 1 : 0, L.boxH) > 4096) {
             orb_set_error("quadtree box %dx%d needs more than %d path levels", L.boxW, L.boxH, ORB_KEY_PATH_LEVELS);
             return ORB_ERR_UNSUPPORTED;
         }

@@ -22,7 +22,8 @@ size_t orb_fast_p_lds_bytes(int P, int rowsMax, int candCap);
 size_t orb_quadtree_lds_bytes(int sortCap, int nodeCap);
 void orb_launch_quadtree(hipStream_t st, const OrbGeom& G, unsigned long long* cand, size_t candSlab,
                          const int* candCount, uint32_t* kpl, int* kpCount, int* errFlags, int sortCap,
-                         int nodeCap, int nFrames, int* ovfBlock);
+                         int nodeCap, int nFrames, int* ovfBlock, unsigned char* globalScratch);
+size_t orb_quadtree_scratch_stride(int nodeCap);
 void orb_launch_orient_desc(hipStream_t st, const OrbGeom& G, const uint8_t* pyr, size_t pyrSlab,
                             const uint32_t* kpl, const int* kpCount, const float* patternF, const uint4* angTab, const uint32_t* hbTab,
                             orb_keypoint* kps, uint8_t* desc, int cap, int32_t* counts, int* errFlags,

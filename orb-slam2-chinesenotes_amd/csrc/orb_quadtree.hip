@@ -348,11 +348,11 @@ __device__ __forceinline__ void qt_body(unsigned long long* keys, int n, const O
         for (int k = nd.lo; k < nd.hi; k++) {
             // max response; among equals the candidate the reference appended first: smallest (ci,cj,y,x)
             const unsigned long long key = keys[k];
-            const unsigned resp = (unsigned)(key & 0xFF), ord = (unsigned)(key >> 8) & 0x3FFFFFFu;
-            const unsigned bresp = (unsigned)(bestKey & 0xFF), bord = (unsigned)(bestKey >> 8) & 0x3FFFFFFu;
+            const unsigned resp = (unsigned)(key & 0xFF), ord = (unsigned)(key >> 8) & ORB_KEY_ORD_MASK;
+            const unsigned bresp = (unsigned)(bestKey & 0xFF), bord = (unsigned)(bestKey >> 8) & ORB_KEY_ORD_MASK;
             if (k == nd.lo || resp > bresp || (resp == bresp && ord < bord)) bestKey = key;
         }
-        const int ci = (int)(bestKey >> 27) & 0x7F, cj = (int)(bestKey >> 20) & 0x7F;
+        const int ci = (int)(bestKey >> ORB_KEY_CI_SHIFT) & 0xFF, cj = (int)(bestKey >> ORB_KEY_CJ_SHIFT) & 0xFF;
         const int yin = (int)(bestKey >> 14) & 0x3F, xin = (int)(bestKey >> 8) & 0x3F;
         const int x = xin + cj * L.wCell + 16, y = yin + ci * L.hCell + 16;     // + minBorder (:892-893)
         out[i] = ((uint32_t)x << 20) | ((uint32_t)y << 8) | (uint32_t)(bestKey & 0xFF);
@@ -407,6 +407,49 @@ __global__ __launch_bounds__(256) void k_quadtree(const OrbGeom G, unsigned long
     }
 }
 
+// Slow-but-correct variant for per-level quotas beyond what one workgroup's LDS holds (nFeatures >~ 12 000): the node lists, cut
+// points and scan arrays of an instance live in a global scratch slab (60 bytes per node slot); the keys stay in LDS when they
+// fit.  Same qt_body: the lists are reached through global pointers, every step a round trip to L2 instead of LDS.
+__global__ __launch_bounds__(256) void k_quadtree_gnodes(const OrbGeom G, unsigned long long* __restrict__ cand, size_t candSlab,
+                                                         const int* __restrict__ candCount, uint32_t* __restrict__ kpl,
+                                                         int* __restrict__ kpCount, int* __restrict__ errFlags, int sortCap, int nodeCap,
+                                                         int* __restrict__ ovfBlock, unsigned char* __restrict__ scratchAll,
+                                                         size_t scratchStride)
+{
+    extern __shared__ unsigned long long qsm[];                    // keys[sortCap] | part[258]
+    unsigned long long* ldsKeys = qsm;
+    int* part = reinterpret_cast<int*>(qsm + sortCap);
+    __shared__ int sh[4];
+    const int level = blockIdx.y, f = blockIdx.x;
+    const OrbLevelGeom& L = G.L[level];
+    const int tid = threadIdx.x, T = blockDim.x;
+    int n = candCount[f * ORB_MAX_LEVELS + level];
+    if (n > L.candCap) n = L.candCap;
+    int* outCount = &kpCount[f * ORB_MAX_LEVELS + level];
+    if (n == 0) {
+        if (tid == 0) *outCount = 0;
+        return;
+    }
+    unsigned char* sc = scratchAll + ((size_t)f * G.nlevels + level) * scratchStride;
+    unsigned long long* prevA = reinterpret_cast<unsigned long long*>(sc);
+    unsigned long long* prevB = prevA + nodeCap;
+    QtNode* A = reinterpret_cast<QtNode*>(prevB + nodeCap);
+    QtNode* B = A + nodeCap;
+    int3* cuts = reinterpret_cast<int3*>(B + nodeCap);
+    int* va = reinterpret_cast<int*>(cuts + nodeCap);
+    int* vb = va + nodeCap;
+    unsigned long long* gk = cand + (size_t)f * candSlab + L.candBase;
+    if (n <= sortCap) {
+        for (int i = tid; i < n; i += T) ldsKeys[i] = gk[i];
+        qt_body(ldsKeys, n, G, L, f, prevA, prevB, A, B, cuts, va, vb, part, kpl, outCount, errFlags, sh, nullptr, 0);
+    } else {
+        if (tid == 0) atomicMax(&ovfBlock[1], n);
+        qt_body(gk, n, G, L, f, prevA, prevB, A, B, cuts, va, vb, part, kpl, outCount, errFlags, sh, nullptr, 0);
+    }
+}
+
+size_t orb_quadtree_scratch_stride(int nodeCap) { return ((size_t)nodeCap * (16 + 2 * sizeof(QtNode) + sizeof(int3) + 8) + 15) & ~(size_t)15; }
+
 size_t orb_quadtree_lds_bytes(int sortCap, int nodeCap)
 {
     return (size_t)sortCap * 8 + (size_t)nodeCap * (16 + 2 * sizeof(QtNode) + sizeof(int3) + 8) + 258 * 4;
@@ -414,8 +457,13 @@ size_t orb_quadtree_lds_bytes(int sortCap, int nodeCap)
 
 void orb_launch_quadtree(hipStream_t st, const OrbGeom& G, unsigned long long* cand, size_t candSlab,
                          const int* candCount, uint32_t* kpl, int* kpCount, int* errFlags, int sortCap,
-                         int nodeCap, int nFrames, int* ovfBlock)
+                         int nodeCap, int nFrames, int* ovfBlock, unsigned char* globalScratch)
 {
+    if (globalScratch) {
+        hipLaunchKernelGGL(k_quadtree_gnodes, dim3(nFrames, G.nlevels), dim3(256), (size_t)sortCap * 8 + 258 * 4, st, G, cand, candSlab,
+                           candCount, kpl, kpCount, errFlags, sortCap, nodeCap, ovfBlock, globalScratch, orb_quadtree_scratch_stride(nodeCap));
+        return;
+    }
     const size_t lds = orb_quadtree_lds_bytes(sortCap, nodeCap);
     // quotas beyond ~1000 per level (nFeatures >~ 4500) need more than the default 64 KB of dynamic LDS: a workgroup may
     // use the CU's whole 160 KB (one workgroup per CU then -- only the huge-quota configurations pay that)

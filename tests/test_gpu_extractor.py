@@ -221,6 +221,15 @@ def test_full_hd_1920x1080_3000_features():
     _cmp(synth.synth_frame(77, 1920, 1080), nfeatures=3000)
 
 
+@pytest.mark.parametrize("w,h,nf", [(4096, 2160, 1000), (4112, 640, 1500), (3900, 480, 800)])
+def test_4k_frames(w, h, nf):
+    """Round 3 envelope: levels of up to 4112 px (cell row / column are 8-bit key fields now, 12 quadtree path levels cover a
+    4096-px box): a 4096 x 2160 frame -- 135 x 71 FAST cells on level 0, a 2128-px quadtree box -- end to end against the
+    oracle; the pyramid goes through the per-level kernels here (a 16-row band of such a level does not fit the chains' LDS)."""
+    n = _cmp(synth.synth_frame(77, w, h), nfeatures=nf)
+    assert n > 0.9 * nf
+
+
 def test_unsupported_geometry_is_reported_not_crashed():
     ex = capi.Extractor()
     img = np.zeros((100, 4200), np.uint8)                       # level 0 wider than the supported 4095 px
@@ -448,6 +457,15 @@ def test_large_feature_counts_kitti_size(nf):
     quotas beyond ~1000 make k_quadtree take more than 64 KB of LDS (up to the CU's 160 KB).  Bit-exact at 1241x376."""
     n = _cmp(synth.synth_frame(100, 1241, 376), nfeatures=nf)
     assert n > min(nf, 4000) * 0.8
+
+
+@pytest.mark.parametrize("w,h,nf", [(1920, 1080, 20000), (1241, 376, 16000)])
+def test_huge_quotas_use_the_global_node_lists(w, h, nf):
+    """Round 3 envelope: per-level quotas whose quadtree node lists do not fit one workgroup's LDS (the level-0 quota of
+    nFeatures = 20 000 is 4340) run through k_quadtree_gnodes (node lists in a global scratch slab): slow, same results."""
+    img = synth.synth_frame(41, w, h, n_rect=1500, n_disc=700)      # enough corners for such a quota
+    n = _cmp(img, nfeatures=nf)
+    assert n > 5000
 
 
 @pytest.mark.parametrize("kind", ["checker1", "checker2", "checker3", "stripes", "blocks", "saltpepper", "gradient_noise", "dots", "cluster"])
