@@ -50,7 +50,7 @@ struct OrbGeom {
 // draws on in LDS (coalesced 16-byte loads, no dependent address), and resamples level after level out of LDS: every
 // produced level is written to HBM once and never read back inside the chain.  The first chain of a batch reads the
 // caller's image and also writes level 0 (reference src/ORBextractor.cc:1173).
-#define ORB_PYR_MAXCHAIN 3
+#define ORB_PYR_MAXCHAIN 4
 struct OrbPyrStep {
     int dstOff, dstPitch, dstH; // produced level inside one frame's pyramid slab
     int x4;                     // pixel quads per row
@@ -68,6 +68,8 @@ struct OrbPyrChain {
     int bands, tabOff;          // workgroups per frame; offset (int2 units) of the band table [band][nSteps + 2]:
                                 //   [0] source rows (first, last), [1 + k] rows of step k, [nSteps + 1] level-0 rows to copy
     int ldsBytes;
+    int xqLdsOff, xqLdsN;       // > 0 entries: the column tables of the chain's levels (contiguous from st[0].xqOff, uint4 units) are
+                                //   copied to LDS at xqLdsOff first (the few-frames variants: an LDS read per item, not an L2 round trip)
     OrbPyrStep st[ORB_PYR_MAXCHAIN];
 };
 

@@ -303,7 +303,7 @@ typedef unsigned int orb_u32x4 __attribute__((ext_vector_type(4)));
 typedef orb_u32x4 __attribute__((aligned(1))) orb_u32x4_a1;
 #define PYR_STAGE_MAX 8            // 16-byte chunks a thread has in flight while staging
 
-template <int RG>
+template <int RG, bool XL>
 __global__ __launch_bounds__(256) void k_pyr_chain(const OrbPyrChain C, const uint8_t* __restrict__ img, size_t rowStride,
                                                    size_t frameStride, uint8_t* __restrict__ pyr, size_t pyrSlab,
                                                    const uint4* __restrict__ xqAll, const int2* __restrict__ ytAll,
@@ -320,6 +320,14 @@ __global__ __launch_bounds__(256) void k_pyr_chain(const OrbPyrChain C, const ui
             const char4 q = pat8[g];
             patF[g] = make_float4((float)q.x, (float)q.y, (float)q.z, (float)q.w);
         }
+    }
+    // XL: the column tables of the chain's levels go to LDS (requested first: their addresses depend on nothing)
+    orb_u32x4 xv[4];
+    if constexpr (XL) {
+        const orb_u32x4* xg = reinterpret_cast<const orb_u32x4*>(xqAll + C.st[0].xqOff);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (tid + 256 * i < C.xqLdsN) xv[i] = xg[tid + 256 * i];
     }
     const int2* bt = bandTab + C.tabOff + b * (C.nSteps + 2);
     const int2 sr = bt[0];
@@ -391,6 +399,11 @@ __global__ __launch_bounds__(256) void k_pyr_chain(const OrbPyrChain C, const ui
             }
         }
     }
+    if constexpr (XL) {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (tid + 256 * i < C.xqLdsN) *reinterpret_cast<orb_u32x4*>(lds + C.xqLdsOff + 16 * (tid + 256 * i)) = xv[i];
+    }
     __syncthreads();
 
     // ---- level after level out of LDS: one item = 4 pixels x RG rows (RG = 4 amortises the column entry best, RG = 1 / 2 leave
@@ -411,7 +424,8 @@ __global__ __launch_bounds__(256) void k_pyr_chain(const OrbPyrChain C, const ui
         uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0;
         uint2 q2 = make_uint2(0, 0);
         unsigned g = 0, x4 = 0;
-        if ((unsigned)tid < nItems) {
+        const uint8_t* xl = lds + C.xqLdsOff + 16 * (T.xqOff - C.st[0].xqOff);
+        if (!XL && (unsigned)tid < nItems) {
             g = inv ? __umulhi((unsigned)tid, inv) : (unsigned)tid;
             x4 = (unsigned)tid - g * x4n;
             q0 = xq[3 * x4]; q1 = xq[3 * x4 + 1];
@@ -422,7 +436,13 @@ __global__ __launch_bounds__(256) void k_pyr_chain(const OrbPyrChain C, const ui
             uint4 n0 = q0, n1 = q1;
             uint2 n2 = q2;
             unsigned gN = g, x4N = x4;
-            if (idxN < nItems) {
+            if constexpr (XL) {
+                g = inv ? __umulhi(idx, inv) : idx;
+                x4 = idx - g * x4n;
+                q0 = *reinterpret_cast<const uint4*>(xl + 48 * x4);
+                q1 = *reinterpret_cast<const uint4*>(xl + 48 * x4 + 16);
+                q2 = *reinterpret_cast<const uint2*>(xl + 48 * x4 + 32);
+            } else if (idxN < nItems) {
                 gN = inv ? __umulhi(idxN, inv) : idxN;
                 x4N = idxN - gN * x4n;
                 n0 = xq[3 * x4N]; n1 = xq[3 * x4N + 1];
@@ -459,7 +479,7 @@ __global__ __launch_bounds__(256) void k_pyr_chain(const OrbPyrChain C, const ui
                     if (keep) *reinterpret_cast<uint32_t*>(keepL + (lr * kpitch + x4 * 4)) = out;
                 }
             }
-            q0 = n0; q1 = n1; q2 = n2; g = gN; x4 = x4N;
+            if constexpr (!XL) { q0 = n0; q1 = n1; q2 = n2; g = gN; x4 = x4N; }
         }
         __syncthreads();
     }
@@ -518,9 +538,14 @@ void orb_launch_pyr_chain(hipStream_t st, const OrbPyrChain& C, const uint8_t* i
                            pyrSlab, xqAll, ytAll, bandTab, clr, clrInts, reinterpret_cast<const char4*>(pat8),
                            reinterpret_cast<float4*>(patF));
     };
-    if (rg == 1) go(k_pyr_chain<1>);
-    else if (rg == 2) go(k_pyr_chain<2>);
-    else go(k_pyr_chain<4>);
+    if (C.xqLdsN > 0) {
+        if (rg == 1) go(k_pyr_chain<1, true>);
+        else if (rg == 2) go(k_pyr_chain<2, true>);
+        else go(k_pyr_chain<4, true>);
+    }
+    else if (rg == 1) go(k_pyr_chain<1, false>);
+    else if (rg == 2) go(k_pyr_chain<2, false>);
+    else go(k_pyr_chain<4, false>);
 }
 
 // Levels M and M+1 in one launch (k_resize_pair); returns false when the pair is not eligible (the caller then

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstddef>
+#include <chrono>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -13,6 +14,12 @@
 #include "../../include/orb_brief_pattern.h"
 #include "orb_extractor_internal.h"
 #include "orb_geometry_host.h"
+
+// ORB_TIMING=1: where a single-frame host call spends its time (image copy-in, launch, wait, copy-out), printed by destroy
+static const bool g_timing = std::getenv("ORB_TIMING") != nullptr;
+static double g_tAcc[4];
+static long g_tCalls;
+static inline double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 #pragma clang fp contract(off)
 
@@ -90,9 +97,11 @@ static int build_geometry(orb_extractor* h, int rows, int cols)
         ORB_HIP_TRY(hipMemcpyAsync(h->dBand.p, P.bandTab.data(), P.bandTab.size() * sizeof(int2), hipMemcpyHostToDevice, h->stream));
         h->pyrChains = P.chains;
         h->pyrChainsLat = P.chainsLat;
+        h->pyrChainsOne = P.chainsOne;
     } else {
         h->pyrChains.clear();
         h->pyrChainsLat.clear();
+        h->pyrChainsOne.clear();
     }
     ORB_HIP_TRY(hipStreamSynchronize(h->stream));     // host vectors go out of scope
     // commit
@@ -227,6 +236,11 @@ extern "C" int orb_extractor_create(const orb_extractor_params* p, int device_id
 extern "C" void orb_extractor_destroy(orb_extractor* h)
 {
     if (!h) return;
+    if (g_timing && g_tCalls) {
+        fprintf(stderr, "orbhip timing over %ld single-frame calls (us): copy-in %.1f  launch %.1f  wait %.1f  copy-out %.1f\n", g_tCalls,
+                g_tAcc[0] / g_tCalls, g_tAcc[1] / g_tCalls, g_tAcc[2] / g_tCalls, g_tAcc[3] / g_tCalls);
+        g_tCalls = 0; g_tAcc[0] = g_tAcc[1] = g_tAcc[2] = g_tAcc[3] = 0;
+    }
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     DevBuf* bufs[] = {&h->dPattern, &h->dPatternF, &h->dAngTab, &h->dCells, &h->dXtab, &h->dYtab, &h->dXq, &h->dPath, &h->dBand, &h->dPyr, &h->dCand, &h->dKpl, &h->dOvf, &h->dQt,
@@ -418,7 +432,11 @@ extern "C" int orb_extract_batch_device(orb_extractor* h, const uint8_t* d_imgs,
     if (!h->pyrChains.empty()) {
         // small batches cannot fill the chip with 16-row bands (21 workgroups per frame at 640x480, 5 resident per CU):
         // below ~10 workgroups per CU the 4-row bands (4x the workgroups, each a quarter as long) finish sooner
-        const std::vector<OrbPyrChain>& chains = (long long)h->pyrChains[0].bands * n < 2560 ? h->pyrChainsLat : h->pyrChains;
+        // one or two frames: fewer launches of longer chains with the column tables in LDS
+        static const int oneMax = std::getenv("ORB_PYR_ONE_MAX") ? std::atoi(std::getenv("ORB_PYR_ONE_MAX")) : 2;
+        const std::vector<OrbPyrChain>& chains = n <= oneMax                                  ? h->pyrChainsOne
+                                                 : (long long)h->pyrChains[0].bands * n < 2560 ? h->pyrChainsLat
+                                                                                               : h->pyrChains;
         for (size_t c = 0; c < chains.size(); c++)
             orb_launch_pyr_chain(st, chains[c], d_imgs, rowStride, frameStride, pyr, h->pyrSlab, (const uint4*)h->dXq.p,
                                  (const int2*)h->dYtab.p, (const int2*)h->dBand.p, n, c == 0 ? h->errP() : nullptr,
@@ -555,6 +573,7 @@ extern "C" int orb_extract_batch(orb_extractor* h, const uint8_t* imgs, int nFra
     const size_t imgOff = (statB + cntB + kpB + dsB + 255) & ~(size_t)255;
     if ((rc = ensure_stage(h, whole ? (zero ? imgOff + imgBytes + 256 : statB + cntB + kpB + dsB) : statB + cntB)) != ORB_OK) return rc;
     uint8_t* stg = (uint8_t*)h->hStage;
+    const double tm0 = g_timing ? now_us() : 0.0;
     if (zero) {
         uint8_t* dst = stg + imgOff;
         if (rowStride == (size_t)cols) std::memcpy(dst, imgs, imgBytes);
@@ -599,6 +618,7 @@ extern "C" int orb_extract_batch(orb_extractor* h, const uint8_t* imgs, int nFra
         }
         return ORB_OK;
     };
+    const double tm1 = g_timing ? now_us() : 0.0;
     orb_extractor::Graph& Gr = h->graph1;
     const bool graphable = nFrames == 1 && whole && !h->profiling && !Gr.broken && !std::getenv("ORB_NO_GRAPH");
     const void* curBufs[10];
@@ -646,7 +666,9 @@ extern "C" int orb_extract_batch(orb_extractor* h, const uint8_t* imgs, int nFra
         for (int f = 0; f < nFrames; f++) counts[f] = 0;
         return ORB_OK;
     }
+    const double tm2 = g_timing ? now_us() : 0.0;
     ORB_HIP_TRY(hipStreamSynchronize(h->stream));
+    const double tm3 = g_timing ? now_us() : 0.0;
     h->hStat.assign((const int*)stg, (const int*)stg + orb_extractor::statInts(nFrames));
     h->statFetched = true;
     h->statSerial = 0;                                         // = the batch just run
@@ -669,6 +691,11 @@ extern "C" int orb_extract_batch(orb_extractor* h, const uint8_t* imgs, int nFra
         }
     }
     if (!whole) ORB_HIP_TRY(hipStreamSynchronize(h->stream));
+    if (g_timing && nFrames == 1) {
+        const double tm4 = now_us();
+        g_tAcc[0] += tm1 - tm0; g_tAcc[1] += tm2 - tm1; g_tAcc[2] += tm3 - tm2; g_tAcc[3] += tm4 - tm3;
+        g_tCalls++;
+    }
     return ORB_OK;
 }
 

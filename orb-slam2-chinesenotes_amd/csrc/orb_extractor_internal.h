@@ -73,6 +73,7 @@ struct orb_extractor {
     DevBuf dPattern, dPatternF, dAngTab, dCells, dXtab, dYtab, dXq, dPath, dBand;   // constants
     std::vector<OrbPyrChain> pyrChains;         // empty: per-level pyramid kernels (k_copy_level0, k_resize_*)
     std::vector<OrbPyrChain> pyrChainsLat;      // the same levels in bands of 4 rows, for batches of a few frames
+    std::vector<OrbPyrChain> pyrChainsOne;      // one or two frames: up to ORB_PYR_MAXCHAIN levels per launch
     std::vector<size_t> xtabOff, ytabOff;       // per level offsets (in int2 units)
     std::vector<long long> xqOff;               // per level offset into dXq (uint4 units), -1 = level not eligible
     DevBuf dPyr, dCand, dKpl, dOvf;             // per-batch scratch (dOvf: FAST strips to redo densely)

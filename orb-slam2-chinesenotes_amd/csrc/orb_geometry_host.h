@@ -37,6 +37,7 @@ struct OrbGeomPlan {                        // everything build_geometry derives
     // pyramid chains (k_pyr_chain): empty when some level is not eligible -- the per-level kernels are used then
     std::vector<OrbPyrChain> chains;        // bands of 16 rows: batches (throughput)
     std::vector<OrbPyrChain> chainsLat;     // bands of 4 rows: a few frames (4x the workgroups, each a quarter as long: latency)
+    std::vector<OrbPyrChain> chainsOne;     // one or two frames: up to ORB_PYR_MAXCHAIN levels per launch, column tables in LDS
     std::vector<int2> bandTab;
 };
 
@@ -182,7 +183,7 @@ static int make_strips(const FastCellRow& row, int wCell, int target, std::vecto
 // the copying chain) unwritten.  Returns false when the chain is not eligible (no column table, a band too large for LDS).
 static bool plan_pyr_chain(const OrbGeom& G, const std::vector<int2>& yt, const std::vector<size_t>& ytabOff,
                            const std::vector<long long>& xqOff, int first, int nSteps, bool copy0, int bandRows,
-                           size_t ldsLimit, OrbPyrChain& C, std::vector<int2>& tab)
+                           size_t ldsLimit, OrbPyrChain& C, std::vector<int2>& tab, bool xqLds = false)
 {
     std::memset(&C, 0, sizeof(C));
     if (first < 1 || nSteps < 1 || nSteps > ORB_PYR_MAXCHAIN || first + nSteps > G.nlevels) return false;
@@ -266,6 +267,16 @@ static bool plan_pyr_chain(const OrbGeom& G, const std::vector<int2>& yt, const 
         T.ldsOff = (int)(rowParamBytes + ((k & 1) ? 0 : r0));
     }
     C.ldsBytes = (int)(rowParamBytes + r0 + r1);
+    if (xqLds) {                                                     // the levels' column tables follow each other in the xq array
+        const long long n = xqOff[first + nSteps - 1] + 3ll * C.st[nSteps - 1].x4 - xqOff[first];
+        bool contiguous = true;
+        for (int k = 0; k + 1 < nSteps; k++) contiguous = contiguous && xqOff[first + k] + 3ll * C.st[k].x4 <= xqOff[first + k + 1];
+        if (contiguous && n > 0 && n <= 1024) {                      // (4 entries of 16 bytes per thread in flight)
+            C.xqLdsOff = C.ldsBytes;
+            C.xqLdsN = (int)n;
+            C.ldsBytes += (int)(16 * n);
+        }
+    }
     if ((size_t)C.ldsBytes > ldsLimit) { tab.resize(tab0); return false; }
     return true;
 }
@@ -456,17 +467,25 @@ static int orb_plan_geometry(const orb_extractor_params& prm, const OrbHostTable
     // pyramid chains: (1, 2) with the level-0 copy, then pairs, the last three levels together when an odd one remains
     P.chains.clear();
     P.chainsLat.clear();
+    P.chainsOne.clear();
     P.bandTab.clear();
-    auto plan_set = [&](std::vector<OrbPyrChain>& set, int bandHi, int bandLo) -> bool {
+    // maxLen 0: pairs as above (throughput); > 0: as few launches as chains of <= maxLen levels allow, the earlier (larger)
+    // levels in the shorter chains (a single frame's duration is launches x dependent round trips, not arithmetic)
+    auto plan_set = [&](std::vector<OrbPyrChain>& set, int bandHi, int bandLo, int maxLen, size_t ldsLimit, bool xqLds) -> bool {
         for (int l = 1; l < nl;) {
             int n = std::min(2, nl - l);
-            if (nl - (l + n) == 1) n = (l == 1) ? n : 3;          // never leave a single level for a launch of its own ...
-            if (l + n > nl) n = nl - l;
+            if (maxLen > 0) {
+                const int left = nl - l, launches = (left + maxLen - 1) / maxLen;
+                n = left / launches;
+            } else {
+                if (nl - (l + n) == 1) n = (l == 1) ? n : 3;      // never leave a single level for a launch of its own ...
+                if (l + n > nl) n = nl - l;
+            }
             OrbPyrChain C;
             bool done = false;
             for (int tryN = n; tryN >= 1 && !done; tryN--)
                 for (int br = bandHi; br >= bandLo && !done; br >>= 1)
-                    if (plan_pyr_chain(G, yt, P.ytabOff, P.xqOff, l, tryN, l == 1, br, (size_t)40 * 1024, C, P.bandTab)) {
+                    if (plan_pyr_chain(G, yt, P.ytabOff, P.xqOff, l, tryN, l == 1, br, ldsLimit, C, P.bandTab, xqLds)) {
                         set.push_back(C);
                         l += tryN;
                         done = true;
@@ -477,7 +496,12 @@ static int orb_plan_geometry(const orb_extractor_params& prm, const OrbHostTable
     };
     if (nl >= 2) {
         const int bandRows = std::getenv("ORB_PYR_BAND") ? std::max(2, std::min(64, std::atoi(std::getenv("ORB_PYR_BAND")))) : 16;
-        if (!plan_set(P.chains, bandRows, std::min(bandRows, 8)) || !plan_set(P.chainsLat, 4, 2)) { P.chains.clear(); P.chainsLat.clear(); P.bandTab.clear(); }
+        const int bandOne = std::getenv("ORB_PYR_BAND_ONE") ? std::max(2, std::min(16, std::atoi(std::getenv("ORB_PYR_BAND_ONE")))) : 4;
+        const bool xl = std::getenv("ORB_PYR_XQLDS") != nullptr;
+        if (!plan_set(P.chains, bandRows, std::min(bandRows, 8), 0, (size_t)40 * 1024, xl) || !plan_set(P.chainsLat, 4, 2, 0, (size_t)40 * 1024, xl) ||
+            !plan_set(P.chainsOne, bandOne, 2, ORB_PYR_MAXCHAIN, (size_t)60 * 1024, true)) {
+            P.chains.clear(); P.chainsLat.clear(); P.chainsOne.clear(); P.bandTab.clear();
+        }
     }
     P.nCells = nCells;
     P.pyrSlab = (size_t)align_up((int)pyrOff, 256);

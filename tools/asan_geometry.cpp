@@ -77,15 +77,22 @@ static int one(const orb_extractor_params& prm, int rows, int cols, const int* s
     // pyramid chains (k_pyr_chain): the chains produce levels 1 .. nl-1 in order; inside a chain every band's row ranges stay
     // inside their levels and inside the LDS regions planned for them, the rows a step reads are rows its source band holds,
     // the bands of every produced level (and the level-0 copy partitions) cover the level without a gap
-    CHECK(P.chains.empty() == P.chainsLat.empty());
-    for (const std::vector<OrbPyrChain>* set : {&P.chains, &P.chainsLat}) if (!set->empty()) {
+    CHECK(P.chains.empty() == P.chainsLat.empty() && P.chains.empty() == P.chainsOne.empty());
+    for (const std::vector<OrbPyrChain>* set : {&P.chains, &P.chainsLat, &P.chainsOne}) if (!set->empty()) {
         int next = 1;
         for (const OrbPyrChain& C : *set) {
             CHECK(C.nSteps >= 1 && C.nSteps <= ORB_PYR_MAXCHAIN && next + C.nSteps <= prm.nlevels);
             const int first = next, ent = C.nSteps + 2;
             CHECK(C.copy0 == (first == 1 ? 1 : 0));
             CHECK(C.srcOff == G.L[first - 1].pyrOff && C.srcW == G.L[first - 1].w && C.srcH == G.L[first - 1].h);
-            CHECK((size_t)C.tabOff + (size_t)C.bands * ent <= P.bandTab.size() && C.ldsBytes <= 40 * 1024);
+            CHECK((size_t)C.tabOff + (size_t)C.bands * ent <= P.bandTab.size() && C.ldsBytes <= (set == &P.chainsOne ? 60 : 40) * 1024);
+            const int bandBytes = C.xqLdsN > 0 ? C.xqLdsOff : C.ldsBytes;   // the row bands end where the column tables start
+            if (C.xqLdsN > 0) {
+                CHECK(C.xqLdsN <= 1024 && (C.xqLdsOff % 16) == 0 && C.xqLdsOff + 16 * C.xqLdsN == C.ldsBytes);
+                for (int k = 0; k < C.nSteps; k++)
+                    CHECK(C.st[k].xqOff >= C.st[0].xqOff && C.st[k].xqOff - C.st[0].xqOff + 3 * C.st[k].x4 <= C.xqLdsN);
+                CHECK((size_t)(C.st[0].xqOff + C.xqLdsN) * 4 <= P.xq.size());
+            }
             CHECK(C.cpr == (C.srcW + 15) / 16 && 16 * C.cpr <= 4 * C.srcLdsPitchDw && (C.srcLdsPitchDw % 4) == 0);
             std::vector<int> covered(C.nSteps + 2, 0);                 // next uncovered row of [source copy, steps...]
             for (int b = 0; b < C.bands; b++) {
@@ -101,7 +108,7 @@ static int one(const orb_extractor_params& prm, int rows, int cols, const int* s
                     CHECK(e[1 + k].x >= 0 && e[1 + k].x <= e[1 + k].y && e[1 + k].y < D.h);
                     CHECK(e[1 + k].y - e[1 + k].x + 1 + 3 <= 64);
                     CHECK((size_t)T.rpOff + 16 * (size_t)((e[1 + k].y - e[1 + k].x + 4) & ~3) <= (size_t)C.srcLdsOff);
-                    CHECK(srcOff + srcBytes <= (size_t)C.ldsBytes);
+                    CHECK(srcOff + srcBytes <= (size_t)bandBytes);
                     for (int y = e[1 + k].x; y <= e[1 + k].y; y++) {       // rows read lie inside the source band
                         const int2 t = P.yt[P.ytabOff[first + k] + y];
                         CHECK((t.x & 0xffff) >= srcRow0 && (int)((unsigned)t.x >> 16) <= srcRow1);
