@@ -717,12 +717,14 @@ def run_c3(args, rank, local_rank, world, dev, comm_dev, dist):
 def run_c5(args, rank, local_rank, world, dev, comm_dev, dist):
     """EuRoC-sized stream: a step = ONE 752x480 query frame: extract + vocabulary descent + SearchByBoW against every
     keyframe of a 1000-keyframe descriptor DB resident in HBM (the Relocalization candidate loop, reference
-    src/Tracking.cc:1471-1492, is the batch axis); match(i) runs beside extract(i+1) over two query slots."""
+    src/Tracking.cc:1471-1492, is the batch axis); the extractor stream runs ahead of the matcher stream over a ring of
+    NSLOT query slots (per-slot events: match(i) waits for extract(i), extract(i) for match(i - NSLOT))."""
     W, H, n_kf = 752, 480, 1000
     ex, mt = capi.Extractor(args.nfeatures, device=local_rank), capi.Matcher(0.7, True, device=local_rank)
     cap = ex.max_keypoints
     QMAX = 8                                                      # stream frames per step in the mini-batch variant
-    F = n_kf + 2 * QMAX                                           # two query slots of up to QMAX stream frames each
+    NSLOT = 4                                                     # query slots of up to QMAX stream frames each
+    F = n_kf + NSLOT * QMAX
     buf = lambda n, dt: torch.zeros(n, dtype=dt, device=dev)
     d_kps, d_desc = buf(F * cap * 28, torch.uint8), buf(F * cap * 32, torch.uint8)
     d_counts, d_node = buf(F, torch.int32), buf(F * cap, torch.int16)
@@ -751,22 +753,22 @@ def run_c5(args, rank, local_rank, world, dev, comm_dev, dist):
     stream = torch.from_numpy(stream_np).to(dev)
     Q = [1]                                                       # stream frames per step (1 = the per-frame configuration)
     kf_idx = torch.arange(n_kf, dtype=torch.int32, device=dev).repeat(QMAX)
-    f_idx = [torch.arange(QMAX, dtype=torch.int32, device=dev).repeat_interleave(n_kf) + (n_kf + s * QMAX) for s in (0, 1)]
-    d_match = [buf(QMAX * n_kf * cap, torch.int32) for _ in (0, 1)]
-    d_nm = [buf(QMAX * n_kf, torch.int32) for _ in (0, 1)]
+    f_idx = [torch.arange(QMAX, dtype=torch.int32, device=dev).repeat_interleave(n_kf) + (n_kf + s * QMAX) for s in range(NSLOT)]
+    d_match = [buf(QMAX * n_kf * cap, torch.int32) for _ in range(NSLOT)]
+    d_nm = [buf(QMAX * n_kf, torch.int32) for _ in range(NSLOT)]
     store = dict(desc=d_desc.data_ptr(), kps=d_kps.data_ptr(), valid=d_valid.data_ptr(), counts=d_counts.data_ptr(),
                  node_of=d_node.data_ptr(), cap=cap, n_frames=F, n_nodes=n_nodes, csr_keys=d_ckeys.data_ptr(),
                  csr_start=d_cstart.data_ptr(), csr_cnt=d_ccnt.data_ptr())
     torch.cuda.synchronize()
 
-    def extract(i):                                # stream frames i*Q .. i*Q+Q-1 -> query slot i % 2
-        s, q = i % 2, Q[0]
+    def extract(i):                                # stream frames i*Q .. i*Q+Q-1 -> query slot i % NSLOT
+        s, q = i % NSLOT, Q[0]
         f0 = n_kf + s * QMAX
         ex.extract_batch_device(stream.data_ptr() + ((i * q) % (n_q - q + 1)) * W * H, q, H, W, W, W * H, d_kps.data_ptr() + f0 * cap * 28,
                                 d_desc.data_ptr() + f0 * cap * 32, cap, d_counts.data_ptr() + f0 * 4)
 
     def match(i):
-        s, q = i % 2, Q[0]
+        s, q = i % NSLOT, Q[0]
         f0 = n_kf + s * QMAX
         voc.transform_device(mt, d_desc.data_ptr() + f0 * cap * 32, d_counts.data_ptr() + f0 * 4, q, cap, 4,
                              d_node_of=d_node.data_ptr() + f0 * cap * 2)
@@ -774,17 +776,24 @@ def run_c5(args, rank, local_rank, world, dev, comm_dev, dist):
                             d_ckeys.data_ptr() + f0 * cap * 4, d_cstart.data_ptr() + f0 * n_nodes * 2, d_ccnt.data_ptr() + f0 * n_nodes * 2)
         mt.match_bow_batch_device(store, kf_idx.data_ptr(), f_idx[s].data_ptr(), q * n_kf, d_match[s].data_ptr(), d_nm[s].data_ptr())
 
+    ex_s, mt_s = torch.cuda.ExternalStream(ex.stream, device=dev), torch.cuda.ExternalStream(mt.stream, device=dev)
+    ev_ex, ev_mt = [torch.cuda.Event() for _ in range(NSLOT)], [torch.cuda.Event() for _ in range(NSLOT)]
+
     def run(n, i0=0):
-        # software pipeline over two query slots: match(i) runs beside extract(i+1).  Both stream waits are taken
-        # BEFORE the two launches, so match(i) waits for extract(i) only and extract(i+1) for match(i-1) only (which
-        # used the slot extract(i+1) is about to overwrite).
-        ex.wait_for(mt.stream)
+        # (called with both streams idle.)  The two streams are coupled per slot only: with two slots and whole-stream waits
+        # the chain match(i-1) -> extract(i+1) -> match(i+1) made two steps cost extract + match + two cross-stream waits
+        # (0.150 ms per frame); with the ring the step is the busier stream's chain
         extract(i0)
+        ev_ex[i0 % NSLOT].record(ex_s)
         for i in range(i0, i0 + n):
-            mt.wait_for(ex.stream)
-            ex.wait_for(mt.stream)
-            extract(i + 1)
+            j = i + 1
+            if j - NSLOT >= i0:
+                ex_s.wait_event(ev_mt[j % NSLOT])                  # match(j - NSLOT) has let go of the slot
+            extract(j)
+            ev_ex[j % NSLOT].record(ex_s)
+            mt_s.wait_event(ev_ex[i % NSLOT])
             match(i)
+            ev_mt[i % NSLOT].record(mt_s)
 
     for _ in range(3):                             # (synchronised calls first: the FAST strip lengths settle)
         run(1)
@@ -818,7 +827,7 @@ def run_c5(args, rank, local_rank, world, dev, comm_dev, dist):
     match_ms = statistics.median(t_m) * 1e3
     if rank != 0:
         return None
-    last, last_q = 3 % 2, 3 % n_q                  # slot / stream frame of the last match above (i = 3)
+    last, last_q = 3 % NSLOT, 3 % n_q              # slot / stream frame of the last match above (i = 3)
     fq = n_kf + last * QMAX                        # store index of that stream frame
     nm = d_nm[last][:n_kf].cpu().numpy()
     cnts = d_counts.cpu().numpy()

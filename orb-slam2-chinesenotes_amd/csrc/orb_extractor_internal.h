@@ -63,6 +63,7 @@ struct orb_extractor {
     // Strip-length feedback without a sync: a device-path batch leaves its overflow counters in pinned memory behind an
     // event; the next device-path call applies them if they have arrived (callers that never call orb_extractor_sync
     // between batches -- device pipelines -- would otherwise keep redoing overflowing strips densely for ever).
+    bool specNoDense = false;               // single-frame host call: leave k_fast_strips_dense out, redo the frame if a strip overflowed
     int* ovfHost = nullptr;                 // pinned copy of the overflow block (kOvfInts ints)
     hipEvent_t ovfEv = nullptr;
     unsigned batchSerial = 0, ovfPendingSerial = 0, ovfAppliedSerial = 0;

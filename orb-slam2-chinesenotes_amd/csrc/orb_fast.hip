@@ -905,7 +905,7 @@ size_t orb_fast_dense_lds_bytes(int pdw, int rowsMax, int sdw)
 void orb_launch_fast_strips(hipStream_t st, const OrbGeom& G, const uint8_t* pyr, size_t pyrSlab,
                             const OrbStrip* strips, int nStrips, const uint32_t* pathTab, unsigned long long* cand,
                             size_t candSlab, int* candCount, int* errFlags, int* ovfCount, int* ovfList, int iniTh, int minTh,
-                            int pdw, int rowsMax, int sdw, int candCap, int nFrames, int fixedPitch)
+                            int pdw, int rowsMax, int sdw, int candCap, int nFrames, int fixedPitch, bool skipDense)
 {
     if (nStrips == 0) return;
     unsigned inv = 0;
@@ -922,6 +922,7 @@ void orb_launch_fast_strips(hipStream_t st, const OrbGeom& G, const uint8_t* pyr
     hipLaunchKernelGGL(k_fast_strips, grid, dim3(WAVE),
                        orb_fast_lds_bytes(pdw, rowsMax, candCap), st, G, pyr, pyrSlab, strips, pathTab, cand, candSlab,
                        candCount, errFlags, ovfCount, ovfList, iniTh, minTh, pdw, rowsMax, candCap, nStrips, nFrames, inv);
+    if (skipDense) return;                                 // the caller looks at *ovfCount afterwards and redoes the batch if it is not 0
     const long long all = (long long)nStrips * nFrames;
     // (the list is almost always empty: a small grid keeps this launch short in a single frame's chain; the kernel
     // strides over the list whatever its length)

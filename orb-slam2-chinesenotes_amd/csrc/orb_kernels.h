@@ -17,7 +17,7 @@ size_t orb_fast_dense_lds_bytes(int pdw, int rowsMax, int sdw);
 void orb_launch_fast_strips(hipStream_t st, const OrbGeom& G, const uint8_t* pyr, size_t pyrSlab,
                             const OrbStrip* strips, int nStrips, const uint32_t* pathTab, unsigned long long* cand,
                             size_t candSlab, int* candCount, int* errFlags, int* ovfCount, int* ovfList, int iniTh, int minTh,
-                            int pdw, int rowsMax, int sdw, int candCap, int nFrames, int fixedPitch);
+                            int pdw, int rowsMax, int sdw, int candCap, int nFrames, int fixedPitch, bool skipDense = false);
 size_t orb_fast_p_lds_bytes(int P, int rowsMax, int candCap);
 size_t orb_quadtree_lds_bytes(int sortCap, int nodeCap);
 void orb_launch_quadtree(hipStream_t st, const OrbGeom& G, unsigned long long* cand, size_t candSlab,

@@ -391,10 +391,8 @@ __device__ __forceinline__ void match_small_node(const BowSide& A, const BowSide
 // best / second-best are two DPP min-reductions on packed (distance << 16 | position).
 // (two 16-wave workgroups per CU need 8 waves per SIMD: at most 64 VGPRs)
 template <bool KK>
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_match_bow(const BowSide* __restrict__ sidesA, const BowSide* __restrict__ sidesB,
-                                                    int nNodes, int capLds, float ratio, int checkOri,
-                                                    int32_t* __restrict__ match, int matchStride,
-                                                    int32_t* __restrict__ nmatchesOut)
+__device__ __forceinline__ void match_bow_pair(const BowSide& A, const BowSide& B, int nNodes, int capLds, float ratio, int checkOri,
+                                               int32_t* __restrict__ match, int matchStride, int32_t* __restrict__ nmatchesOut)
 {
     extern __shared__ uint32_t msm[];
     // carve-up: keysA[cap] keysB[cap] tmp[cap] cntw[nNodes] (u32) | startA cntA startB cntB [nNodes] (u16) |
@@ -416,9 +414,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     __shared__ int nm;
     __shared__ int nextNode;
 
-    const BowSide A = sidesA[blockIdx.x], B = sidesB[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63;
-    if (A.n < 0 || B.n < 0 || A.n > capLds || B.n > capLds) {      // invalid pair (k_fill_sides): reported, never run
+    if (A.n < 0 || B.n < 0 || A.n > capLds || B.n > capLds) {      // invalid pair (bow_side_of_store): reported, never run
         for (int i = tid; i < matchStride; i += blockDim.x) match[(size_t)blockIdx.x * matchStride + i] = -1;
         if (tid == 0) nmatchesOut[blockIdx.x] = -1;
         return;
@@ -585,31 +582,44 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     if (tid == 0) nmatchesOut[blockIdx.x] = nm;
 }
 
-// fills the BowSide descriptors of a batch of pairs from a feature store (device side, no host sync)
-__global__ void k_fill_sides(orb_featstore S, const int32_t* __restrict__ kfIndex, const int32_t* __restrict__ fIndex,
-                             int nPairs, int nNodes, BowSide* __restrict__ sidesA, BowSide* __restrict__ sidesB)
+// the BowSide of frame `idx` of a feature store (side 0 = keyframe: carries the "has a good MapPoint" flags)
+__device__ __forceinline__ BowSide bow_side_of_store(const orb_featstore& S, int idx, int s, int nNodes)
 {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= nPairs) return;
-    const int32_t idx[2] = {kfIndex[p], fIndex[p]};
-    BowSide* outs[2] = {sidesA + p, sidesB + p};
-    for (int s = 0; s < 2; s++) {
-        BowSide b;
-        const bool inStore = idx[s] >= 0 && idx[s] < S.n_frames;
-        const size_t row = inStore ? (size_t)idx[s] * S.cap : 0;
-        b.desc = S.desc + row * 32;
-        b.angle = &S.kps[row].angle;
-        b.angleStride = sizeof(orb_keypoint) / sizeof(float);
-        b.valid = (s == 0 && S.valid) ? S.valid + row : nullptr;
-        b.nodeOf = S.node_of + row;
-        const int n = inStore ? S.counts[idx[s]] : -1;
-        b.n = (n >= 0 && n <= S.cap) ? n : -1;             // an index or count outside the store: the pair reports nmatches = -1
-        b.csrKeys = S.csr_keys ? S.csr_keys + row : nullptr;
-        b.csrStart = (S.csr_keys && inStore) ? S.csr_start + (size_t)idx[s] * nNodes : nullptr;
-        b.csrCnt = (S.csr_keys && inStore) ? S.csr_cnt + (size_t)idx[s] * nNodes : nullptr;
-        if (!S.csr_start || !S.csr_cnt) b.csrKeys = nullptr;
-        *outs[s] = b;
-    }
+    BowSide b;
+    const bool inStore = idx >= 0 && idx < S.n_frames;
+    const size_t row = inStore ? (size_t)idx * S.cap : 0;
+    b.desc = S.desc + row * 32;
+    b.angle = &S.kps[row].angle;
+    b.angleStride = sizeof(orb_keypoint) / sizeof(float);
+    b.valid = (s == 0 && S.valid) ? S.valid + row : nullptr;
+    b.nodeOf = S.node_of + row;
+    const int n = inStore ? S.counts[idx] : -1;
+    b.n = (n >= 0 && n <= S.cap) ? n : -1;                 // an index or count outside the store: the pair reports nmatches = -1
+    b.csrKeys = S.csr_keys ? S.csr_keys + row : nullptr;
+    b.csrStart = (S.csr_keys && inStore) ? S.csr_start + (size_t)idx * nNodes : nullptr;
+    b.csrCnt = (S.csr_keys && inStore) ? S.csr_cnt + (size_t)idx * nNodes : nullptr;
+    if (!S.csr_start || !S.csr_cnt) b.csrKeys = nullptr;
+    return b;
+}
+
+template <bool KK>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_match_bow(const BowSide* __restrict__ sidesA, const BowSide* __restrict__ sidesB,
+                                                    int nNodes, int capLds, float ratio, int checkOri,
+                                                    int32_t* __restrict__ match, int matchStride,
+                                                    int32_t* __restrict__ nmatchesOut)
+{
+    const BowSide A = sidesA[blockIdx.x], B = sidesB[blockIdx.x];
+    match_bow_pair<KK>(A, B, nNodes, capLds, ratio, checkOri, match, matchStride, nmatchesOut);
+}
+
+// SearchByBoW(KeyFrame*, Frame&) over pairs (kfIndex[p], fIndex[p]) of a feature store: the pair's two sides are derived
+// by the workgroup itself (a separate fill kernel was a 5 us launch in front of every batch, a tenth of a 1000-pair query)
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_match_bow_store(orb_featstore S, const int32_t* __restrict__ kfIndex,
+                                                    const int32_t* __restrict__ fIndex, int nNodes, float ratio, int checkOri,
+                                                    int32_t* __restrict__ match, int32_t* __restrict__ nmatchesOut)
+{
+    const BowSide A = bow_side_of_store(S, kfIndex[blockIdx.x], 0, nNodes), B = bow_side_of_store(S, fIndex[blockIdx.x], 1, nNodes);
+    match_bow_pair<false>(A, B, nNodes, S.cap, ratio, checkOri, match, S.cap, nmatchesOut);
 }
 
 // ------------------------------------------------------------------ host side
@@ -713,14 +723,18 @@ extern "C" int orb_match_bow_batch_device(orb_matcher* m, const orb_featstore* s
     if (nPairs == 0) return ORB_OK;
     if (store->cap <= 0 || store->cap > 8192) { orb_set_error("featstore cap must be 1..8192"); return ORB_ERR_UNSUPPORTED; }
     ORB_HIP_TRY(hipSetDevice(m->device));
-    int rc;
-    if ((rc = m->sidesA.ensure(sizeof(BowSide) * (size_t)nPairs)) != ORB_OK) return rc;
-    if ((rc = m->sidesB.ensure(sizeof(BowSide) * (size_t)nPairs)) != ORB_OK) return rc;
     const int nNodes = store->n_nodes > 0 ? store->n_nodes : 128;
-    hipLaunchKernelGGL(k_fill_sides, dim3((nPairs + 255) / 256), dim3(256), 0, m->stream, *store, d_kf, d_f, nPairs, nNodes,
-                       (BowSide*)m->sidesA.p, (BowSide*)m->sidesB.p);
-    return launch_match(m, false, (const BowSide*)m->sidesA.p, (const BowSide*)m->sidesB.p, nPairs, nNodes, store->cap,
-                        ratio, checkOri, d_match, store->cap, d_nm);
+    const size_t lds = match_lds_bytes(store->cap, nNodes);
+    if (lds > 156 * 1024 || store->cap > 1024 * ORB_CSR_MAXPT) {
+        orb_set_error("feature capacity %d x %d nodes exceeds the match kernel's LDS budget", store->cap, nNodes);
+        return ORB_ERR_UNSUPPORTED;
+    }
+    if (lds > 64 * 1024)                                   // frames of > ~3900 features: the CU's whole LDS for one pair
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_match_bow_store), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_match_bow_store, dim3(nPairs), dim3(1024), lds, m->stream, *store, d_kf, d_f, nNodes, ratio, checkOri, d_match,
+                       d_nm);
+    ORB_HIP_TRY(hipGetLastError());
+    return ORB_OK;
 }
 
 extern "C" int orb_bow_build_csr_device(orb_matcher* m, const uint16_t* d_node_of, const int32_t* d_counts, int nFrames, int cap,

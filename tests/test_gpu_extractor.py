@@ -542,6 +542,22 @@ def test_strip_lengths_settle_without_any_sync():
         assert cnt[i] == len(rk) and kk[i, :len(rk)].tobytes() == rk.tobytes() and np.array_equal(dd[i, :len(rk)], rd)
 
 
+def test_single_frame_call_without_the_dense_launch_redoes_overflowing_frames():
+    """orb_extract leaves k_fast_strips_dense out of its chain and looks at the overflow counter afterwards: a frame whose
+    strips overflow their candidate queues (noise) is redone with that kernel in the same call, the strips get shorter, and
+    the replayed graph of the later calls gives the same result; ORB_NO_SPEC=1 (always launch it) changes nothing."""
+    rng = np.random.default_rng(5)
+    imgs = [rng.integers(0, 256, (300, 420)).astype(np.uint8), synth.synth_frame(3, 420, 300), rng.integers(0, 256, (300, 420)).astype(np.uint8)]
+    ref = oracle.Extractor(600)
+    want = [ref.extract(im) for im in imgs]
+    ex = capi.Extractor(600)
+    for rep in range(4):
+        for im, (rk, rd) in zip(imgs, want):
+            k, d = ex.extract(im)
+            assert k.tobytes() == rk.tobytes() and np.array_equal(d, rd), rep
+    ex.close()
+
+
 def test_host_batch_pipeline_strided_rows_and_tiny_tail():
     """The chunked host pipeline with a row stride larger than the width (pageable: row-wise staging; pinned: 2-D copies),
     17 frames (chunks of 8, 8 and a tail of 1) and more handles' worth of frames than devices in orb_multi (3 frames on
