@@ -432,8 +432,8 @@ extern "C" int orb_extract_batch_device(orb_extractor* h, const uint8_t* d_imgs,
     if (!h->pyrChains.empty()) {
         // small batches cannot fill the chip with 16-row bands (21 workgroups per frame at 640x480, 5 resident per CU):
         // below ~10 workgroups per CU the 4-row bands (4x the workgroups, each a quarter as long) finish sooner
-        // one or two frames: fewer launches of longer chains with the column tables in LDS
-        static const int oneMax = std::getenv("ORB_PYR_ONE_MAX") ? std::atoi(std::getenv("ORB_PYR_ONE_MAX")) : 2;
+        // up to 32 frames: fewer launches of longer chains (column tables in LDS where they fit)
+        static const int oneMax = std::getenv("ORB_PYR_ONE_MAX") ? std::atoi(std::getenv("ORB_PYR_ONE_MAX")) : 32;
         const std::vector<OrbPyrChain>& chains = n <= oneMax                                  ? h->pyrChainsOne
                                                  : (long long)h->pyrChains[0].bands * n < 2560 ? h->pyrChainsLat
                                                                                                : h->pyrChains;
