@@ -234,8 +234,8 @@ class Extractor:
         if img.size and img.strides[1] != 1:
             img = np.ascontiguousarray(img)
         cap = self.max_keypoints
-        kps = np.zeros(cap, KP_DTYPE)
-        desc = np.zeros((cap, 32), np.uint8)
+        kps = np.empty(cap, KP_DTYPE)                      # (only the first n entries are written and returned)
+        desc = np.empty((cap, 32), np.uint8)
         n = C.c_int(0)
         rows, cols = (img.shape if img.ndim == 2 else (0, 0))
         stride = img.strides[0] if img.size else 0
