@@ -326,6 +326,20 @@ __device__ __forceinline__ void match_small_node(const BowSide& A, const BowSide
         for (int g = 0; g < GA; g++) {
             if (abase + 4 * g >= na) continue;
             const int iA = iAg[g];
+            // No free column within TH_LOW of any of the four A features: nothing can be accepted, nothing changes (most
+            // groups of a pair of unrelated frames, e.g. a query against a keyframe DB) -- the two row reductions, the
+            // acceptance test and the commit logic (~50 of a group's ~70 instructions) are skipped.
+            {
+                bool near = false;
+#pragma unroll
+                for (int k = 0; k < NB; k++) {
+                    unsigned d = 0;
+#pragma unroll
+                    for (int w = 0; w < 8; w++) d += __popc(dB[k][w] ^ dA[g][w]);
+                    near = near || (!taken[k] && (KK ? d < (unsigned)TH_LOW : d <= (unsigned)TH_LOW));
+                }
+                if (__ballot(near && okAg[g]) == 0) continue;
+            }
             unsigned r1, r2;
             reduce2(dA[g], r1, r2);
             const int b1 = (int)(r1 >> 16), b2 = (int)(r2 >> 16);                 // 256 when nothing is left
@@ -487,6 +501,8 @@ __device__ __forceinline__ void match_bow_pair(const BowSide& A, const BowSide& 
 #pragma unroll
                         for (int w = 0; w < 8; w++) d1 += __popc(dB1[w] ^ a8[w]);
                     }
+                    // (nothing within TH_LOW: no acceptance possible, see match_small_node)
+                    if (__ballot(KK ? min(d0, d1) < (unsigned)TH_LOW : min(d0, d1) <= (unsigned)TH_LOW) == 0) continue;
                     // packed (distance << 16 | position): the lane's smaller and larger value, then the wave's two smallest
                     const unsigned v0 = (d0 << 16) | (unsigned)lane, v1 = (d1 << 16) | (unsigned)(lane + WAVE);
                     const unsigned lo = min(v0, v1), hi = max(v0, v1);
