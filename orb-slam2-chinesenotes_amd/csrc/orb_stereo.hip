@@ -5,9 +5,11 @@
 // Frame.cc must link unchanged, so this is an ADDITIONAL entry point, parity-
 // checked against the oracle's restatement; a maintainer may call it from ComputeStereoMatches.
 //
-//   k_stereo_match     one wave64 per left keypoint: row-band test against every right keypoint
-//                      (no row table: 64 candidates per step, ascending index = the table's order),
-//                      Hamming coarse match (first minimum wins), 11x11 SAD at 11 offsets from LDS
+//   k_stereo_rows      one workgroup per pair: per right keypoint its row band, octave and x as one record, and the
+//                      reference's vRowIndices (:528-540) as a CSR over image rows
+//   k_stereo_match     one wave64 per left keypoint: the right keypoints of its row (64 candidates per step; the minimum of
+//                      (distance << 16 | index) IS "first minimum wins" whatever the order inside a row's list),
+//                      Hamming coarse match, 11x11 SAD at 11 offsets from LDS
 //                      patches (exact integers: the float patches of the reference hold integers),
 //                      parabola fit and depth in float with the reference's operation order.
 //   k_stereo_outliers  one workgroup per pair: median SAD by histogram selection, cut >= 1.5*1.4*median (:685-698).
@@ -29,37 +31,73 @@ __device__ __forceinline__ unsigned st_umin_dpp(unsigned v)
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
-// Right-image side of the coarse search, once per pair instead of once per LEFT keypoint: per right keypoint its row
-// band (:528-540: r = 2 * scale[octave], rows floor(y - r) .. ceil(y + r)), octave and x as one 16-byte record, and --
-// the extractor emits keypoints level after level -- the index at which every level starts, so that a left keypoint of
-// level l scans only levels l-1 .. l+1 (:583).  Keypoints in any other order (a caller's own arrays) raise `unsorted`
-// and are scanned in full.  lv = [nPairs][ORB_MAX_LEVELS + 1].
-__global__ __launch_bounds__(256) void k_stereo_prep(const OrbGeom G, const orb_keypoint* __restrict__ kR0, int nR,
-                                                     const int32_t* __restrict__ countsR, size_t stride,
-                                                     uint4* __restrict__ rec0, size_t recStride, int* __restrict__ lv0,
-                                                     int* __restrict__ unsorted0)
+// Right-image side of the coarse search, once per pair instead of once per LEFT keypoint.  Per right keypoint its row band
+// (:528-540: r = 2 * scale[octave], rows floor(y - r) .. ceil(y + r)), octave and x as one 16-byte record, and
+// vRowIndices (:528-540) of the pair as a CSR: rowStart[row] .. rowStart[row + 1] index the right keypoints whose band
+// covers the row (u16 indices, any order inside a row).  A left keypoint then looks at the ~40 right keypoints of its row
+// instead of testing the bands of all of them (1200 of 2000 at KITTI size with the level windows of the earlier version:
+// three quarters of the search kernel's instructions).  One workgroup per pair, counters in LDS.
+// dynamic LDS: cnt[nRows + 1] | fill[nRows] | part[1024] ints
+__global__ __launch_bounds__(1024) void k_stereo_rows(const OrbGeom G, const orb_keypoint* __restrict__ kR0,
+                                                      uint4* __restrict__ rec0, size_t recStride, int nR,
+                                                      const int32_t* __restrict__ countsR, size_t stride, int nRows,
+                                                      int maxBand, int* __restrict__ rowStart0,
+                                                      unsigned short* __restrict__ rowList0, size_t listCap)
 {
-    const int pr = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    extern __shared__ int rsm[];
+    int* cnt = rsm;
+    int* fill = cnt + nRows + 1;
+    int* part = fill + nRows;
+    const int pr = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
     const int Nr = countsR ? min(countsR[pr], (int)stride) : nR;
-    int* lv = lv0 + (size_t)pr * (ORB_MAX_LEVELS + 1);
-    const int nl = G.nlevels;
-    if (Nr <= 0) {
-        if (i == 0)
-            for (int o = 0; o <= nl; o++) lv[o] = 0;
-        return;
-    }
-    if (i >= Nr) return;
+    uint4* recs = rec0 + recStride * pr;
     const orb_keypoint* kR = kR0 + stride * pr;
-    const orb_keypoint kp = kR[i];
-    const int oc = min(max(kp.octave, 0), nl - 1);
-    const float r = __fmul_rn(2.0f, G.L[oc].scale);                          // :531
-    const int maxr = (int)ceilf(__fadd_rn(kp.y, r)), minr = (int)floorf(__fsub_rn(kp.y, r));
-    rec0[recStride * pr + i] = make_uint4((unsigned)minr, (unsigned)maxr, (unsigned)kp.octave, __float_as_uint(kp.x));
-    const int prevOc = i > 0 ? min(max(kR[i - 1].octave, 0), nl - 1) : -1;
-    if (oc < prevOc) unsorted0[pr] = 1;
-    for (int o = prevOc + 1; o <= oc; o++) lv[o] = i;
-    if (i == Nr - 1)
-        for (int o = oc + 1; o <= nl; o++) lv[o] = Nr;
+    int* rowStart = rowStart0 + (size_t)pr * (nRows + 1);
+    unsigned short* rowList = rowList0 + listCap * pr;
+    for (int y = tid; y <= nRows; y += T) cnt[y] = 0;
+    for (int y = tid; y < nRows; y += T) fill[y] = 0;
+    __syncthreads();
+    // (a band longer than maxBand cannot come from a finite y: such a keypoint gets no rows -- the reference would index
+    // vRowIndices out of range with it)
+    for (int i = tid; i < Nr; i += T) {
+        const orb_keypoint kp = kR[i];
+        const int oc = min(max(kp.octave, 0), G.nlevels - 1);
+        const float r = __fmul_rn(2.0f, G.L[oc].scale);                      // :531
+        const int maxr = (int)ceilf(__fadd_rn(kp.y, r)), minr = (int)floorf(__fsub_rn(kp.y, r));
+        const uint4 rc = make_uint4((unsigned)minr, (unsigned)maxr, (unsigned)kp.octave, __float_as_uint(kp.x));
+        recs[i] = rc;                                              // (read back below by the thread that wrote it)
+        const int lo = max((int)rc.x, 0), hi = min((int)rc.y, nRows - 1);
+        if ((int)rc.y - (int)rc.x < maxBand)
+            for (int y = lo; y <= hi; y++) atomicAdd(&cnt[y], 1);
+    }
+    __syncthreads();
+    {   // exclusive scan of cnt[0 .. nRows) in place, the total into cnt[nRows]
+        const int C = (nRows + T - 1) / T;
+        const int b = min(tid * C, nRows), e = min(b + C, nRows);
+        int sum = 0;
+        for (int y = b; y < e; y++) sum += cnt[y];
+        part[tid] = sum;
+        __syncthreads();
+        if (tid < WAVE) {
+            int mine = 0;
+            for (int j = 0; j < 16; j++) mine += part[16 * tid + j];
+            const int incl = orb_wave_scan_incl(mine);
+            int run = incl - mine;
+            for (int j = 0; j < 16; j++) { const int v = part[16 * tid + j]; part[16 * tid + j] = run; run += v; }
+            if (tid == WAVE - 1) cnt[nRows] = incl;
+        }
+        __syncthreads();
+        int run = part[tid];
+        for (int y = b; y < e; y++) { const int v = cnt[y]; cnt[y] = run; run += v; }
+    }
+    __syncthreads();
+    for (int y = tid; y <= nRows; y += T) rowStart[y] = cnt[y];
+    for (int i = tid; i < Nr; i += T) {
+        const uint4 rc = recs[i];
+        const int lo = max((int)rc.x, 0), hi = min((int)rc.y, nRows - 1);
+        if ((int)rc.y - (int)rc.x < maxBand)
+            for (int y = lo; y <= hi; y++) rowList[cnt[y] + atomicAdd(&fill[y], 1)] = (unsigned short)i;
+    }
 }
 
 // grid (left keypoint, pair): pair p uses frames frame0 + p of the two pyramids and rows [p * stride, ...) of the
@@ -77,14 +115,14 @@ __global__ __launch_bounds__(WAVE) void k_stereo_match(const OrbGeom G, const ui
                                                        float* __restrict__ depth0,
                                                        unsigned long long* __restrict__ pairs0,
                                                        const uint4* __restrict__ rec0,
-                                                       size_t recStride, const int* __restrict__ lv0,
-                                                       const int* __restrict__ unsorted0)
+                                                       size_t recStride, const int* __restrict__ rowStart0,
+                                                       const unsigned short* __restrict__ rowList0, size_t listCap)
 {
     __shared__ int IL[11][11];
     __shared__ int IR[11][21];
     __shared__ int part[11][11];
     const int iL = blockIdx.x, lane = threadIdx.x, pr = blockIdx.y;
-    const int N = countsL ? min(countsL[pr], (int)stride) : nL, Nr = countsR ? min(countsR[pr], (int)stride) : nR;
+    const int N = countsL ? min(countsL[pr], (int)stride) : nL;
     const uint8_t* pyrL = pyrL0 + slabL * pr;
     const uint8_t* pyrR = pyrR0 + slabR * pr;
     const orb_keypoint* kL = kL0 + stride * pr;
@@ -94,15 +132,6 @@ __global__ __launch_bounds__(WAVE) void k_stereo_match(const OrbGeom G, const ui
     float* depth = depth0 + stride * pr;
     unsigned long long* pairs = pairs0 + stride * pr;
     if (iL >= N) return;
-    // the pair's level table and order flag are requested here, before the left keypoint is known (one round trip less in
-    // the chain keypoint -> level range -> records -> descriptors -> patches)
-    int lvAll[ORB_MAX_LEVELS + 1];
-    {
-        const int* lv = lv0 + (size_t)pr * (ORB_MAX_LEVELS + 1);
-#pragma unroll
-        for (int o = 0; o <= ORB_MAX_LEVELS; o++) lvAll[o] = lv[o];
-    }
-    const int unsortedR = unsorted0[pr];
     // (every left keypoint owns slot iL of `pairs`: ~0 = no match.  One atomic slot counter per pair used to serialise all
     // the waves of a batch on ONE cache line of the L2: 64 k returning atomics took longer than the search itself)
     if (lane == 0) { uRight[iL] = -1.0f; depth[iL] = -1.0f; pairs[iL] = ~0ull; }
@@ -121,48 +150,45 @@ __global__ __launch_bounds__(WAVE) void k_stereo_match(const OrbGeom G, const ui
         const uint4 lo = reinterpret_cast<const uint4*>(dL + (size_t)iL * 32)[0], hi = reinterpret_cast<const uint4*>(dL + (size_t)iL * 32)[1];
         dl[0] = lo.x; dl[1] = lo.y; dl[2] = lo.z; dl[3] = lo.w; dl[4] = hi.x; dl[5] = hi.y; dl[6] = hi.z; dl[7] = hi.w;
     }
-    // candidates come from the per-pair records of k_stereo_prep; only the levels levelL-1 .. levelL+1 are scanned (when
-    // the right keypoints are in level order).  A wave is a chain of dependent global round trips and nothing else, so the
-    // scan is arranged for FEW of them: every lane keeps its own best over the records lane, lane + 64, ... (one wave
-    // reduction at the end: the minimum of (distance << 16 | index) IS "first minimum wins"), four chunks of 64 records
-    // are requested at once, then the descriptors of their candidates, then the distances.
+    // candidates = the right keypoints of the row (k_stereo_rows).  A wave is a chain of dependent global round trips and
+    // little else, so two chunks of 64 list entries are requested at once, then their records, then the descriptors of
+    // those that pass the octave and disparity tests; every lane keeps its own best (one wave reduction at the end).
     const uint4* recs = rec0 + recStride * pr;
-    int scanLo = 0, scanHi = Nr;
-    if (!unsortedR) {
-        const int iLo = min(max(levelL - 1, 0), G.nlevels), iHi = min(max(levelL + 2, 0), G.nlevels);
-#pragma unroll
-        for (int o = 0; o <= ORB_MAX_LEVELS; o++) {               // (a select chain: the table sits in registers)
-            if (o == iLo) scanLo = lvAll[o];
-            if (o == iHi) scanHi = lvAll[o];
-        }
+    const unsigned short* rowList = rowList0 + listCap * pr;
+    int s0, s1;
+    {
+        const int* rs = rowStart0 + (size_t)pr * (nRows + 1) + row;
+        s0 = rs[0]; s1 = rs[1];
     }
     unsigned best = 0xFFFFFFFFu;
     float bestX = 0.0f;                                            // x of this lane's best candidate (its record is at hand)
-    for (int base = scanLo & ~(WAVE - 1); base < scanHi; base += 4 * WAVE) {
-        uint4 rc[4];
+    for (int base = s0; base < s1; base += 2 * WAVE) {
+        int idx[2];
 #pragma unroll
-        for (int k = 0; k < 4; k++) rc[k] = recs[min(base + k * WAVE + lane, Nr - 1)];
-        bool cand[4];
+        for (int k = 0; k < 2; k++) idx[k] = rowList[min(base + k * WAVE + lane, s1 - 1)];
+        uint4 rc[2];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < 2; k++) rc[k] = recs[idx[k]];
+        bool cand[2];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
             const int oct = (int)rc[k].z;
             const float x = __uint_as_float(rc[k].w);
-            cand[k] = base + k * WAVE + lane < scanHi && row >= (int)rc[k].x && row <= (int)rc[k].y && oct >= levelL - 1 &&
-                      oct <= levelL + 1 && x >= minU && x <= maxU;
+            cand[k] = base + k * WAVE + lane < s1 && oct >= levelL - 1 && oct <= levelL + 1 && x >= minU && x <= maxU;
         }
-        uint4 lo[4], hi[4];
+        uint4 lo[2], hi[2];
 #pragma unroll
-        for (int k = 0; k < 4; k++)
+        for (int k = 0; k < 2; k++)
             if (cand[k]) {
-                const uint4* d = reinterpret_cast<const uint4*>(dR + (size_t)(base + k * WAVE + lane) * 32);
+                const uint4* d = reinterpret_cast<const uint4*>(dR + (size_t)idx[k] * 32);
                 lo[k] = d[0]; hi[k] = d[1];
             }
 #pragma unroll
-        for (int k = 0; k < 4; k++)
+        for (int k = 0; k < 2; k++)
             if (cand[k]) {
                 const int dist = __popc(dl[0] ^ lo[k].x) + __popc(dl[1] ^ lo[k].y) + __popc(dl[2] ^ lo[k].z) + __popc(dl[3] ^ lo[k].w) +
                                  __popc(dl[4] ^ hi[k].x) + __popc(dl[5] ^ hi[k].y) + __popc(dl[6] ^ hi[k].z) + __popc(dl[7] ^ hi[k].w);
-                const unsigned key = ((unsigned)dist << 16) | (unsigned)(base + k * WAVE + lane);
+                const unsigned key = ((unsigned)dist << 16) | (unsigned)idx[k];
                 if (key < best) { best = key; bestX = __uint_as_float(rc[k].w); }
             }
     }
@@ -316,28 +342,33 @@ static int stereo_launch(orb_extractor* left, orb_extractor* right, int frameL, 
     int rc;
     const size_t perPair = stride;                                  // (SAD, index) slots per pair
     // scratch: pairs[perPair * nPairs] (u64, slot iL of pair p = left keypoint iL) | rec[recStride * nPairs] (uint4)
-    //          | unsorted[nPairs] (cleared) | lv[nPairs][ORB_MAX_LEVELS + 1]
+    //          | rowStart[nPairs][nRows + 1] (int) | rowList[nPairs][listCap] (u16)
     const size_t nSlots = perPair * nPairs;
     const size_t recStride = std::max<size_t>(stride, (size_t)(cR ? 0 : nR));       // single pair: stride is the LEFT count
     const size_t nRecs = recStride * nPairs;
-    if ((rc = left->dStereo.ensure((size_t)8 * (nSlots + 1) + (size_t)16 * nRecs + (size_t)4 * nPairs * (2 + ORB_MAX_LEVELS + 1) + 16)) != ORB_OK)
+    const int nRows = left->G.L[0].h;
+    // rows a right keypoint's band can cover: floor(y - r) .. ceil(y + r), r = 2 * scale <= 2 * scale of the last level
+    const int maxBand = std::min(nRows, 2 * (int)std::ceil(2.0 * left->G.L[left->G.nlevels - 1].scale) + 3);
+    const size_t listCap = (recStride * (size_t)maxBand + 7) & ~(size_t)7;
+    const size_t rowsLds = ((size_t)2 * nRows + 1 + 1024) * 4;
+    if (rowsLds > 64 * 1024) { orb_set_error("stereo: %d image rows exceed the row table's LDS budget", nRows); return ORB_ERR_UNSUPPORTED; }
+    if ((rc = left->dStereo.ensure((size_t)8 * (nSlots + 1) + (size_t)16 * nRecs + (size_t)4 * nPairs * (nRows + 1) + (size_t)2 * nPairs * listCap + 64)) != ORB_OK)
         return rc;
     hipStream_t st = left->stream;
     ORB_HIP_TRY(hipEventRecord(left->waitEv, right->stream));      // the right pyramid must be complete
     ORB_HIP_TRY(hipStreamWaitEvent(st, left->waitEv, 0));
     unsigned long long* pairs = (unsigned long long*)left->dStereo.p;
     uint4* rec = (uint4*)(pairs + ((nSlots + 1) & ~(size_t)1));           // 16-byte aligned
-    int* unsorted = (int*)(rec + nRecs);
-    int* lv = unsorted + nPairs;
-    ORB_HIP_TRY(hipMemsetAsync(unsorted, 0, (size_t)4 * nPairs, st));
+    int* rowStart = (int*)(rec + nRecs);
+    unsigned short* rowList = (unsigned short*)(rowStart + (size_t)nPairs * (nRows + 1));
     const float maxD = mbf / mb;                                   // :546
     const int gridX = cL ? (int)stride : nL;
-    const int gridR = cR ? (int)stride : std::max(nR, 1);
-    hipLaunchKernelGGL(k_stereo_prep, dim3((gridR + 255) / 256, nPairs), dim3(256), 0, st, left->G, kR, nR, cR, stride, rec, recStride, lv, unsorted);
+    hipLaunchKernelGGL(k_stereo_rows, dim3(nPairs), dim3(1024), rowsLds, st, left->G, kR, rec, recStride, nR, cR, stride, nRows, maxBand,
+                       rowStart, rowList, listCap);
     hipLaunchKernelGGL(k_stereo_match, dim3(gridX, nPairs), dim3(WAVE), 0, st, left->G,
                        (const uint8_t*)left->dPyr.p + left->pyrSlab * frameL, left->pyrSlab,
                        (const uint8_t*)right->dPyr.p + right->pyrSlab * frameR, right->pyrSlab, kL, dL, nL, cL, kR, dR, nR, cR,
-                       stride, maxD, mbf, uR, dep, pairs, rec, recStride, lv, unsorted);
+                       stride, maxD, mbf, uR, dep, pairs, rec, recStride, rowStart, rowList, listCap);
     hipLaunchKernelGGL(k_stereo_outliers, dim3(nPairs), dim3(1024), 0, st, pairs, perPair, nL, cL, uR, dep);
     ORB_HIP_TRY(hipGetLastError());
     return ORB_OK;
