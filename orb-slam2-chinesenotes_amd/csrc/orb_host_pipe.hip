@@ -4,13 +4,46 @@
 // streams, two slots deep:
 //     H2D(chunk k+1)  ||  kernel chain(chunk k)  ||  D2H(chunk k-1) + host-side unpacking(chunk k-2)
 // Caller buffers that are already pinned (hipHostMalloc / hipHostRegister) are copied from / to directly; pageable
-// ones go through the handle's pinned staging (a CPU memcpy per chunk, the price of pageable memory).
+// ones go through the handle's pinned staging (CPU memcpys per chunk, the price of pageable memory; spread over up to
+// four threads -- ORB_HOST_THREADS -- because one core copies ~20 GB/s and the chunk's 20 MB were the pipeline's period).
 // The kernel chain, the scratch slabs and the status block are the handle's own (one chain at a time on its stream);
 // only the device in/out buffers and the staging are doubled.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
+#include <thread>
+#include <vector>
 
 #include "orb_extractor_internal.h"
+
+// fn(i) for i in [0, n), split over a few short-lived threads when the items are worth it (>= 2 MB per thread)
+template <class F>
+static void par_items(int n, size_t bytesPerItem, F fn)
+{
+    static const int maxT = [] {
+        const char* e = std::getenv("ORB_HOST_THREADS");
+        const int t = e ? std::atoi(e) : (int)std::min(4u, std::max(1u, std::thread::hardware_concurrency()));
+        return std::max(1, std::min(16, t));
+    }();
+    int T = (int)std::min<size_t>((size_t)maxT, std::max<size_t>(1, (size_t)n * bytesPerItem / ((size_t)2 << 20)));
+    T = std::min(T, n);
+    std::vector<std::thread> th;
+    if (T > 1) {
+        try {
+            for (int t = 1; t < T; t++)
+                th.emplace_back([=] { for (int i = t; i < n; i += T) fn(i); });
+        } catch (...) {                                        // no more threads to be had: the caller's thread does the rest
+            const int started = (int)th.size() + 1;
+            for (std::thread& x : th) x.join();
+            for (int t = started; t < T; t++)
+                for (int i = t; i < n; i += T) fn(i);
+            for (int i = 0; i < n; i += T) fn(i);
+            return;
+        }
+    }
+    for (int i = 0; i < n; i += std::max(T, 1)) fn(i);
+    for (std::thread& x : th) x.join();
+}
 
 static bool is_pinned(const void* p)
 {
@@ -102,10 +135,11 @@ int orb_extract_batch_pipelined(orb_extractor* h, const uint8_t* imgs, int nFram
         size_t srcRow = rowStride, srcFrame = frameStride;
         if (!inPinned) {                                       // pageable input: CPU copy into this slot's pinned buffer
             uint8_t* st = (uint8_t*)P.pinIn[s];
-            for (int f = 0; f < c; f++)
+            par_items(c, imgBytes, [=](int f) {
                 for (int y = 0; y < (rowStride == (size_t)cols ? 1 : rows); y++)
                     std::memcpy(st + imgBytes * f + (size_t)y * cols, imgs + frameStride * (f0 + f) + rowStride * y,
                                 rowStride == (size_t)cols ? imgBytes : (size_t)cols);
+            });
             src = st; srcRow = cols; srcFrame = imgBytes;
         }
         if (srcRow == (size_t)cols && srcFrame == imgBytes) {
@@ -157,12 +191,12 @@ int orb_extract_batch_pipelined(orb_extractor* h, const uint8_t* imgs, int nFram
         std::memcpy(counts + f0, po + statB, (size_t)4 * c);
         if (r != ORB_OK) return r;
         if (!outPinned)
-            for (int f = 0; f < c; f++) {
+            par_items(c, kpSlab + dsSlab, [=](int f) {
                 const int n = counts[f0 + f];
-                if (n <= 0) continue;
+                if (n <= 0) return;
                 std::memcpy(kps + (size_t)cap * (f0 + f), po + statB + cntB + kpSlab * f, sizeof(orb_keypoint) * (size_t)n);
                 std::memcpy(desc + dsSlab * (f0 + f), po + statB + cntB + kpSlab * C + dsSlab * f, (size_t)ORB_DESC_BYTES * n);
-            }
+            });
         return ORB_OK;
     };
 
