@@ -98,6 +98,7 @@ def parse():
                     help="config c3: ONE batch of 2 S frames (left views, then right views) through one extractor handle instead of two "
                          "handles on two streams (the default, the shape of the reference's two threads, src/Frame.cc:82-85; measured: "
                          "156 k frames/s with two handles, 144 k with one -- the two chains overlap each other's latency-bound kernels)")
+    ap.add_argument("--c5-slots", type=int, default=4, help="config 5: query slots in the ring between the extractor and the matcher stream")
     ap.add_argument("--stream-frames", type=int, default=256,
                     help="config c5: distinct stream frames resident in HBM that the timed steps walk through (3682 = the whole "
                          "EuRoC MH01-sized sequence of BASELINE configs[4]; generating them on the host takes about a minute)")
@@ -723,7 +724,7 @@ def run_c5(args, rank, local_rank, world, dev, comm_dev, dist):
     ex, mt = capi.Extractor(args.nfeatures, device=local_rank), capi.Matcher(0.7, True, device=local_rank)
     cap = ex.max_keypoints
     QMAX = 8                                                      # stream frames per step in the mini-batch variant
-    NSLOT = 4                                                     # query slots of up to QMAX stream frames each
+    NSLOT = max(2, min(16, args.c5_slots))                        # query slots of up to QMAX stream frames each
     F = n_kf + NSLOT * QMAX
     buf = lambda n, dt: torch.zeros(n, dtype=dt, device=dev)
     d_kps, d_desc = buf(F * cap * 28, torch.uint8), buf(F * cap * 32, torch.uint8)
