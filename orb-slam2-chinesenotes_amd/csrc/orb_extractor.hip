@@ -434,9 +434,11 @@ extern "C" int orb_extract_batch_device(orb_extractor* h, const uint8_t* d_imgs,
         // below ~10 workgroups per CU the 4-row bands (4x the workgroups, each a quarter as long) finish sooner
         // up to 32 frames: fewer launches of longer chains (column tables in LDS where they fit)
         static const int oneMax = std::getenv("ORB_PYR_ONE_MAX") ? std::atoi(std::getenv("ORB_PYR_ONE_MAX")) : 32;
-        const std::vector<OrbPyrChain>& chains = n <= oneMax                                  ? h->pyrChainsOne
-                                                 : (long long)h->pyrChains[0].bands * n < 2560 ? h->pyrChainsLat
-                                                                                               : h->pyrChains;
+        // ORB_PYR_SET=batch|few|one pins the variant (tests: every variant on the same frames)
+        const char* pin = std::getenv("ORB_PYR_SET");
+        const int which = pin ? (pin[0] == 'b' ? 0 : pin[0] == 'f' ? 1 : 2)
+                          : n <= oneMax ? 2 : (long long)h->pyrChains[0].bands * n < 2560 ? 1 : 0;
+        const std::vector<OrbPyrChain>& chains = which == 2 ? h->pyrChainsOne : which == 1 ? h->pyrChainsLat : h->pyrChains;
         for (size_t c = 0; c < chains.size(); c++)
             orb_launch_pyr_chain(st, chains[c], d_imgs, rowStride, frameStride, pyr, h->pyrSlab, (const uint4*)h->dXq.p,
                                  (const int2*)h->dYtab.p, (const int2*)h->dBand.p, n, c == 0 ? h->errP() : nullptr,

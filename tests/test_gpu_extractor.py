@@ -542,6 +542,26 @@ def test_strip_lengths_settle_without_any_sync():
         assert cnt[i] == len(rk) and kk[i, :len(rk)].tobytes() == rk.tobytes() and np.array_equal(dd[i, :len(rk)], rd)
 
 
+@pytest.mark.parametrize("variant", ["batch", "few", "one"])
+@pytest.mark.parametrize("w,h,nf", [(640, 480, 1000), (1241, 376, 2000), (333, 257, 500)])
+def test_every_pyramid_chain_variant_on_the_same_frames(monkeypatch, variant, w, h, nf):
+    """The pyramid kernel picks its band tables by batch size (16-row bands for batches that fill the chip, 4-row bands for a few
+    frames, two launches of up to four levels with the column tables in LDS for up to 32 frames); ORB_PYR_SET pins one, so that
+    every variant is compared level by level with the oracle on the same three frames (a plain test reaches the 16-row
+    bands only with ~120 frames)."""
+    monkeypatch.setenv("ORB_PYR_SET", variant)
+    imgs = np.stack([synth.synth_frame(40, w, h), synth.synth_natural(41, w, h), synth.synth_frame(42, w, h)])
+    ex = capi.Extractor(nf)
+    ref = oracle.Extractor(nf)
+    got = ex.extract_batch(imgs)
+    for i in range(3):
+        rk, rd = ref.extract(imgs[i])
+        for l in range(8):
+            assert np.array_equal(ex.pyramid_level(i, l), ref.pyramid_level(l)), (variant, i, l)
+        assert got[i][0].tobytes() == rk.tobytes() and np.array_equal(got[i][1], rd)
+    ex.close()
+
+
 def test_single_frame_call_without_the_dense_launch_redoes_overflowing_frames():
     """orb_extract leaves k_fast_strips_dense out of its chain and looks at the overflow counter afterwards: a frame whose
     strips overflow their candidate queues (noise) is redone with that kernel in the same call, the strips get shorter, and
