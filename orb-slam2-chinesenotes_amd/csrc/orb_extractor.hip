@@ -624,7 +624,7 @@ extern "C" int orb_extract_batch(orb_extractor* h, const uint8_t* imgs, int nFra
     // Single frames leave the (almost always idle) launch for overflowed FAST strips out of the chain: ~4.5 us of a ~95 us chain.
     // The overflow counter comes back with the status block; if a strip did overflow the frame is redone with that kernel
     // (and the strips get shorter: apply_fast_overflows).
-    static const bool noSpec = std::getenv("ORB_NO_SPEC") != nullptr;
+    const bool noSpec = std::getenv("ORB_NO_SPEC") != nullptr;
     struct SpecGuard { orb_extractor* h; ~SpecGuard() { h->specNoDense = false; } } specGuard{h};
     h->specNoDense = zero && !noSpec;
     orb_extractor::Graph& Gr = h->graph1;

@@ -562,6 +562,23 @@ def test_every_pyramid_chain_variant_on_the_same_frames(monkeypatch, variant, w,
     ex.close()
 
 
+@pytest.mark.parametrize("knob", ["ORB_NO_GRAPH", "ORB_NO_ZEROCOPY", "ORB_NO_SPEC", "ORB_NO_ZEROCOPY+ORB_NO_GRAPH"])
+def test_single_frame_path_switches_do_not_change_results(monkeypatch, knob):
+    """The single-frame host call has three accelerations that can be switched off one by one (graph replay, zero-copy pinned
+    staging, the chain without the dense-strip launch): every combination returns what the oracle returns, call after call."""
+    for k in knob.split("+"):
+        monkeypatch.setenv(k, "1")
+    imgs = [synth.synth_frame(50), synth.synth_natural(51), np.random.default_rng(52).integers(0, 256, (480, 640)).astype(np.uint8)]
+    ref = oracle.Extractor()
+    want = [ref.extract(im) for im in imgs]
+    ex = capi.Extractor()
+    for rep in range(3):
+        for im, (rk, rd) in zip(imgs, want):
+            k, d = ex.extract(im)
+            assert k.tobytes() == rk.tobytes() and np.array_equal(d, rd), (knob, rep)
+    ex.close()
+
+
 def test_single_frame_call_without_the_dense_launch_redoes_overflowing_frames():
     """orb_extract leaves k_fast_strips_dense out of its chain and looks at the overflow counter afterwards: a frame whose
     strips overflow their candidate queues (noise) is redone with that kernel in the same call, the strips get shorter, and
