@@ -604,60 +604,78 @@ def run_c3(args, rank, local_rank, world, dev, comm_dev, dist):
     streams, as the reference's two threads, src/Frame.cc:82-85) + ComputeStereoMatches (src/Frame.cc:513-699) per pair
     on the device-resident pyramids."""
     W, H, nf, S = 1241, 376, 2000, 32
-    exl, exr = capi.Extractor(nf, device=local_rank), capi.Extractor(nf, device=local_rank)
-    cap = exl.max_keypoints
     base = rank * S
     lefts = np.stack([synth.synth_frame(100 + base + i, W, H) for i in range(S)])
     rights = np.stack([synth.synth_stereo_right(100 + base + i, W, H) for i in range(S)])
     d_l, d_r = torch.from_numpy(lefts).to(dev), torch.from_numpy(rights).to(dev)
     buf = lambda n, dt: torch.zeros(n, dtype=dt, device=dev)
-    kl, kr = buf(S * cap * 28, torch.uint8), buf(S * cap * 28, torch.uint8)
-    dl, dr = buf(S * cap * 32, torch.uint8), buf(S * cap * 32, torch.uint8)
-    cl, cr = buf(S, torch.int32), buf(S, torch.int32)
-    ur, dp = buf(S * cap, torch.float32), buf(S * cap, torch.float32)
+    one = args.c3_one_handle
+    d_lr = torch.cat([d_l, d_r]) if one else None
+    # Lanes: independent (left handle, right handle, output buffers) sets that consecutive steps alternate between, as in
+    # config c4.  Inside a lane everything is ordered (the stereo search of a step reads the right handle's pyramid and
+    # keypoints, so the library orders the right handle's next extraction behind it); the search of one lane runs beside
+    # the extractions of the other.
+    n_lanes = args.pipeline if args.pipeline > 0 else 3          # (measured 1 / 2 / 3 / 4 / 6 lanes: 174 / 181 / 192 / 187 / 189 k frames/s)
+
+    def make_lane():
+        ln = {"exl": capi.Extractor(nf, device=local_rank)}
+        ln["exr"] = ln["exl"] if one else capi.Extractor(nf, device=local_rank)
+        cap_ = ln["exl"].max_keypoints
+        if one:       # ONE batch [L0 .. L(S-1), R0 .. R(S-1)] through one handle; pair p = frames (p, S + p) of that batch
+            ln["k2"], ln["d2"], ln["c2"] = buf(2 * S * cap_ * 28, torch.uint8), buf(2 * S * cap_ * 32, torch.uint8), buf(2 * S, torch.int32)
+            ln["kl"], ln["kr"] = ln["k2"][:S * cap_ * 28], ln["k2"][S * cap_ * 28:]
+            ln["dl"], ln["dr"] = ln["d2"][:S * cap_ * 32], ln["d2"][S * cap_ * 32:]
+            ln["cl"], ln["cr"] = ln["c2"][:S], ln["c2"][S:]
+        else:
+            ln["kl"], ln["kr"] = buf(S * cap_ * 28, torch.uint8), buf(S * cap_ * 28, torch.uint8)
+            ln["dl"], ln["dr"] = buf(S * cap_ * 32, torch.uint8), buf(S * cap_ * 32, torch.uint8)
+            ln["cl"], ln["cr"] = buf(S, torch.int32), buf(S, torch.int32)
+        ln["ur"], ln["dp"] = buf(S * cap_, torch.float32), buf(S * cap_, torch.float32)
+        return ln
+
+    lanes = [make_lane() for _ in range(n_lanes)]
+    exl, exr = lanes[0]["exl"], lanes[0]["exr"]
+    cap = exl.max_keypoints
+    kl, dl, cl, cr, ur, dp = (lanes[0][k] for k in ("kl", "dl", "cl", "cr", "ur", "dp"))
     torch.cuda.synchronize()
 
-    one = args.c3_one_handle
-    if one:
-        # ONE batch [L0 .. L(S-1), R0 .. R(S-1)] through one handle; pair p = frames (p, S + p) of that batch
-        d_lr = torch.cat([d_l, d_r])
-        k2, d2, c2 = buf(2 * S * cap * 28, torch.uint8), buf(2 * S * cap * 32, torch.uint8), buf(2 * S, torch.int32)
-        kl, kr = k2[:S * cap * 28], k2[S * cap * 28:]
-        dl, dr = d2[:S * cap * 32], d2[S * cap * 32:]
-        cl, cr = c2[:S], c2[S:]
-        exr = exl
-
-    def step():
+    def step(i=0):
+        ln = lanes[i % n_lanes]
+        p = lambda k: ln[k].data_ptr()
         if one:
-            exl.extract_batch_device(d_lr.data_ptr(), 2 * S, H, W, W, W * H, k2.data_ptr(), d2.data_ptr(), cap, c2.data_ptr())
-            capi.stereo_match_batch_device(exl, exl, 0, S, S, kl.data_ptr(), dl.data_ptr(), cl.data_ptr(), kr.data_ptr(), dr.data_ptr(),
-                                           cr.data_ptr(), cap, MB, MBF, ur.data_ptr(), dp.data_ptr())
+            ln["exl"].extract_batch_device(d_lr.data_ptr(), 2 * S, H, W, W, W * H, p("k2"), p("d2"), cap, p("c2"))
+            capi.stereo_match_batch_device(ln["exl"], ln["exl"], 0, S, S, p("kl"), p("dl"), p("cl"), p("kr"), p("dr"), p("cr"), cap, MB, MBF,
+                                           p("ur"), p("dp"))
             return
-        exl.extract_batch_device(d_l.data_ptr(), S, H, W, W, W * H, kl.data_ptr(), dl.data_ptr(), cap, cl.data_ptr())
-        exr.extract_batch_device(d_r.data_ptr(), S, H, W, W, W * H, kr.data_ptr(), dr.data_ptr(), cap, cr.data_ptr())
+        ln["exl"].extract_batch_device(d_l.data_ptr(), S, H, W, W, W * H, p("kl"), p("dl"), cap, p("cl"))
+        ln["exr"].extract_batch_device(d_r.data_ptr(), S, H, W, W, W * H, p("kr"), p("dr"), cap, p("cr"))
         # all S pairs in one launch; the keypoint counts stay on the device (no host round trip inside a step)
-        capi.stereo_match_batch_device(exl, exr, 0, 0, S, kl.data_ptr(), dl.data_ptr(), cl.data_ptr(), kr.data_ptr(), dr.data_ptr(),
-                                       cr.data_ptr(), cap, MB, MBF, ur.data_ptr(), dp.data_ptr())
+        capi.stereo_match_batch_device(ln["exl"], ln["exr"], 0, 0, S, p("kl"), p("dl"), p("cl"), p("kr"), p("dr"), p("cr"), cap, MB, MBF,
+                                       p("ur"), p("dp"))
 
-    for i in range(args.warmup):
-        step()
-        if i < 4:                                  # a caller that synchronises lets the strip lengths settle (orb_check_status
-            exl.sync(); exr.sync()                 # shortens a level's FAST strips by one cell per overflowing sync)
-    exl.sync(); exr.sync(); torch.cuda.synchronize()
+    def sync_all():
+        for ln in lanes:
+            ln["exl"].sync(); ln["exr"].sync()
+
+    for i in range(max(args.warmup, 4) * n_lanes):
+        step(i)
+        if i < 4 * n_lanes:                        # a caller that synchronises lets the strip lengths settle (orb_check_status
+            sync_all()                             # shortens a level's FAST strips by one cell per overflowing sync)
+    sync_all(); torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    exl.sync(); exr.sync(); torch.cuda.synchronize()
+    for i in range(args.steps):
+        step(i)
+    sync_all(); torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     elapsed = shard.max_over_ranks(dist, time.perf_counter() - t0, comm_dev)
     pairs = shard.sum_over_ranks(dist, S * args.steps, comm_dev)
     exl.set_profiling(True)
     for _ in range(4):
-        step()
-    exl.sync(); exr.sync()
+        step(0)
+    sync_all()
     stage_ms = exl.stage_ms()
     exl.set_profiling(False)
     nl, nr = cl.cpu().numpy(), cr.cpu().numpy()
@@ -678,7 +696,9 @@ def run_c3(args, rank, local_rank, world, dev, comm_dev, dist):
            "dtype": "u8", "data": "synthetic",
            "config": {"workload": "BASELINE configs[2]: %d synthetic KITTI-sized stereo pairs (1241x376, disparity 12+8*floor(y/94), "
                                   "nFeatures 2000) per step: extract left + right%s, ComputeStereoMatches of all pairs (one launch) on the "
-                                  "device pyramids" % (S, " as ONE batch of 2 S frames through one handle" if one else " through two handles on two streams"), "pairs_per_step": S, "pairs_per_s": round(pairs / elapsed, 2),
+                                  "device pyramids; %d independent lanes of handles and buffers that consecutive steps alternate between"
+                                  % (S, " as ONE batch of 2 S frames through one handle" if one else " through two handles on two streams", n_lanes),
+                      "lanes": n_lanes, "pairs_per_step": S, "pairs_per_s": round(pairs / elapsed, 2),
                       "ms_per_pair": round(elapsed / (pairs / world) * 1e3, 4), "mean_keypoints_left": round(mean_kp, 1),
                       "mean_stereo_matches": round(float((u[:, :] >= 0).sum() / S), 1),
                       "stage_ms_per_launch_left_handle": {n: round(float(v), 4) for n, v in zip(STAGES + ["extract_total"], stage_ms)}},

@@ -413,7 +413,9 @@ int orb_multi_match_bow_batch(orb_multi_db* db, const uint8_t* q_desc, const orb
 /* Batch of stereo pairs in ONE launch: pair p = frames (first_frame_l + p, first_frame_r + p) of the two handles' last
  * batches, its keypoints / descriptors / results at rows [p * cap, (p + 1) * cap) of the arrays orb_extract_batch_device
  * wrote, its keypoint counts read on the device from the extractors' d_counts (no host round trip between extraction
- * and search).  d_u_right / d_depth: [n_pairs * cap] floats.  Asynchronous on the LEFT handle's stream. */
+ * and search).  d_u_right / d_depth: [n_pairs * cap] floats.  Asynchronous on the LEFT handle's stream; it waits for the
+ * right handle's stream first, and work issued on the RIGHT handle afterwards (the next extraction, which overwrites the
+ * pyramid and the keypoints the search reads) is ordered behind the search.  The same holds for orb_stereo_match_device. */
 int orb_stereo_match_batch_device(orb_extractor* left, orb_extractor* right, int first_frame_l, int first_frame_r,
                                   int n_pairs, const orb_keypoint* d_kps_l, const uint8_t* d_desc_l,
                                   const int32_t* d_counts_l, const orb_keypoint* d_kps_r, const uint8_t* d_desc_r,

@@ -371,6 +371,13 @@ static int stereo_launch(orb_extractor* left, orb_extractor* right, int frameL, 
                        stride, maxD, mbf, uR, dep, pairs, rec, recStride, rowStart, rowList, listCap);
     hipLaunchKernelGGL(k_stereo_outliers, dim3(nPairs), dim3(1024), 0, st, pairs, perPair, nL, cL, uR, dep);
     ORB_HIP_TRY(hipGetLastError());
+    // The search reads the RIGHT handle's pyramid (and the right keypoints / descriptors) on the LEFT handle's stream: whatever
+    // the caller issues next on the right handle -- typically the next extraction, which overwrites all three -- is ordered
+    // behind it.  (Without this edge a pipelined caller raced the search of step k against the right extraction of step k + 1.)
+    if (right->stream != st) {
+        ORB_HIP_TRY(hipEventRecord(right->waitEv, st));
+        ORB_HIP_TRY(hipStreamWaitEvent(right->stream, right->waitEv, 0));
+    }
     return ORB_OK;
 }
 

@@ -139,3 +139,41 @@ def test_stereo_batch_of_pairs_in_one_launch():
         wu, wz = oracle.stereo_matches(rl, rr, k1, d1, k2, d2, MB, MBF)
         assert u[i, :nl[i]].tobytes() == wu.tobytes() and zz[i, :nl[i]].tobytes() == wz.tobytes(), i
     assert np.all(u[3, :nl[3]] == -1)
+
+
+def test_pipelined_stereo_steps_without_a_sync_in_between():
+    """Six steps of (extract left batch, extract right batch, stereo search) issued back to back, the extractors' output
+    buffers REUSED by every step and only the (u_right, depth) results kept per step: the search of step k reads the right
+    handle's pyramid and the right keypoints on the left handle's stream, so the right extraction of step k + 1 must be
+    ordered behind it (orb_stereo_match_batch_device adds that edge; without it the two raced).  Every step bit-exact."""
+    import torch
+    W, H, nf, S, STEPS = 752, 480, 1200, 3, 6
+    dev = torch.device("cuda", 0)
+    exl, exr = capi.Extractor(nf), capi.Extractor(nf)
+    cap = exl.max_keypoints
+    z = lambda n, dt: torch.zeros(n, dtype=dt, device=dev)
+    lefts = [np.stack([synth.synth_frame(600 + 10 * k + i, W, H) for i in range(S)]) for k in range(STEPS)]
+    rights = [np.stack([synth.synth_stereo_right(600 + 10 * k + i, W, H) for i in range(S)]) for k in range(STEPS)]
+    d_l = [torch.from_numpy(a).to(dev) for a in lefts]
+    d_r = [torch.from_numpy(a).to(dev) for a in rights]
+    kl, kr = z(S * cap * 28, torch.uint8), z(S * cap * 28, torch.uint8)
+    dl, dr = z(S * cap * 32, torch.uint8), z(S * cap * 32, torch.uint8)
+    cl, cr = z(S, torch.int32), z(S, torch.int32)
+    ur = [z(S * cap, torch.float32) for _ in range(STEPS)]
+    dp = [z(S * cap, torch.float32) for _ in range(STEPS)]
+    torch.cuda.synchronize()
+    for k in range(STEPS):
+        exl.extract_batch_device(d_l[k].data_ptr(), S, H, W, W, W * H, kl.data_ptr(), dl.data_ptr(), cap, cl.data_ptr())
+        exr.extract_batch_device(d_r[k].data_ptr(), S, H, W, W, W * H, kr.data_ptr(), dr.data_ptr(), cap, cr.data_ptr())
+        capi.stereo_match_batch_device(exl, exr, 0, 0, S, kl.data_ptr(), dl.data_ptr(), cl.data_ptr(), kr.data_ptr(), dr.data_ptr(),
+                                       cr.data_ptr(), cap, MB, MBF, ur[k].data_ptr(), dp[k].data_ptr())
+    exl.sync(); exr.sync(); torch.cuda.synchronize()
+    for k in range(STEPS):
+        u, zz = ur[k].cpu().numpy().reshape(S, cap), dp[k].cpu().numpy().reshape(S, cap)
+        for i in range(S):
+            rl, rr = oracle.Extractor(nf), oracle.Extractor(nf)
+            k1, d1 = rl.extract(lefts[k][i])
+            k2, d2 = rr.extract(rights[k][i])
+            wu, wz = oracle.stereo_matches(rl, rr, k1, d1, k2, d2, MB, MBF)
+            assert u[i, :len(k1)].tobytes() == wu.tobytes() and zz[i, :len(k1)].tobytes() == wz.tobytes(), (k, i)
+    exl.close(); exr.close()
