@@ -1,6 +1,6 @@
 #!/bin/bash
 # Run ON THE GPU BOX: kernel trace of the single-frame host call (tools/latency.py), per-kernel average duration and
-# the GPU-side span of one call (first kernel start -> last kernel end).
+# the GPU-side span of one call (first kernel start -> last kernel end); then tools/latency_c.sh (the call from C).
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/lat_trace
 mkdir -p "$OUT"
@@ -33,3 +33,5 @@ print("GPU span per call: %.1f us, sum of kernel durations %.1f us, %d launches"
 for n, v in agg.items():
     print("  %-24s x%d  %.1f us each" % (n, len(v) // len(calls), sum(v) / len(v)))
 PY
+# the same call from a C caller (no interpreter between the caller and the C ABI)
+bash "$ROOT/tools/latency_c.sh" 300
