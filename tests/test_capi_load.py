@@ -94,3 +94,12 @@ def test_multi_without_a_device_is_a_loud_error():
         pytest.skip("GPU present")
     with pytest.raises(capi.OrbError):
         capi.MultiExtractor([0, 1])
+
+
+def test_c_caller_of_the_abi_compiles_and_links(lib):
+    """tools/latency_c.c is a plain-C caller of include/orb_hip.h (the header must stay C-clean, and every entry point it
+    uses must link from liborbhip.so): built here with gcc, run only on the GPU box (tools/latency_c.sh)."""
+    import subprocess
+    r = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "orb-slam2-chinesenotes_amd"), "latency-c"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert os.path.exists(os.path.join(ROOT, "tools", "latency_c"))
