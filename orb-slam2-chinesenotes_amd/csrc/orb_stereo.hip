@@ -58,7 +58,7 @@ __global__ __launch_bounds__(1024) void k_stereo_rows(const OrbGeom G, const orb
     for (int y = tid; y < nRows; y += T) fill[y] = 0;
     __syncthreads();
     // (a band longer than maxBand cannot come from a finite y: such a keypoint gets no rows -- the reference would index
-    // vRowIndices out of range with it)
+    // vRowIndices out of range with it; the list holds maxBand entries per keypoint)
     for (int i = tid; i < Nr; i += T) {
         const orb_keypoint kp = kR[i];
         const int oc = min(max(kp.octave, 0), G.nlevels - 1);
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(1024) void k_stereo_rows(const OrbGeom G, const orb
         const uint4 rc = make_uint4((unsigned)minr, (unsigned)maxr, (unsigned)kp.octave, __float_as_uint(kp.x));
         recs[i] = rc;                                              // (read back below by the thread that wrote it)
         const int lo = max((int)rc.x, 0), hi = min((int)rc.y, nRows - 1);
-        if ((int)rc.y - (int)rc.x < maxBand)
+        if (hi - lo < maxBand)                              // (clamped values: no overflow whatever y was)
             for (int y = lo; y <= hi; y++) atomicAdd(&cnt[y], 1);
     }
     __syncthreads();
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(1024) void k_stereo_rows(const OrbGeom G, const orb
     for (int i = tid; i < Nr; i += T) {
         const uint4 rc = recs[i];
         const int lo = max((int)rc.x, 0), hi = min((int)rc.y, nRows - 1);
-        if ((int)rc.y - (int)rc.x < maxBand)
+        if (hi - lo < maxBand)                              // (clamped values: no overflow whatever y was)
             for (int y = lo; y <= hi; y++) rowList[cnt[y] + atomicAdd(&fill[y], 1)] = (unsigned short)i;
     }
 }

@@ -177,3 +177,19 @@ def test_pipelined_stereo_steps_without_a_sync_in_between():
             wu, wz = oracle.stereo_matches(rl, rr, k1, d1, k2, d2, MB, MBF)
             assert u[i, :len(k1)].tobytes() == wu.tobytes() and zz[i, :len(k1)].tobytes() == wz.tobytes(), (k, i)
     exl.close(); exr.close()
+
+
+def test_stereo_ignores_right_keypoints_that_lie_in_no_image_row():
+    """Right keypoints whose y is NaN, infinite or far outside the image belong to no row of the per-row table
+    (k_stereo_rows): the reference would index vRowIndices out of range with them; here they are simply never candidates --
+    the result equals the oracle's on the arrays without them, and nothing is written out of bounds."""
+    (exl, exr, kl, dl, kr, dr), (rl, rr) = _pair(311, 752, 480, 1200)
+    want_u, want_z = oracle.stereo_matches(rl, rr, kl, dl, kr, dr, MB, MBF)
+    rng = np.random.default_rng(9)
+    bad = kr[:64].copy()
+    bad["y"] = np.resize(np.array([np.nan, np.inf, -np.inf, 1e9, -1e9, 3e38, -3e38, 479.9 + 1000], np.float32), 64)
+    bad["octave"] = np.resize(np.array([0, 7, 3, 100, -5], np.int32), 64)
+    krb = np.concatenate([kr, bad])
+    drb = np.concatenate([dr, rng.integers(0, 256, (64, 32), dtype=np.uint8)])
+    got_u, got_z = capi.stereo_match(exl, exr, kl, dl, krb, np.ascontiguousarray(drb), MB, MBF)
+    assert got_u.tobytes() == want_u.tobytes() and got_z.tobytes() == want_z.tobytes()
