@@ -127,12 +127,13 @@ struct orb_extractor {
                                                 // only their last chunk on the device)
 
     // pipelined host batches (orb_host_pipe.hip): two slots of device in/out buffers and pinned staging, copy streams
+    static const int kPipeSlots = 3;            // chunks in flight in the host pipeline (issue k, retire k - 2)
     struct Pipe {
         hipStream_t h2d = nullptr, d2h = nullptr;
-        hipEvent_t evIn[2] = {nullptr, nullptr}, evK[2] = {nullptr, nullptr}, evOut[2] = {nullptr, nullptr};
-        DevBuf dImg[2], dKps[2], dDesc[2], dCnt[2];
-        void* pinIn[2] = {nullptr, nullptr};
-        void* pinOut[2] = {nullptr, nullptr};
+        hipEvent_t evIn[kPipeSlots] = {}, evK[kPipeSlots] = {}, evOut[kPipeSlots] = {};
+        DevBuf dImg[kPipeSlots], dKps[kPipeSlots], dDesc[kPipeSlots], dCnt[kPipeSlots];
+        void* pinIn[kPipeSlots] = {};
+        void* pinOut[kPipeSlots] = {};
         size_t pinInBytes = 0, pinOutBytes = 0;
         bool ready = false;
     } pipe;

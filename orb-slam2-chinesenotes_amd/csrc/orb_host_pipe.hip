@@ -1,13 +1,13 @@
 // orb_host_pipe.hip -- orb_extract_batch for LARGE host batches: the reference API hands over host images
 // (cv::Mat, reference src/ORBextractor.cc:1084-1091, called from src/Frame.cc:262-268), so the PCIe-inclusive path
 // matters next to the device-resident one.  The batch is cut into chunks that flow through three stages on three
-// streams, two slots deep:
-//     H2D(chunk k+1)  ||  kernel chain(chunk k)  ||  D2H(chunk k-1) + host-side unpacking(chunk k-2)
+// streams, three slots deep:
+//     staging copy + H2D(chunk k)  ||  kernel chain(chunk k-1)  ||  D2H(chunk k-1) ... host-side unpacking(chunk k-2)
 // Caller buffers that are already pinned (hipHostMalloc / hipHostRegister) are copied from / to directly; pageable
 // ones go through the handle's pinned staging (CPU memcpys per chunk, the price of pageable memory; spread over up to
 // four threads -- ORB_HOST_THREADS -- because one core copies ~20 GB/s and the chunk's 20 MB were the pipeline's period).
 // The kernel chain, the scratch slabs and the status block are the handle's own (one chain at a time on its stream);
-// only the device in/out buffers and the staging are doubled.
+// only the device in/out buffers and the staging exist once per slot.
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -61,7 +61,7 @@ static int pipe_init(orb_extractor* h)
     if (P.ready) return ORB_OK;
     ORB_HIP_TRY(hipStreamCreateWithFlags(&P.h2d, hipStreamNonBlocking));
     ORB_HIP_TRY(hipStreamCreateWithFlags(&P.d2h, hipStreamNonBlocking));
-    for (int s = 0; s < 2; s++) {
+    for (int s = 0; s < orb_extractor::kPipeSlots; s++) {
         ORB_HIP_TRY(hipEventCreateWithFlags(&P.evIn[s], hipEventDisableTiming));
         ORB_HIP_TRY(hipEventCreateWithFlags(&P.evK[s], hipEventDisableTiming));
         ORB_HIP_TRY(hipEventCreateWithFlags(&P.evOut[s], hipEventDisableTiming));
@@ -73,7 +73,7 @@ static int pipe_init(orb_extractor* h)
 void orb_pipe_release(orb_extractor* h)
 {
     orb_extractor::Pipe& P = h->pipe;
-    for (int s = 0; s < 2; s++) {
+    for (int s = 0; s < orb_extractor::kPipeSlots; s++) {
         P.dImg[s].release(); P.dKps[s].release(); P.dDesc[s].release(); P.dCnt[s].release();
         if (P.pinIn[s]) (void)hipHostFree(P.pinIn[s]);
         if (P.pinOut[s]) (void)hipHostFree(P.pinOut[s]);
@@ -90,15 +90,18 @@ void orb_pipe_release(orb_extractor* h)
     P.ready = false;
 }
 
-static int ensure_pinned(void** p, size_t* have, size_t need, void** q)
+static int ensure_pinned(void** slots, size_t* have, size_t need)
 {
-    if (need <= *have && *p && *q) return ORB_OK;
-    if (*p) (void)hipHostFree(*p);
-    if (*q) (void)hipHostFree(*q);
-    *p = *q = nullptr;
+    const int NS = orb_extractor::kPipeSlots;
+    bool all = need <= *have;
+    for (int s = 0; s < NS; s++) all = all && slots[s] != nullptr;
+    if (all) return ORB_OK;
+    for (int s = 0; s < NS; s++) {
+        if (slots[s]) (void)hipHostFree(slots[s]);
+        slots[s] = nullptr;
+    }
     *have = 0;
-    ORB_HIP_TRY(hipHostMalloc(p, need, hipHostMallocDefault));
-    ORB_HIP_TRY(hipHostMalloc(q, need, hipHostMallocDefault));
+    for (int s = 0; s < NS; s++) ORB_HIP_TRY(hipHostMalloc(&slots[s], need, hipHostMallocDefault));
     *have = need;
     return ORB_OK;
 }
@@ -118,19 +121,20 @@ int orb_extract_batch_pipelined(orb_extractor* h, const uint8_t* imgs, int nFram
     const size_t statB = orb_extractor::statInts(C) * 4, cntB = (size_t)4 * C;
     // pinned out slot: [status | counts | keypoints | descriptors] (the two slabs only for pageable caller buffers)
     const size_t outB = statB + cntB + (outPinned ? 0 : (kpSlab + dsSlab) * C);
-    for (int s = 0; s < 2; s++) {
+    for (int s = 0; s < orb_extractor::kPipeSlots; s++) {
         if ((rc = P.dImg[s].ensure(imgBytes * C)) != ORB_OK || (rc = P.dKps[s].ensure(kpSlab * C)) != ORB_OK ||
             (rc = P.dDesc[s].ensure(dsSlab * C)) != ORB_OK || (rc = P.dCnt[s].ensure(cntB)) != ORB_OK)
             return rc;
     }
-    if (!inPinned && (rc = ensure_pinned(&P.pinIn[0], &P.pinInBytes, imgBytes * C, &P.pinIn[1])) != ORB_OK) return rc;
-    if ((rc = ensure_pinned(&P.pinOut[0], &P.pinOutBytes, outB, &P.pinOut[1])) != ORB_OK) return rc;
+    if (!inPinned && (rc = ensure_pinned(P.pinIn, &P.pinInBytes, imgBytes * C)) != ORB_OK) return rc;
+    if ((rc = ensure_pinned(P.pinOut, &P.pinOutBytes, outB)) != ORB_OK) return rc;
     hipStream_t cs = h->stream;
     int firstErr = ORB_OK;
-    unsigned chunkSerial[2] = {0, 0};
+    const int NS = orb_extractor::kPipeSlots;
+    unsigned chunkSerial[orb_extractor::kPipeSlots] = {};
 
     auto issue = [&](int k) -> int {
-        const int s = k & 1, f0 = k * C, c = std::min(C, nFrames - f0);
+        const int s = k % NS, f0 = k * C, c = std::min(C, nFrames - f0);
         const uint8_t* src = imgs + frameStride * f0;
         size_t srcRow = rowStride, srcFrame = frameStride;
         if (!inPinned) {                                       // pageable input: CPU copy into this slot's pinned buffer
@@ -155,7 +159,7 @@ int orb_extract_batch_pipelined(orb_extractor* h, const uint8_t* imgs, int nFram
         }
         ORB_HIP_TRY(hipEventRecord(P.evIn[s], P.h2d));
         ORB_HIP_TRY(hipStreamWaitEvent(cs, P.evIn[s], 0));
-        if (k >= 2) ORB_HIP_TRY(hipStreamWaitEvent(cs, P.evOut[s], 0));       // this slot's outputs of chunk k-2 have left
+        if (k >= NS) ORB_HIP_TRY(hipStreamWaitEvent(cs, P.evOut[s], 0));      // this slot's outputs of chunk k - NS have left
         int r = orb_extract_batch_device(h, (const uint8_t*)P.dImg[s].p, c, rows, cols, cols, imgBytes, (orb_keypoint*)P.dKps[s].p,
                                          (uint8_t*)P.dDesc[s].p, cap, (int32_t*)P.dCnt[s].p);
         if (r != ORB_OK) return r;
@@ -178,7 +182,7 @@ int orb_extract_batch_pipelined(orb_extractor* h, const uint8_t* imgs, int nFram
     };
 
     auto retire = [&](int k) -> int {
-        const int s = k & 1, f0 = k * C, c = std::min(C, nFrames - f0);
+        const int s = k % NS, f0 = k * C, c = std::min(C, nFrames - f0);
         ORB_HIP_TRY(hipEventSynchronize(P.evOut[s]));
         const uint8_t* po = (const uint8_t*)P.pinOut[s];
         const int keepFrames = h->lastFrames;                  // orb_check_status reads the block of `c` frames
@@ -200,14 +204,17 @@ int orb_extract_batch_pipelined(orb_extractor* h, const uint8_t* imgs, int nFram
         return ORB_OK;
     };
 
+    // chunk k is issued while chunk k - 1 runs and chunk k - 2 is retired: the host copies chunk k's images into pinned
+    // staging (pageable callers) BEFORE it waits for anything -- with two slots it waited for chunk k - 1's results first,
+    // and the H2D engine idled for as long as that copy took
     int issued = 0;
-    for (int k = 0; k <= nChunks; k++) {
+    for (int k = 0; k <= nChunks + 1; k++) {
         if (k < nChunks && firstErr == ORB_OK) {
             const int r = issue(k);
             if (r != ORB_OK) firstErr = r; else issued = k + 1;
         }
-        if (k >= 1 && k - 1 < issued) {
-            const int r = retire(k - 1);
+        if (k >= 2 && k - 2 < issued) {
+            const int r = retire(k - 2);
             if (r != ORB_OK && firstErr == ORB_OK) firstErr = r;
         }
     }
