@@ -98,6 +98,7 @@ def parse():
                     help="config c3: ONE batch of 2 S frames (left views, then right views) through one extractor handle instead of two "
                          "handles on two streams (the default, the shape of the reference's two threads, src/Frame.cc:82-85; measured: "
                          "156 k frames/s with two handles, 144 k with one -- the two chains overlap each other's latency-bound kernels)")
+    ap.add_argument("--c5-pair-kernel", action="store_true", help="config 5: SearchByBoW with the pair kernel (one workgroup per (keyframe, frame) pair) instead of the query form")
     ap.add_argument("--c5-slots", type=int, default=4, help="config 5: query slots in the ring between the extractor and the matcher stream")
     ap.add_argument("--stream-frames", type=int, default=256,
                     help="config c5: distinct stream frames resident in HBM that the timed steps walk through (3682 = the whole "
@@ -762,9 +763,10 @@ def run_c5(args, rank, local_rank, world, dev, comm_dev, dist):
                                 d_desc.data_ptr() + k0 * cap * 32, cap, d_counts.data_ptr() + k0 * 4)
         ex.sync()
     d_ckeys, d_cstart, d_ccnt = buf(F * cap, torch.int32), buf(F * n_nodes, torch.int16), buf(F * n_nodes, torch.int16)
+    d_cdesc = buf(F * cap * 32, torch.uint8)                      # descriptors in feature-vector order (orb_featstore.csr_desc)
     voc.transform_device(mt, d_desc.data_ptr(), d_counts.data_ptr(), n_kf, cap, 4, d_node_of=d_node.data_ptr())
-    mt.build_csr_device(d_node.data_ptr(), d_counts.data_ptr(), n_kf, cap, n_nodes, d_ckeys.data_ptr(), d_cstart.data_ptr(),
-                        d_ccnt.data_ptr())
+    mt.build_csr_desc_device(d_node.data_ptr(), d_counts.data_ptr(), d_desc.data_ptr(), n_kf, cap, n_nodes, d_ckeys.data_ptr(),
+                             d_cstart.data_ptr(), d_ccnt.data_ptr(), d_cdesc.data_ptr())
     mt.sync()
     n_q = max(16, args.stream_frames)
     q_first = 3 + 8 * (rank % 100)
@@ -773,13 +775,15 @@ def run_c5(args, rank, local_rank, world, dev, comm_dev, dist):
                                 for g in range((n_q + 7) // 8)])[:n_q]
     stream = torch.from_numpy(stream_np).to(dev)
     Q = [1]                                                       # stream frames per step (1 = the per-frame configuration)
-    kf_idx = torch.arange(n_kf, dtype=torch.int32, device=dev).repeat(QMAX)
-    f_idx = [torch.arange(QMAX, dtype=torch.int32, device=dev).repeat_interleave(n_kf) + (n_kf + s * QMAX) for s in range(NSLOT)]
+    kf_idx = torch.arange(n_kf, dtype=torch.int32, device=dev)
+    f_idx = [torch.arange(QMAX, dtype=torch.int32, device=dev) + (n_kf + s * QMAX) for s in range(NSLOT)]
+    kf_pairs = kf_idx.repeat(QMAX)
+    f_pairs = [f.repeat_interleave(n_kf) for f in f_idx]
     d_match = [buf(QMAX * n_kf * cap, torch.int32) for _ in range(NSLOT)]
     d_nm = [buf(QMAX * n_kf, torch.int32) for _ in range(NSLOT)]
     store = dict(desc=d_desc.data_ptr(), kps=d_kps.data_ptr(), valid=d_valid.data_ptr(), counts=d_counts.data_ptr(),
                  node_of=d_node.data_ptr(), cap=cap, n_frames=F, n_nodes=n_nodes, csr_keys=d_ckeys.data_ptr(),
-                 csr_start=d_cstart.data_ptr(), csr_cnt=d_ccnt.data_ptr())
+                 csr_start=d_cstart.data_ptr(), csr_cnt=d_ccnt.data_ptr(), csr_desc=d_cdesc.data_ptr())
     torch.cuda.synchronize()
 
     def extract(i):                                # stream frames i*Q .. i*Q+Q-1 -> query slot i % NSLOT
@@ -793,9 +797,13 @@ def run_c5(args, rank, local_rank, world, dev, comm_dev, dist):
         f0 = n_kf + s * QMAX
         voc.transform_device(mt, d_desc.data_ptr() + f0 * cap * 32, d_counts.data_ptr() + f0 * 4, q, cap, 4,
                              d_node_of=d_node.data_ptr() + f0 * cap * 2)
-        mt.build_csr_device(d_node.data_ptr() + f0 * cap * 2, d_counts.data_ptr() + f0 * 4, q, cap, n_nodes,
-                            d_ckeys.data_ptr() + f0 * cap * 4, d_cstart.data_ptr() + f0 * n_nodes * 2, d_ccnt.data_ptr() + f0 * n_nodes * 2)
-        mt.match_bow_batch_device(store, kf_idx.data_ptr(), f_idx[s].data_ptr(), q * n_kf, d_match[s].data_ptr(), d_nm[s].data_ptr())
+        mt.build_csr_desc_device(d_node.data_ptr() + f0 * cap * 2, d_counts.data_ptr() + f0 * 4, d_desc.data_ptr() + f0 * cap * 32, q, cap,
+                                 n_nodes, d_ckeys.data_ptr() + f0 * cap * 4, d_cstart.data_ptr() + f0 * n_nodes * 2,
+                                 d_ccnt.data_ptr() + f0 * n_nodes * 2, d_cdesc.data_ptr() + f0 * cap * 32)
+        if args.c5_pair_kernel:                    # round 3's form: one workgroup per (keyframe, frame) pair
+            mt.match_bow_batch_device(store, kf_pairs.data_ptr(), f_pairs[s].data_ptr(), q * n_kf, d_match[s].data_ptr(), d_nm[s].data_ptr())
+        else:                                      # one query against many keyframes (csrc/orb_matcher_query.hip)
+            mt.match_bow_query_device(store, kf_idx.data_ptr(), n_kf, f_idx[s].data_ptr(), q, d_match[s].data_ptr(), d_nm[s].data_ptr())
 
     ex_s, mt_s = torch.cuda.ExternalStream(ex.stream, device=dev), torch.cuda.ExternalStream(mt.stream, device=dev)
     ev_ex, ev_mt = [torch.cuda.Event() for _ in range(NSLOT)], [torch.cuda.Event() for _ in range(NSLOT)]

@@ -278,12 +278,19 @@ typedef struct orb_featstore {
     const uint32_t* csr_keys;   /* [n_frames*cap]      node << 16 | feature index, grouped by node            */
     const uint16_t* csr_start;  /* [n_frames*n_nodes]  first key of the node                                  */
     const uint16_t* csr_cnt;    /* [n_frames*n_nodes]  features of the frame in the node                      */
+    /* optional (ABI 4): the frame's descriptors in csr_keys order -- row p of frame f = desc of feature csr_keys[f*cap + p] & 0xFFFF --
+     * filled by orb_bow_build_csr_desc_device; what orb_match_bow_query_device walks (contiguous runs per node) */
+    const uint8_t* csr_desc;    /* [n_frames*cap][32] or NULL                                                  */
 } orb_featstore;
 
 /* Builds the CSR arrays above for frames [0, n_frames) of node_of / counts (same layout as in the store; pass
  * pointers offset to a frame to (re)build just that frame).  Asynchronous on the matcher's stream. */
 int orb_bow_build_csr_device(orb_matcher* m, const uint16_t* d_node_of, const int32_t* d_counts, int n_frames, int cap,
                              int n_nodes, uint32_t* d_keys, uint16_t* d_start, uint16_t* d_cnt);
+/* The same, and the node-sorted descriptor copy csr_desc of the same frames (d_desc: their descriptors, [n_frames*cap][32]). */
+int orb_bow_build_csr_desc_device(orb_matcher* m, const uint16_t* d_node_of, const int32_t* d_counts, const uint8_t* d_desc,
+                                  int n_frames, int cap, int n_nodes, uint32_t* d_keys, uint16_t* d_start, uint16_t* d_cnt,
+                                  uint8_t* d_csr_desc);
 
 /* Vocabulary stand-in of SURVEY 8d (the full DBoW2 descent is orb_bow_transform* below): 2-level k=10 tree,
  * centroids = 110 x 32 bytes (device pointer).
@@ -297,6 +304,22 @@ int orb_bow_assign_device(orb_matcher* m, const uint8_t* d_desc, const int32_t* 
 int orb_match_bow_batch_device(orb_matcher* m, const orb_featstore* store,
                                const int32_t* d_kf_index, const int32_t* d_f_index, int n_pairs,
                                float ratio, int check_ori, int32_t* d_match, int32_t* d_nmatches);
+
+/* One query frame against many keyframes: the candidate loop of Relocalization / DetectLoop itself (reference
+ * src/Tracking.cc:1471-1492 calls ORBmatcher::SearchByBoW(vpCandidateKFs[i], mCurrentFrame, ...) once per candidate,
+ * src/ORBmatcher.cc:552-687) as ONE call: query q = frame d_f_index[q] of the store against keyframes d_kf_index[0..n_kf).
+ * Pair p = q * n_kf + k; d_match [n_queries*n_kf][cap] and d_nmatches [n_queries*n_kf] exactly as
+ * orb_match_bow_batch_device would fill them for the pair list (d_kf_index[k], d_f_index[q]) -- same results, but the query
+ * side is staged once per vocabulary node instead of once per pair.  Needs the store's CSR arrays including csr_desc
+ * (ORB_ERR_INVALID otherwise).  Asynchronous on the matcher's stream. */
+int orb_match_bow_query_device(orb_matcher* m, const orb_featstore* store, const int32_t* d_kf_index, int n_kf,
+                               const int32_t* d_f_index, int n_queries, float ratio, int check_ori, int32_t* d_match,
+                               int32_t* d_nmatches);
+
+/* Diagnostics: a device buffer of `capacity` 64-bit words in which every workgroup of the following
+ * orb_match_bow_query_device calls leaves the 100 MHz device clock at its stage boundaries (8 words per workgroup: start,
+ * query staged, phase 1 done, phase 2 start / done, finish start, row written; tools/qk_stamps.py).  NULL switches it off. */
+int orb_matcher_set_stage_stamps(orb_matcher* m, unsigned long long* d_stamps, size_t capacity);
 
 void* orb_matcher_stream(orb_matcher* m);
 int orb_matcher_wait_for(orb_matcher* m, void* hip_stream);
@@ -424,10 +447,10 @@ int orb_stereo_match_batch_device(orb_extractor* left, orb_extractor* right, int
 /* ---------------------------------------------------------------- misc ---------------------*/
 const char* orb_last_error(void);   /* thread-local description of the last failure */
 const char* orb_version(void);
-/* ABI guard: the structs of this header grow between releases (orb_featstore gained the CSR pointers in 2).  A caller
+/* ABI guard: the structs of this header grow between releases (orb_featstore gained the CSR pointers in 2, csr_desc in 4).  A caller
  * built against an older header would be read past the end of its struct: compare orb_abi_version() with the
  * ORB_HIP_ABI_VERSION it was compiled with and orb_sizeof_featstore() with sizeof(orb_featstore) before the first call. */
-#define ORB_HIP_ABI_VERSION 3
+#define ORB_HIP_ABI_VERSION 4
 int orb_abi_version(void);
 size_t orb_sizeof_featstore(void);
 

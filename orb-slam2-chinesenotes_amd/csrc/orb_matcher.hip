@@ -18,14 +18,11 @@
 #include <vector>
 
 #include "orb_block_sort.h"
-#include "orb_wave.h"
 #include "orb_matcher_internal.h"
+#include "orb_bow_device.h"
 
 #pragma clang fp contract(off)
 
-#define WAVE 64
-#define TH_LOW 50
-#define HISTO_LENGTH 30
 #define MAX_NODES 1024
 #define NODE_NONE 0xFFFFu
 
@@ -61,65 +58,6 @@ extern "C" void orb_three_maxima(const int32_t* counts30, int32_t* ind3)
     int a, b, c;
     three_maxima(counts30, a, b, c);
     ind3[0] = a; ind3[1] = b; ind3[2] = c;
-}
-
-// ------------------------------------------------------------------ device helpers
-__device__ __forceinline__ int hamming8(const uint32_t* a, const uint32_t* b)
-{
-    int d = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) d += __popc(a[i] ^ b[i]);
-    return d;
-}
-
-// A load through a pointer that is known to point to global (HBM) memory.  The BowSide pointers reach the kernel inside a
-// struct read from memory, so the compiler cannot tell their address space and would emit flat_load (which also takes an
-// LDS-aperture check and counts on both wait counters); this makes it a global_load.
-template <class T>
-__device__ __forceinline__ T gload(const T* p)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    return *reinterpret_cast<const __attribute__((address_space(1))) T*>(reinterpret_cast<uintptr_t>(p));
-#else
-    return *p;                                         // (host pass of the single-source compile: never executed)
-#endif
-}
-
-__device__ __forceinline__ void load_desc(const uint8_t* p, uint32_t v[8])
-{
-    const uint4 lo = gload(reinterpret_cast<const uint4*>(p)), hi = gload(reinterpret_cast<const uint4*>(p) + 1);
-    v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w;
-    v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
-}
-
-// rotation-histogram bin (reference :634-641): factor is 1/HISTO_LENGTH, so only bins 0..12 occur
-__device__ __forceinline__ int rot_bin(float angA, float angB)
-{
-    float rot = __fsub_rn(angA, angB);
-    if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
-    int bin = (int)roundf(__fmul_rn(rot, 1.0f / HISTO_LENGTH));
-    if (bin == HISTO_LENGTH) bin = 0;
-    return bin;
-}
-
-// ComputeThreeMaxima (:1663-1707) by one wave: the reference's sequential scan with strict > keeps, among equal counts,
-// the lower bin first, i.e. it selects by (count descending, bin ascending) -- three wave maxima of (count << 8 | 63 - bin),
-// empty bins (the scan never takes a count of 0) excluded.  (A serial 30-step loop by one thread, unrolled by the compiler
-// under this kernel's 64-VGPR limit, spilled ~150 scratch accesses into the tail of every pair.)
-__device__ __forceinline__ void three_maxima_wave(const int* hist, int* keep, int lane)
-{
-    const int cnt = lane < HISTO_LENGTH ? hist[lane] : 0;
-    const unsigned key = cnt > 0 ? ((unsigned)cnt << 8) | (unsigned)(63 - lane) : 0u;
-    const unsigned k1 = ~orb_wave_umin(~key);
-    const unsigned key2 = key == k1 ? 0u : key;
-    const unsigned k2 = ~orb_wave_umin(~key2);
-    const unsigned key3 = key2 == k2 ? 0u : key2;
-    const unsigned k3 = ~orb_wave_umin(~key3);
-    int ind1 = k1 ? 63 - (int)(k1 & 0xFFu) : -1, ind2 = k2 ? 63 - (int)(k2 & 0xFFu) : -1, ind3 = k3 ? 63 - (int)(k3 & 0xFFu) : -1;
-    const float max1 = (float)(k1 >> 8), max2 = (float)(k2 >> 8), max3 = (float)(k3 >> 8);
-    if (max2 < __fmul_rn(0.1f, max1)) { ind2 = -1; ind3 = -1; }
-    else if (max3 < __fmul_rn(0.1f, max1)) { ind3 = -1; }
-    if (lane == 0) { keep[0] = ind1; keep[1] = ind2; keep[2] = ind3; }
 }
 
 // ------------------------------------------------------------------ vocabulary stand-in
@@ -238,7 +176,8 @@ __device__ __forceinline__ void load_or_build_csr(const BowSide& S, int nNodes, 
 // one workgroup per frame of a feature store: its CSR, kept in HBM next to node_of
 __global__ __launch_bounds__(1024) void k_build_csr(const uint16_t* __restrict__ nodeOf, const int32_t* __restrict__ counts,
                                                     int cap, int nNodes, uint32_t* __restrict__ keysOut,
-                                                    uint16_t* __restrict__ startOut, uint16_t* __restrict__ cntOut)
+                                                    uint16_t* __restrict__ startOut, uint16_t* __restrict__ cntOut,
+                                                    const uint8_t* __restrict__ descIn, uint8_t* __restrict__ descOut)
 {
     extern __shared__ uint32_t csm[];
     uint32_t* keys = csm;
@@ -254,6 +193,14 @@ __global__ __launch_bounds__(1024) void k_build_csr(const uint16_t* __restrict__
     for (int t = threadIdx.x; t < nNodes; t += blockDim.x) {
         startOut[(size_t)f * nNodes + t] = start[t];
         cntOut[(size_t)f * nNodes + t] = cnt[t];
+    }
+    if (descOut) {                                             // the descriptors in key order (orb_featstore.csr_desc)
+        const uint4* src = reinterpret_cast<const uint4*>(descIn) + (size_t)f * cap * 2;
+        uint4* dst = reinterpret_cast<uint4*>(descOut) + (size_t)f * cap * 2;
+        for (int i = threadIdx.x; i < 2 * cap; i += blockDim.x) {
+            const uint32_t k = keys[i >> 1];
+            if (k != 0xFFFFFFFFu) dst[i] = src[2 * (k & 0xFFFFu) + (i & 1)];
+        }
     }
 }
 
@@ -658,6 +605,7 @@ extern "C" int orb_matcher_create(int device_id, orb_matcher** out)
     orb_matcher* m = new (std::nothrow) orb_matcher();
     if (!m) return ORB_ERR_INTERNAL;
     m->device = device_id;
+    { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0) m->cus = cus; }
     hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete m; orb_set_error("hipStreamCreate: %s", hipGetErrorString(e)); return ORB_ERR_HIP; }
     (void)hipEventCreateWithFlags(&m->waitEv, hipEventDisableTiming);
@@ -679,7 +627,7 @@ extern "C" void orb_matcher_destroy(orb_matcher* m)
     if (!m) return;
     (void)hipSetDevice(m->device);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
-    m->sidesA.release(); m->sidesB.release(); m->out.release(); m->nm.release();
+    m->sidesA.release(); m->sidesB.release(); m->out.release(); m->nm.release(); m->plan.release();
     for (auto& b : m->stage) b.release();
     for (auto& b : m->init) b.release();
     if (m->waitEv) (void)hipEventDestroy(m->waitEv);
@@ -718,8 +666,8 @@ static int launch_match(orb_matcher* m, bool kk, const BowSide* dA, const BowSid
         return ORB_ERR_UNSUPPORTED;
     }
     if (lds > 64 * 1024) {                                 // frames of > ~3900 features: the CU's whole LDS for one pair
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_match_bow<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_match_bow<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        ORB_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_match_bow<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        ORB_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_match_bow<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     if (kk)
         hipLaunchKernelGGL(k_match_bow<true>, dim3(nPairs), dim3(1024), lds, m->stream, dA, dB, nNodes, capLds, ratio,
@@ -746,17 +694,19 @@ extern "C" int orb_match_bow_batch_device(orb_matcher* m, const orb_featstore* s
         return ORB_ERR_UNSUPPORTED;
     }
     if (lds > 64 * 1024)                                   // frames of > ~3900 features: the CU's whole LDS for one pair
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_match_bow_store), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        ORB_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_match_bow_store), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_match_bow_store, dim3(nPairs), dim3(1024), lds, m->stream, *store, d_kf, d_f, nNodes, ratio, checkOri, d_match,
                        d_nm);
     ORB_HIP_TRY(hipGetLastError());
     return ORB_OK;
 }
 
-extern "C" int orb_bow_build_csr_device(orb_matcher* m, const uint16_t* d_node_of, const int32_t* d_counts, int nFrames, int cap,
-                                        int nNodes, uint32_t* d_keys, uint16_t* d_start, uint16_t* d_cnt)
+extern "C" int orb_bow_build_csr_desc_device(orb_matcher* m, const uint16_t* d_node_of, const int32_t* d_counts, const uint8_t* d_desc,
+                                             int nFrames, int cap, int nNodes, uint32_t* d_keys, uint16_t* d_start, uint16_t* d_cnt,
+                                             uint8_t* d_csr_desc)
 {
     if (!m || !d_node_of || !d_counts || !d_keys || !d_start || !d_cnt || nFrames < 0 || nNodes <= 0) return ORB_ERR_INVALID;
+    if ((d_csr_desc != nullptr) != (d_desc != nullptr)) return ORB_ERR_INVALID;
     if (nFrames == 0) return ORB_OK;
     if (cap <= 0 || cap > 8192) { orb_set_error("featstore cap must be 1..8192"); return ORB_ERR_UNSUPPORTED; }
     const size_t lds = (size_t)cap * 8 + (size_t)nNodes * 8;
@@ -764,9 +714,15 @@ extern "C" int orb_bow_build_csr_device(orb_matcher* m, const uint16_t* d_node_o
     ORB_HIP_TRY(hipSetDevice(m->device));                      // the attribute below is per device
     if (lds > 64 * 1024) ORB_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_csr), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_build_csr, dim3(nFrames), dim3(1024), lds, m->stream, d_node_of, d_counts, cap, nNodes, d_keys, d_start,
-                       d_cnt);
+                       d_cnt, d_desc, d_csr_desc);
     ORB_HIP_TRY(hipGetLastError());
     return ORB_OK;
+}
+
+extern "C" int orb_bow_build_csr_device(orb_matcher* m, const uint16_t* d_node_of, const int32_t* d_counts, int nFrames, int cap,
+                                        int nNodes, uint32_t* d_keys, uint16_t* d_start, uint16_t* d_cnt)
+{
+    return orb_bow_build_csr_desc_device(m, d_node_of, d_counts, nullptr, nFrames, cap, nNodes, d_keys, d_start, d_cnt, nullptr);
 }
 
 // CSR feature vectors of both sides -> per-feature compact node index over the COMMON node ids

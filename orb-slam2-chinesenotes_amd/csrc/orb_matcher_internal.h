@@ -18,10 +18,14 @@ struct MBuf {
 
 struct orb_matcher {
     int device = 0;
+    int cus = 256;                       // compute units of the device (grid sizing of the query-form matcher)
     hipStream_t stream = nullptr;
     MBuf sidesA, sidesB;                 // BowSide arrays of a batch
     MBuf stage[12];                      // host-API staging (SearchByBoW)
     MBuf init[12];                       // host-API staging + scratch (SearchForInitialization)
     MBuf out, nm;
+    MBuf plan;                           // pair lists of orb_match_bow_query_device's large-frame fallback (orb_matcher_query.hip)
     hipEvent_t waitEv = nullptr;
+    unsigned long long* stamps = nullptr;   // diagnostics: orb_matcher_set_stage_stamps
+    size_t stampCap = 0;
 };

@@ -19,7 +19,7 @@
 struct OrbDbShard {
     int device = 0, first = 0, count = 0;      // keyframes [first, first + count) of the database
     orb_matcher* mt = nullptr;
-    MBuf desc, kps, valid, counts, nodeOf, ckeys, cstart, ccnt, kfIdx, fIdx, match, nm;
+    MBuf desc, kps, valid, counts, nodeOf, ckeys, cstart, ccnt, cdesc, kfIdx, fIdx, match, nm;
     orb_featstore store;
 };
 
@@ -34,7 +34,7 @@ extern "C" void orb_multi_db_destroy(orb_multi_db* db)
     for (OrbDbShard& s : db->sh) {
         (void)hipSetDevice(s.device);
         if (s.mt) { (void)orb_matcher_sync(s.mt); orb_matcher_destroy(s.mt); }
-        MBuf* bufs[] = {&s.desc, &s.kps, &s.valid, &s.counts, &s.nodeOf, &s.ckeys, &s.cstart, &s.ccnt, &s.kfIdx, &s.fIdx, &s.match, &s.nm};
+        MBuf* bufs[] = {&s.desc, &s.kps, &s.valid, &s.counts, &s.nodeOf, &s.ckeys, &s.cstart, &s.ccnt, &s.cdesc, &s.kfIdx, &s.fIdx, &s.match, &s.nm};
         for (MBuf* b : bufs) b->release();
     }
     delete db;
@@ -51,7 +51,7 @@ static int build_shard(OrbDbShard& s, const uint8_t* desc, const orb_keypoint* k
     if ((rc = s.desc.ensure(F * c * ORB_DESC_BYTES)) != ORB_OK || (rc = s.kps.ensure(F * c * sizeof(orb_keypoint))) != ORB_OK ||
         (rc = s.valid.ensure(F * c)) != ORB_OK || (rc = s.counts.ensure(F * 4)) != ORB_OK || (rc = s.nodeOf.ensure(F * c * 2)) != ORB_OK ||
         (rc = s.ckeys.ensure(F * c * 4)) != ORB_OK || (rc = s.cstart.ensure(F * (size_t)nNodes * 2)) != ORB_OK ||
-        (rc = s.ccnt.ensure(F * (size_t)nNodes * 2)) != ORB_OK || (rc = s.kfIdx.ensure(std::max<size_t>(s.count, 1) * 4)) != ORB_OK ||
+        (rc = s.ccnt.ensure(F * (size_t)nNodes * 2)) != ORB_OK || (rc = s.cdesc.ensure(F * c * ORB_DESC_BYTES)) != ORB_OK || (rc = s.kfIdx.ensure(std::max<size_t>(s.count, 1) * 4)) != ORB_OK ||
         (rc = s.fIdx.ensure(std::max<size_t>(s.count, 1) * 4)) != ORB_OK || (rc = s.match.ensure(std::max<size_t>(s.count, 1) * c * 4)) != ORB_OK ||
         (rc = s.nm.ensure(std::max<size_t>(s.count, 1) * 4)) != ORB_OK)
         return rc;
@@ -71,8 +71,8 @@ static int build_shard(OrbDbShard& s, const uint8_t* desc, const orb_keypoint* k
         ORB_HIP_TRY(hipMemcpyAsync(s.fIdx.p, fq.data(), n * 4, hipMemcpyHostToDevice, st));
         ORB_HIP_TRY(hipStreamSynchronize(st));                      // the index vectors go out of scope
         // the keyframes' feature vectors, once (the reference computes them once per KeyFrame, src/KeyFrame.cc:70)
-        rc = orb_bow_build_csr_device(s.mt, (const uint16_t*)s.nodeOf.p, (const int32_t*)s.counts.p, (int)n, cap, nNodes,
-                                      (uint32_t*)s.ckeys.p, (uint16_t*)s.cstart.p, (uint16_t*)s.ccnt.p);
+        rc = orb_bow_build_csr_desc_device(s.mt, (const uint16_t*)s.nodeOf.p, (const int32_t*)s.counts.p, (const uint8_t*)s.desc.p, (int)n,
+                                           cap, nNodes, (uint32_t*)s.ckeys.p, (uint16_t*)s.cstart.p, (uint16_t*)s.ccnt.p, (uint8_t*)s.cdesc.p);
         if (rc != ORB_OK) return rc;
     }
     s.store.desc = (const uint8_t*)s.desc.p;
@@ -86,6 +86,7 @@ static int build_shard(OrbDbShard& s, const uint8_t* desc, const orb_keypoint* k
     s.store.csr_keys = (const uint32_t*)s.ckeys.p;
     s.store.csr_start = (const uint16_t*)s.cstart.p;
     s.store.csr_cnt = (const uint16_t*)s.ccnt.p;
+    s.store.csr_desc = (const uint8_t*)s.cdesc.p;
     return orb_matcher_sync(s.mt);
 }
 
@@ -143,11 +144,13 @@ static int query_shard(OrbDbShard& s, int cap, int nNodes, const uint8_t* qDesc,
     const int32_t qc = qCount;
     ORB_HIP_TRY(hipMemcpyAsync((int32_t*)s.counts.p + slot, &qc, 4, hipMemcpyHostToDevice, st));
     ORB_HIP_TRY(hipStreamSynchronize(st));                          // &qc is a stack variable
-    int rc = orb_bow_build_csr_device(s.mt, (const uint16_t*)s.nodeOf.p + slot * c, (const int32_t*)s.counts.p + slot, 1, cap, nNodes,
-                                      (uint32_t*)s.ckeys.p + slot * c, (uint16_t*)s.cstart.p + slot * (size_t)nNodes,
-                                      (uint16_t*)s.ccnt.p + slot * (size_t)nNodes);
+    int rc = orb_bow_build_csr_desc_device(s.mt, (const uint16_t*)s.nodeOf.p + slot * c, (const int32_t*)s.counts.p + slot,
+                                           (const uint8_t*)s.desc.p + slot * c * ORB_DESC_BYTES, 1, cap, nNodes,
+                                           (uint32_t*)s.ckeys.p + slot * c, (uint16_t*)s.cstart.p + slot * (size_t)nNodes,
+                                           (uint16_t*)s.ccnt.p + slot * (size_t)nNodes, (uint8_t*)s.cdesc.p + slot * c * ORB_DESC_BYTES);
     if (rc != ORB_OK) return rc;
-    rc = orb_match_bow_batch_device(s.mt, &s.store, (const int32_t*)s.kfIdx.p, (const int32_t*)s.fIdx.p, s.count, ratio, checkOri,
+    // one query against the shard's keyframes: the candidate loop as ONE launch pair (orb_matcher_query.hip)
+    rc = orb_match_bow_query_device(s.mt, &s.store, (const int32_t*)s.kfIdx.p, s.count, (const int32_t*)s.fIdx.p, 1, ratio, checkOri,
                                     (int32_t*)s.match.p, (int32_t*)s.nm.p);
     if (rc != ORB_OK) return rc;
     ORB_HIP_TRY(hipMemcpyAsync(match + (size_t)s.first * c, s.match.p, (size_t)s.count * c * 4, hipMemcpyDeviceToHost, st));

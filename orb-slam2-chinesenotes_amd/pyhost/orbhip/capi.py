@@ -42,7 +42,7 @@ class FeatVecC(C.Structure):
 class FeatStoreC(C.Structure):
     _fields_ = [("desc", C.c_void_p), ("kps", C.c_void_p), ("valid", C.c_void_p), ("counts", C.c_void_p),
                 ("node_of", C.c_void_p), ("cap", C.c_int32), ("n_frames", C.c_int32), ("n_nodes", C.c_int32),
-                ("csr_keys", C.c_void_p), ("csr_start", C.c_void_p), ("csr_cnt", C.c_void_p)]
+                ("csr_keys", C.c_void_p), ("csr_start", C.c_void_p), ("csr_cnt", C.c_void_p), ("csr_desc", C.c_void_p)]
 
 
 def build_library(force=False):
@@ -65,6 +65,7 @@ SYMBOLS = [
     "orb_hamming", "orb_three_maxima", "orb_matcher_create", "orb_matcher_destroy", "orb_matcher_sync",
     "orb_match_bow", "orb_match_bow_kk", "orb_match_init", "orb_match_projection", "orb_match_projection_best", "orb_match_triangulation", "orb_vocab_create", "orb_vocab_destroy", "orb_vocab_level_nodes", "orb_bow_transform",
     "orb_bow_transform_device", "orb_distinctive_descriptors", "orb_distinctive_descriptors_device", "orb_bow_assign_device", "orb_match_bow_batch_device", "orb_bow_build_csr_device",
+    "orb_bow_build_csr_desc_device", "orb_match_bow_query_device", "orb_matcher_set_stage_stamps",
     "orb_matcher_stream", "orb_stereo_match", "orb_stereo_match_device", "orb_stereo_match_batch_device", "orb_extractor_wait_for", "orb_matcher_wait_for", "orb_last_error", "orb_version", "orb_abi_version", "orb_sizeof_featstore", "orb_multi_create", "orb_multi_destroy", "orb_multi_devices", "orb_multi_handle",
     "orb_multi_set_pattern", "orb_multi_extract_batch", "orb_shard_range", "orb_multi_db_create", "orb_multi_db_destroy",
     "orb_multi_db_shards", "orb_multi_match_bow_batch",
@@ -135,6 +136,9 @@ def lib():
     L.orb_bow_assign_device.argtypes = [vp, vp, vp, ci, ci, vp, vp]
     L.orb_match_bow_batch_device.argtypes = [vp, C.POINTER(FeatStoreC), vp, vp, ci, cf, ci, vp, vp]
     L.orb_bow_build_csr_device.argtypes = [vp, vp, vp, ci, ci, ci, vp, vp, vp]
+    L.orb_bow_build_csr_desc_device.argtypes = [vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp]
+    L.orb_matcher_set_stage_stamps.argtypes = [vp, vp, C.c_size_t]
+    L.orb_match_bow_query_device.argtypes = [vp, C.POINTER(FeatStoreC), vp, ci, vp, ci, cf, ci, vp, vp]
     L.orb_matcher_stream.argtypes = [vp]
     L.orb_matcher_stream.restype = vp
     L.orb_extractor_wait_for.argtypes = [vp, vp]
@@ -540,11 +544,26 @@ class Matcher:
         _check(self.L.orb_bow_build_csr_device(self.h, C.c_void_p(d_node_of), C.c_void_p(d_counts), n_frames, cap, n_nodes,
                                                C.c_void_p(d_keys), C.c_void_p(d_start), C.c_void_p(d_cnt)))
 
+    def build_csr_desc_device(self, d_node_of, d_counts, d_desc, n_frames, cap, n_nodes, d_keys, d_start, d_cnt, d_csr_desc):
+        _check(self.L.orb_bow_build_csr_desc_device(self.h, C.c_void_p(d_node_of), C.c_void_p(d_counts), C.c_void_p(d_desc), n_frames,
+                                                    cap, n_nodes, C.c_void_p(d_keys), C.c_void_p(d_start), C.c_void_p(d_cnt),
+                                                    C.c_void_p(d_csr_desc)))
+
+    @staticmethod
+    def _store(store):
+        return FeatStoreC(store["desc"], store["kps"], store.get("valid") or None, store["counts"], store["node_of"],
+                          store["cap"], store["n_frames"], store.get("n_nodes", 0), store.get("csr_keys") or None,
+                          store.get("csr_start") or None, store.get("csr_cnt") or None, store.get("csr_desc") or None)
+
+    def match_bow_query_device(self, store, d_kf_index, n_kf, d_f_index, n_queries, d_match, d_nmatches):
+        """queries d_f_index[0..n_queries) against keyframes d_kf_index[0..n_kf): pair q * n_kf + k."""
+        s = self._store(store)
+        _check(self.L.orb_match_bow_query_device(self.h, C.byref(s), C.c_void_p(d_kf_index), n_kf, C.c_void_p(d_f_index), n_queries,
+                                                 self.nnratio, int(self.check_ori), C.c_void_p(d_match), C.c_void_p(d_nmatches)))
+
     def match_bow_batch_device(self, store, d_kf_index, d_f_index, n_pairs, d_match, d_nmatches):
         """store = dict(desc=, kps=, valid=, counts=, node_of=, cap=, n_frames=) of raw device pointers."""
-        s = FeatStoreC(store["desc"], store["kps"], store.get("valid") or None, store["counts"], store["node_of"],
-                       store["cap"], store["n_frames"], store.get("n_nodes", 0), store.get("csr_keys") or None,
-                       store.get("csr_start") or None, store.get("csr_cnt") or None)
+        s = self._store(store)
         _check(self.L.orb_match_bow_batch_device(self.h, C.byref(s), C.c_void_p(d_kf_index), C.c_void_p(d_f_index), n_pairs,
                                                  self.nnratio, int(self.check_ori), C.c_void_p(d_match),
                                                  C.c_void_p(d_nmatches)))

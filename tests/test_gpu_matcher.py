@@ -615,11 +615,19 @@ def test_c5_full_size_1000_keyframe_db():
         ex.sync()
     voc.transform_device(mt, d_desc.data_ptr(), d_counts.data_ptr(), F, cap, 3, d_node_of=d_node.data_ptr())
     d_ck, d_cs, d_cc = z(F * cap, torch.int32), z(F * nn, torch.int16), z(F * nn, torch.int16)
-    mt.build_csr_device(d_node.data_ptr(), d_counts.data_ptr(), F, cap, nn, d_ck.data_ptr(), d_cs.data_ptr(), d_cc.data_ptr())
+    d_cd = z(F * cap * 32, torch.uint8)
+    mt.build_csr_desc_device(d_node.data_ptr(), d_counts.data_ptr(), d_desc.data_ptr(), F, cap, nn, d_ck.data_ptr(), d_cs.data_ptr(),
+                             d_cc.data_ptr(), d_cd.data_ptr())
     base = dict(desc=d_desc.data_ptr(), kps=d_kps.data_ptr(), valid=d_valid.data_ptr(), counts=d_counts.data_ptr(),
                 node_of=d_node.data_ptr(), cap=cap, n_frames=F, n_nodes=nn)
-    with_csr = dict(base, csr_keys=d_ck.data_ptr(), csr_start=d_cs.data_ptr(), csr_cnt=d_cc.data_ptr())
+    with_csr = dict(base, csr_keys=d_ck.data_ptr(), csr_start=d_cs.data_ptr(), csr_cnt=d_cc.data_ptr(), csr_desc=d_cd.data_ptr())
     kf_idx = torch.arange(n_kf, dtype=torch.int32, device=dev)
+    # the query form (orb_match_bow_query_device): all three queries against the 1000 keyframes in ONE call
+    q_idx = torch.arange(n_kf, n_kf + nq, dtype=torch.int32, device=dev)
+    d_mq, d_nq = z(nq * n_kf * cap, torch.int32), z(nq * n_kf, torch.int32)
+    mt.match_bow_query_device(with_csr, kf_idx.data_ptr(), n_kf, q_idx.data_ptr(), nq, d_mq.data_ptr(), d_nq.data_ptr())
+    mt.sync()
+    mq, nmq = d_mq.cpu().numpy().reshape(nq, n_kf, cap), d_nq.cpu().numpy().reshape(nq, n_kf)
     counts = d_counts.cpu().numpy()
     kps = d_kps.cpu().numpy().view(capi.KP_DTYPE).reshape(F, cap)
     desc = d_desc.cpu().numpy().reshape(F, cap, 32)
@@ -635,6 +643,7 @@ def test_c5_full_size_1000_keyframe_db():
         (m0, n0), (m1, n1), (m2, n2) = res
         assert np.array_equal(m0, m1) and np.array_equal(n0, n1)            # idempotent
         assert np.array_equal(m0, m2) and np.array_equal(n0, n2)            # store CSR == CSR built inside the matcher
+        assert np.array_equal(n0, nmq[q]) and np.array_equal(m0[:, :int(counts[n_kf + q])], mq[q][:, :int(counts[n_kf + q])])   # query form == pair kernel, all 1000 keyframes
         nqf = int(counts[n_kf + q])
         assert np.all(n0 == (m0[:, :nqf] >= 0).sum(axis=1))                  # rows are written for the query's features only
         for kf in rng.choice(n_kf, 25, replace=False):                      # a keyframe feature is matched at most once
