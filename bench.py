@@ -99,6 +99,8 @@ def parse():
                          "handles on two streams (the default, the shape of the reference's two threads, src/Frame.cc:82-85; measured: "
                          "156 k frames/s with two handles, 144 k with one -- the two chains overlap each other's latency-bound kernels)")
     ap.add_argument("--c5-pair-kernel", action="store_true", help="config 5: SearchByBoW with the pair kernel (one workgroup per (keyframe, frame) pair) instead of the query form")
+    ap.add_argument("--c5-extractors", type=int, default=2, help="config 5: extractor handles that consecutive stream frames alternate between")
+    ap.add_argument("--c5-matchers", type=int, default=1, help="config 5: matcher handles that consecutive stream frames alternate between")
     ap.add_argument("--c5-slots", type=int, default=4, help="config 5: query slots in the ring between the extractor and the matcher stream")
     ap.add_argument("--stream-frames", type=int, default=256,
                     help="config c5: distinct stream frames resident in HBM that the timed steps walk through (3682 = the whole "
@@ -786,15 +788,25 @@ def run_c5(args, rank, local_rank, world, dev, comm_dev, dist):
                  csr_start=d_cstart.data_ptr(), csr_cnt=d_ccnt.data_ptr(), csr_desc=d_cdesc.data_ptr())
     torch.cuda.synchronize()
 
+    # the extraction of one frame is a chain of six latency-bound launches (~92 us for a handful of workgroups each): frame
+    # i + 1 goes through a second extractor handle (its own stream and scratch) while frame i is still in its chain
+    exs = [ex] + [capi.Extractor(args.nfeatures, device=local_rank) for _ in range(max(1, args.c5_extractors) - 1)]
+    NEX = len(exs)
+
     def extract(i):                                # stream frames i*Q .. i*Q+Q-1 -> query slot i % NSLOT
         s, q = i % NSLOT, Q[0]
         f0 = n_kf + s * QMAX
-        ex.extract_batch_device(stream.data_ptr() + ((i * q) % (n_q - q + 1)) * W * H, q, H, W, W, W * H, d_kps.data_ptr() + f0 * cap * 28,
+        exs[i % NEX].extract_batch_device(stream.data_ptr() + ((i * q) % (n_q - q + 1)) * W * H, q, H, W, W, W * H, d_kps.data_ptr() + f0 * cap * 28,
                                 d_desc.data_ptr() + f0 * cap * 32, cap, d_counts.data_ptr() + f0 * 4)
+
+    # likewise the matcher side: descent (7 us) + feature vector (6 us) of frame i + 1 run beside frame i's 1000 matchings
+    mts = [mt] + [capi.Matcher(0.7, True, device=local_rank) for _ in range(max(1, args.c5_matchers) - 1)]
+    NMT = len(mts)
 
     def match(i):
         s, q = i % NSLOT, Q[0]
         f0 = n_kf + s * QMAX
+        mt = mts[i % NMT]
         voc.transform_device(mt, d_desc.data_ptr() + f0 * cap * 32, d_counts.data_ptr() + f0 * 4, q, cap, 4,
                              d_node_of=d_node.data_ptr() + f0 * cap * 2)
         mt.build_csr_desc_device(d_node.data_ptr() + f0 * cap * 2, d_counts.data_ptr() + f0 * 4, d_desc.data_ptr() + f0 * cap * 32, q, cap,
@@ -805,7 +817,8 @@ def run_c5(args, rank, local_rank, world, dev, comm_dev, dist):
         else:                                      # one query against many keyframes (csrc/orb_matcher_query.hip)
             mt.match_bow_query_device(store, kf_idx.data_ptr(), n_kf, f_idx[s].data_ptr(), q, d_match[s].data_ptr(), d_nm[s].data_ptr())
 
-    ex_s, mt_s = torch.cuda.ExternalStream(ex.stream, device=dev), torch.cuda.ExternalStream(mt.stream, device=dev)
+    ex_ss = [torch.cuda.ExternalStream(e.stream, device=dev) for e in exs]
+    mt_ss = [torch.cuda.ExternalStream(m.stream, device=dev) for m in mts]
     ev_ex, ev_mt = [torch.cuda.Event() for _ in range(NSLOT)], [torch.cuda.Event() for _ in range(NSLOT)]
 
     def run(n, i0=0):
@@ -813,27 +826,28 @@ def run_c5(args, rank, local_rank, world, dev, comm_dev, dist):
         # the chain match(i-1) -> extract(i+1) -> match(i+1) made two steps cost extract + match + two cross-stream waits
         # (0.150 ms per frame); with the ring the step is the busier stream's chain
         extract(i0)
-        ev_ex[i0 % NSLOT].record(ex_s)
+        ev_ex[i0 % NSLOT].record(ex_ss[i0 % NEX])
         for i in range(i0, i0 + n):
             j = i + 1
             if j - NSLOT >= i0:
-                ex_s.wait_event(ev_mt[j % NSLOT])                  # match(j - NSLOT) has let go of the slot
+                ex_ss[j % NEX].wait_event(ev_mt[j % NSLOT])        # match(j - NSLOT) has let go of the slot
             extract(j)
-            ev_ex[j % NSLOT].record(ex_s)
-            mt_s.wait_event(ev_ex[i % NSLOT])
+            ev_ex[j % NSLOT].record(ex_ss[j % NEX])
+            mt_ss[i % NMT].wait_event(ev_ex[i % NSLOT])
             match(i)
-            ev_mt[i % NSLOT].record(mt_s)
+            ev_mt[i % NSLOT].record(mt_ss[i % NMT])
 
     for _ in range(3):                             # (synchronised calls first: the FAST strip lengths settle)
         run(1)
-        ex.sync(); mt.sync()
+        [e.sync() for e in exs]; [m.sync() for m in mts]
     run(max(args.warmup, 2))
-    ex.sync(); mt.sync(); torch.cuda.synchronize()
+    [e.sync() for e in exs]; [m.sync() for m in mts]; torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
     run(args.steps)
-    ex.sync(); mt.sync(); torch.cuda.synchronize()
+    t_submit = time.perf_counter() - t0            # host side alone: when it is close to `elapsed` the step is bound by the launches
+    [e.sync() for e in exs]; [m.sync() for m in mts]; torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     elapsed = shard.max_over_ranks(dist, time.perf_counter() - t0, comm_dev)
@@ -841,18 +855,18 @@ def run_c5(args, rank, local_rank, world, dev, comm_dev, dist):
     # the same stream in mini-batches of QMAX frames per step (offline sequence processing): throughput, not `value`
     Q[0] = QMAX
     run(3)
-    ex.sync(); mt.sync(); torch.cuda.synchronize()
+    [e.sync() for e in exs]; [m.sync() for m in mts]; torch.cuda.synchronize()
     t1 = time.perf_counter()
     n_mb = max(10, args.steps // QMAX)
     run(n_mb)
-    ex.sync(); mt.sync(); torch.cuda.synchronize()
+    [e.sync() for e in exs]; [m.sync() for m in mts]; torch.cuda.synchronize()
     mini_fps = n_mb * QMAX / (time.perf_counter() - t1)
     Q[0] = 1
     # non-overlapped match duration (the dominant kernel of this configuration is k_match_bow over 1000 pairs)
     t_m = []
     for i in range(4):
-        ex.wait_for(mt.stream); extract(i); ex.sync()
-        t1 = time.perf_counter(); match(i); mt.sync(); t_m.append(time.perf_counter() - t1)
+        exs[i % NEX].wait_for(mts[i % NMT].stream); extract(i); exs[i % NEX].sync()
+        t1 = time.perf_counter(); match(i); mts[i % NMT].sync(); t_m.append(time.perf_counter() - t1)
     match_ms = statistics.median(t_m) * 1e3
     if rank != 0:
         return None
@@ -871,9 +885,10 @@ def run_c5(args, rank, local_rank, world, dev, comm_dev, dist):
                                   "a %d-keyframe DB in HBM (moving-camera sequence of 125 scenes x 8 views; the stream revisits "
                                   "them)" % n_kf, "pair_matchings_per_s": round(n_kf * done / elapsed, 0),
                       "mean_matches_per_pair": round(float(nm.mean()), 2), "max_matches_per_pair": int(nm.max()),
-                      "distinct_stream_frames": n_q,
+                      "distinct_stream_frames": n_q, "extractor_handles": NEX, "matcher_handles": NMT,
                       "frames_per_s_in_mini_batches_of_%d" % QMAX: round(mini_fps, 1),
-                      "transform_plus_match_ms_alone": round(match_ms, 4)},
+                      "transform_plus_match_ms_alone": round(match_ms, 4),
+                      "host_submit_ms_per_step": round(t_submit / args.steps * 1e3, 4)},
            "roofline": {"bound": "hbm", "kernel": "k_match_bow (+ k_vocab_transform of the query)", "achieved": round(ach, 2),
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
                         "algorithmic_bytes_per_query": int(bytes_query), "kernel_ms_per_launch": round(match_ms, 4),

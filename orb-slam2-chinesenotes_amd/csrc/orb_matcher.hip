@@ -627,7 +627,7 @@ extern "C" void orb_matcher_destroy(orb_matcher* m)
     if (!m) return;
     (void)hipSetDevice(m->device);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
-    m->sidesA.release(); m->sidesB.release(); m->out.release(); m->nm.release(); m->plan.release();
+    m->sidesA.release(); m->sidesB.release(); m->out.release(); m->nm.release(); m->plan.release(); m->qctr.release();
     for (auto& b : m->stage) b.release();
     for (auto& b : m->init) b.release();
     if (m->waitEv) (void)hipEventDestroy(m->waitEv);

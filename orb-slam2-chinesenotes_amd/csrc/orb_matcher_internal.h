@@ -26,6 +26,9 @@ struct orb_matcher {
     MBuf out, nm;
     MBuf plan;                           // pair lists of orb_match_bow_query_device's large-frame fallback (orb_matcher_query.hip)
     hipEvent_t waitEv = nullptr;
+    MBuf qctr;                           // ring of 8 x qctrStride group counters of k_match_bow_query (launch L uses slot L % 8 and clears slot (L + 4) % 8)
+    size_t qctrStride = 0;
+    unsigned qserial = 0;
     unsigned long long* stamps = nullptr;   // diagnostics: orb_matcher_set_stage_stamps
     size_t stampCap = 0;
 };

@@ -47,7 +47,7 @@
 // the LDS; 4 -- one round over a 1000-keyframe list -- measured slower: 86 against 64-70 us, every barrier then waits for the
 // slowest of four keyframes)
 // diagnostics (orb_matcher_set_stage_stamps): thread 0 of a workgroup leaves the 100 MHz clock at the stage boundaries of its FIRST keyframe pair
-#define QK_STAMP(k) do { if (stamps && tid == 0 && s0 == (int)blockIdx.x) stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define QK_STAMP(k) do { if (stamps && tid == 0 && iter == 0) stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 
 __device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c)
 {
@@ -99,14 +99,17 @@ static size_t query_lds_bytes(int cap, int nNodes, int G)
     return (size_t)cap * (32 + 4 + 2 + G * (8 + 4 + 2 + 1)) + (size_t)nNodes * (4 + G * 8) + 64;
 }
 
-// grid: x = keyframe slots (half g of workgroup b: slots b + g gridDim.x, + G gridDim.x, ...: the keyframes of a workgroup are
-// far apart in the list, so neighbours of one scene -- the expensive pairs -- land in different workgroups), y = query
+// grid: x = workgroups, one per CU, each taking groups of G keyframe slots (p, p + nGroups, ...: far apart in the list, so
+// neighbours of one scene -- the expensive pairs -- land in different groups) from a counter until the list is done: a
+// workgroup that drew the keyframe of the query's own scene (16 us of phase 2 instead of 0.4) takes fewer groups afterwards;
+// with a fixed two groups per workgroup those few set the kernel's end 15-20 us after everyone else's.  y = query
 // ONE workgroup per CU is resident (hipOccupancyMaxActiveBlocksPerMultiprocessor): the fused kernel needs ~100 scalar and ~96 vector
 // registers, a second 16-wave workgroup would need 8 waves per SIMD (<= 96 / 64), and forcing that (amdgpu_waves_per_eu) spills.
 template <int QK_G>
 __global__ __launch_bounds__(QK_THREADS) void k_match_bow_query(orb_featstore S, const int32_t* __restrict__ kfIndex, int nKf,
                                                                const int32_t* __restrict__ fIndex, int nNodes, float ratio, int checkOri,
                                                                int32_t* __restrict__ match, int32_t* __restrict__ nmatches,
+                                                               unsigned* __restrict__ groupCtr, unsigned* __restrict__ ctrToClear,
                                                                unsigned long long* __restrict__ stamps)
 {
     extern __shared__ uint4 qsm[];
@@ -156,9 +159,17 @@ __global__ __launch_bounds__(QK_THREADS) void k_match_bow_query(orb_featstore S,
     }
     for (int n = t; n < nNodes; n += QK_HALF) firstAcc[n] = 0xFFFFFFFFu;      // (again after every phase 2)
 
-    { const int s0 = blockIdx.x; QK_STAMP(0); }
-    for (int s0 = blockIdx.x; s0 < nKf; s0 += gridDim.x * QK_G) {
-        const int slot = s0 + g * gridDim.x;
+    __shared__ int nextGroup;
+    const int nGroups = (nKf + QK_G - 1) / QK_G;
+    if (blockIdx.x == 0 && tid == 0) ctrToClear[q] = 0;            // (the counter a later launch will use; this launch's is groupCtr[q])
+    int iter = 0;
+    QK_STAMP(0);
+    for (;; iter++) {
+        if (tid == 0) nextGroup = (int)atomicAdd(&groupCtr[q], 1u);
+        __syncthreads();
+        const int s0 = nextGroup;
+        if (s0 >= nGroups) break;
+        const int slot = s0 + g * nGroups;
         const size_t pair = (size_t)q * nKf + (size_t)min(slot, nKf - 1);
         int32_t* out = match + pair * cap;
         int nA = -1, kf = 0;
@@ -483,9 +494,21 @@ extern "C" int orb_match_bow_query_device(orb_matcher* m, const orb_featstore* s
     // a workgroup stages the query side once and keeps it for its keyframes: one workgroup per CU, each looping over its share
     const int perCu = 1;
     const long long slots = (long long)m->cus * perCu;
-    const int blocks = (int)std::max<long long>(1, std::min<long long>((n_kf + G - 1) / G, std::max<long long>(1, slots / n_queries)));
+    const int blocks = (int)std::max<long long>(1, std::min<long long>((n_kf + G - 1) / G, std::max<long long>(1, slots / n_queries)));      // per query
     unsigned long long* stamps = (unsigned long long)blocks * n_queries * 8 <= m->stampCap ? m->stamps : nullptr;
     const dim3 grid(blocks, n_queries), block(QK_THREADS);
+    if ((size_t)n_queries > m->qctrStride) {                       // the counter ring (zeroed once; every launch clears a slot for a later one)
+        const size_t stride = std::max<size_t>(64, (size_t)n_queries);
+        ORB_HIP_TRY(hipStreamSynchronize(m->stream));
+        int rc = m->qctr.ensure(8 * stride * sizeof(unsigned));
+        if (rc != ORB_OK) return rc;
+        ORB_HIP_TRY(hipMemsetAsync(m->qctr.p, 0, 8 * stride * sizeof(unsigned), m->stream));
+        m->qctrStride = stride;
+        m->qserial = 0;
+    }
+    unsigned* groupCtr = (unsigned*)m->qctr.p + (size_t)(m->qserial % 8) * m->qctrStride;
+    unsigned* ctrToClear = (unsigned*)m->qctr.p + (size_t)((m->qserial + 4) % 8) * m->qctrStride;
+    m->qserial++;
     if (envDbg) {
         int nb = -1;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, QK_THREADS, lds);
@@ -493,13 +516,13 @@ extern "C" int orb_match_bow_query_device(orb_matcher* m, const orb_featstore* s
     }
     if (G == 4)
         hipLaunchKernelGGL(k_match_bow_query<4>, grid, block, lds, m->stream, *store, d_kf_index, n_kf, d_f_index, nNodes, ratio, check_ori,
-                           d_match, d_nmatches, stamps);
+                           d_match, d_nmatches, groupCtr, ctrToClear, stamps);
     else if (G == 2)
         hipLaunchKernelGGL(k_match_bow_query<2>, grid, block, lds, m->stream, *store, d_kf_index, n_kf, d_f_index, nNodes, ratio, check_ori,
-                           d_match, d_nmatches, stamps);
+                           d_match, d_nmatches, groupCtr, ctrToClear, stamps);
     else
         hipLaunchKernelGGL(k_match_bow_query<1>, grid, block, lds, m->stream, *store, d_kf_index, n_kf, d_f_index, nNodes, ratio, check_ori,
-                           d_match, d_nmatches, stamps);
+                           d_match, d_nmatches, groupCtr, ctrToClear, stamps);
     ORB_HIP_TRY(hipGetLastError());
     return ORB_OK;
 }
