@@ -566,14 +566,17 @@ extern "C" int orb_extract_batch(orb_extractor* h, const uint8_t* imgs, int nFra
     const size_t kStageLimit = (size_t)96 << 20;
     const size_t statB = orb_extractor::statInts(nFrames) * 4, cntB = (size_t)4 * nFrames;
     const size_t kpB = sizeof(orb_keypoint) * (size_t)cap * nFrames, dsB = (size_t)ORB_DESC_BYTES * cap * nFrames;
-    const bool whole = statB + cntB + kpB + dsB <= kStageLimit;
+    // where the pieces sit in the pinned staging: keypoints and descriptors on 16-byte boundaries (the descriptor kernel stores
+    // 8-byte words straight into it in the single-frame path; 28 * cap bytes of keypoints would leave them 4-byte aligned)
+    const size_t kpOff = (statB + cntB + 15) & ~(size_t)15, dsOff = (kpOff + kpB + 15) & ~(size_t)15, stgEnd = dsOff + dsB;
+    const bool whole = stgEnd <= kStageLimit;
     // Single frames (the reference's operator() path) skip both DMA legs: the image is copied by the CPU into the handle's
     // pinned staging and the first pyramid kernel reads it from there over PCIe; keypoints, descriptors and the count are
     // written by the descriptor kernel straight into pinned staging.  What is left on the copy engines is the 200-byte
     // status block.  (A pageable hipMemcpyAsync of 307 KB costs more than the CPU copy + the kernel's reads.)
     const bool zero = nFrames == 1 && whole && !std::getenv("ORB_NO_ZEROCOPY");
-    const size_t imgOff = (statB + cntB + kpB + dsB + 255) & ~(size_t)255;
-    if ((rc = ensure_stage(h, whole ? (zero ? imgOff + imgBytes + 256 : statB + cntB + kpB + dsB) : statB + cntB)) != ORB_OK) return rc;
+    const size_t imgOff = (stgEnd + 255) & ~(size_t)255;
+    if ((rc = ensure_stage(h, whole ? (zero ? imgOff + imgBytes + 256 : stgEnd) : statB + cntB)) != ORB_OK) return rc;
     uint8_t* stg = (uint8_t*)h->hStage;
     const double tm0 = g_timing ? now_us() : 0.0;
     if (zero) {
@@ -603,8 +606,8 @@ extern "C" int orb_extract_batch(orb_extractor* h, const uint8_t* imgs, int nFra
     // the chain and the copies back; issued eagerly, or (single frames, the reference's per-call path) as one graph
     auto chain = [&]() -> int {
         if (zero) {
-            int r = orb_extract_batch_device(h, stg + imgOff, 1, rows, cols, cols, imgBytes, (orb_keypoint*)(stg + statB + cntB),
-                                             stg + statB + cntB + kpB, cap, (int32_t*)(stg + statB));
+            int r = orb_extract_batch_device(h, stg + imgOff, 1, rows, cols, cols, imgBytes, (orb_keypoint*)(stg + kpOff),
+                                             stg + dsOff, cap, (int32_t*)(stg + statB));
             if (r != ORB_OK) return r;
             ORB_HIP_TRY(hipMemcpyAsync(stg, h->dStat.p, statB, hipMemcpyDeviceToHost, h->stream));
             return ORB_OK;
@@ -615,8 +618,8 @@ extern "C" int orb_extract_batch(orb_extractor* h, const uint8_t* imgs, int nFra
         ORB_HIP_TRY(hipMemcpyAsync(stg, h->dStat.p, statB, hipMemcpyDeviceToHost, h->stream));
         ORB_HIP_TRY(hipMemcpyAsync(stg + statB, h->dCounts.p, cntB, hipMemcpyDeviceToHost, h->stream));
         if (whole) {
-            ORB_HIP_TRY(hipMemcpyAsync(stg + statB + cntB, h->dKps.p, kpB, hipMemcpyDeviceToHost, h->stream));
-            ORB_HIP_TRY(hipMemcpyAsync(stg + statB + cntB + kpB, h->dDesc.p, dsB, hipMemcpyDeviceToHost, h->stream));
+            ORB_HIP_TRY(hipMemcpyAsync(stg + kpOff, h->dKps.p, kpB, hipMemcpyDeviceToHost, h->stream));
+            ORB_HIP_TRY(hipMemcpyAsync(stg + dsOff, h->dDesc.p, dsB, hipMemcpyDeviceToHost, h->stream));
         }
         return ORB_OK;
     };
@@ -692,8 +695,8 @@ extern "C" int orb_extract_batch(orb_extractor* h, const uint8_t* imgs, int nFra
         const int n = counts[f];
         if (n <= 0) continue;
         if (whole) {
-            std::memcpy(kps + (size_t)cap * f, stg + statB + cntB + sizeof(orb_keypoint) * (size_t)cap * f, sizeof(orb_keypoint) * n);
-            std::memcpy(desc + (size_t)ORB_DESC_BYTES * cap * f, stg + statB + cntB + kpB + (size_t)ORB_DESC_BYTES * cap * f,
+            std::memcpy(kps + (size_t)cap * f, stg + kpOff + sizeof(orb_keypoint) * (size_t)cap * f, sizeof(orb_keypoint) * n);
+            std::memcpy(desc + (size_t)ORB_DESC_BYTES * cap * f, stg + dsOff + (size_t)ORB_DESC_BYTES * cap * f,
                         (size_t)ORB_DESC_BYTES * n);
         } else {
             ORB_HIP_TRY(hipMemcpyAsync(kps + (size_t)cap * f, (orb_keypoint*)h->dKps.p + (size_t)cap * f,

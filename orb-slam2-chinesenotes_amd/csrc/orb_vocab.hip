@@ -276,6 +276,7 @@ static int compact_table(orb_vocab* v, int levelsup, const int32_t** dTab, int* 
 extern "C" int orb_vocab_level_nodes(orb_vocab* v, int levelsup)
 {
     if (!v) return ORB_ERR_INVALID;
+    ORB_HIP_TRY(hipSetDevice(v->device));                          // (compact_table allocates and uploads on first use; found by tests/test_lint_setdevice.py)
     const int32_t* t; int K;
     const int rc = compact_table(v, levelsup, &t, &K);
     return rc == ORB_OK ? K : rc;

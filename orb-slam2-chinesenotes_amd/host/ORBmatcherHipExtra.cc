@@ -370,11 +370,15 @@ int ORBmatcher::Fuse(KeyFrame* pKF, const std::vector<MapPoint*>& vpMapPoints, c
                                     pKF->mvuRight.empty() ? nullptr : pKF->mvuRight.data(), pKF->N, grid4, TH_LOW, 1,
                                     pKF->mvInvLevelSigma2.data(), (int)pKF->mvInvLevelSigma2.size(), best.data(), dist.data()),
           "orb_match_projection_best");
-    // the map surgery, in the reference's order (:1456-1476): it never feeds back into the search
+    // the map surgery, in the reference's order (:1456-1476).  It does not feed back into the SEARCH (a MapPoint's position and
+    // descriptor do not change), but it does feed back into the gates of :1386-1387, which the reference evaluates per
+    // iteration: a pointer listed twice is in the keyframe (or replaced, i.e. bad) by its second turn, and Replace() can turn
+    // a later entry bad -- so the gates are evaluated again here, at the point of the reference's loop.
     int nFused = 0;
     for (int i = 0; i < nMPs; i++) {
         if (best[i] < 0) continue;
         MapPoint* pMP = vpMapPoints[i];
+        if (pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;
         MapPoint* pMPinKF = pKF->GetMapPoint(best[i]);
         if (pMPinKF) {
             if (!pMPinKF->isBad()) {

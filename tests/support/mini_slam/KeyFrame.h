@@ -1,0 +1,4 @@
+// TEST DOUBLE: the reference's include/KeyFrame.h stand-in lives in ORBmatcher.h of this directory (one header for all the
+// SLAM types the shims touch).
+#pragma once
+#include "ORBmatcher.h"

@@ -8,6 +8,7 @@
 #pragma once
 #include <cmath>
 #include <map>
+#include <mutex>
 #include <set>
 #include <vector>
 #include <opencv2/core/core.hpp>
@@ -15,9 +16,15 @@
 namespace ORB_SLAM2 { class ORBextractor; }
 
 namespace DBoW2 {
+// Mirrors the PUBLIC and PROTECTED interface of ORB-SLAM2's Thirdparty/DBoW2 (BowVector.h, FeatureVector.h, FORB.h,
+// TemplatedVocabulary.h) as far as the shims use it -- same names, same access -- so that a shim written against a name
+// that the real library lacks fails to compile here as well.
 typedef unsigned int NodeId;
 typedef unsigned int WordId;
 typedef double WordValue;
+enum LNorm { L1, L2 };
+enum WeightingType { TF_IDF, TF, IDF, BINARY };
+enum ScoringType { L1_NORM, L2_NORM, CHI_SQUARE, KL, BHATTACHARYYA, DOT_PRODUCT };
 class FeatureVector : public std::map<NodeId, std::vector<unsigned int> > {
 public:
     void addFeature(NodeId id, unsigned int i_feature)           // DBoW2/FeatureVector.cpp
@@ -38,41 +45,69 @@ public:
         if (vit != this->end() && !(this->key_comp()(id, vit->first))) vit->second += v;
         else this->insert(vit, value_type(id, v));
     }
-    void normalizeL1()
+    void addIfNotExist(WordId id, WordValue v)
+    {
+        iterator vit = this->lower_bound(id);
+        if (vit == this->end() || (this->key_comp()(id, vit->first))) this->insert(vit, value_type(id, v));
+    }
+    void normalize(LNorm norm_type)
     {
         double norm = 0.0;
-        for (iterator it = begin(); it != end(); ++it) norm += std::fabs(it->second);
+        if (norm_type == DBoW2::L1) {
+            for (iterator it = begin(); it != end(); ++it) norm += std::fabs(it->second);
+        } else {
+            for (iterator it = begin(); it != end(); ++it) norm += it->second * it->second;
+            norm = std::sqrt(norm);
+        }
         if (norm > 0.0)
             for (iterator it = begin(); it != end(); ++it) it->second /= norm;
     }
 };
-// The slice of DBoW2::TemplatedVocabulary<TDescriptor, F> the ComputeBoW replacement needs: the node table is a
-// PROTECTED member there too (m_nodes: id, weight, children, parent, descriptor, word_id), so the shim reaches it
-// through a derived accessor class, exactly as it would in a real tree.
-class Vocabulary {
+class FORB {
 public:
+    typedef cv::Mat TDescriptor;
+    typedef const TDescriptor* pDescriptor;
+    static const int L = 32;
+};
+// The slice of DBoW2::TemplatedVocabulary<TDescriptor, F> the ComputeBoW replacements need.  The node type and the node
+// table are PROTECTED there: a shim reaches them through a class derived from the vocabulary, and so does the test driver.
+template <class TDescriptor, class F>
+class TemplatedVocabulary {
+public:
+    TemplatedVocabulary(int k = 10, int L = 5, WeightingType weighting = TF_IDF, ScoringType scoring = L1_NORM)
+        : m_k(k), m_L(L), m_weighting(weighting), m_scoring(scoring) {}
+    virtual ~TemplatedVocabulary() {}
+    int getBranchingFactor() const { return m_k; }
+    int getDepthLevels() const { return m_L; }
+    WeightingType getWeightingType() const { return m_weighting; }
+    ScoringType getScoringType() const { return m_scoring; }
+    virtual inline unsigned int size() const { return (unsigned int)m_words.size(); }
+    virtual inline bool empty() const { return m_words.empty(); }
+
+protected:
+    typedef const TDescriptor* pDescriptor;
     struct Node {
         NodeId id;
         WordValue weight;
         std::vector<NodeId> children;
         NodeId parent;
-        cv::Mat descriptor;
+        TDescriptor descriptor;
         WordId word_id;
         Node() : id(0), weight(0), parent(0), word_id(0) {}
-        bool isLeaf() const { return children.empty(); }
+        Node(NodeId _id) : id(_id), weight(0), parent(0), word_id(0) {}
+        inline bool isLeaf() const { return children.empty(); }
     };
-    int getDepthLevels() const { return m_L; }
-    int getBranchingFactor() const { return m_k; }
-    int m_k = 10, m_L = 6;
-    std::vector<Node> m_nodes_public_for_the_test_driver;          // the driver fills the tree through this alias
-protected:
-    std::vector<Node>& m_nodes = m_nodes_public_for_the_test_driver;
+    int m_k;
+    int m_L;
+    WeightingType m_weighting;
+    ScoringType m_scoring;
+    std::vector<Node> m_nodes;
+    std::vector<Node*> m_words;
 };
 }  // namespace DBoW2
-
 namespace ORB_SLAM2 {
 
-typedef DBoW2::Vocabulary ORBVocabulary;
+typedef DBoW2::TemplatedVocabulary<DBoW2::FORB::TDescriptor, DBoW2::FORB> ORBVocabulary;      // include/ORBVocabulary.h
 class KeyFrame;
 class Frame;
 
@@ -88,6 +123,8 @@ public:
     float GetMaxDistanceInvariance() { return 1.2f * mfMaxDistance; }
     int PredictScale(const float& currentDist, KeyFrame* pKF);
     int PredictScale(const float& currentDist, Frame* pF);
+    void ComputeDistinctiveDescriptors();                          // host/MapPointHip.cc (src/MapPoint.cc:275-342)
+    std::mutex mMutexFeatures;
     bool IsInKeyFrame(KeyFrame* pKF) { return mObservations.count(pKF) != 0; }
     int GetIndexInKeyFrame(KeyFrame* pKF) { return mObservations.count(pKF) ? (int)mObservations[pKF] : -1; }
     void AddObservation(KeyFrame* pKF, size_t idx) { if (!mObservations.count(pKF)) { mObservations[pKF] = idx; nObs++; } }
@@ -134,7 +171,12 @@ public:
     std::vector<cv::KeyPoint> mvKeysUn;
     std::vector<float> mvuRight;
     cv::Mat mDescriptors;
+    DBoW2::BowVector mBowVec;
     DBoW2::FeatureVector mFeatVec;
+    ORBVocabulary* mpORBvocabulary = nullptr;
+    bool mbBad = false;
+    bool isBad() { return mbBad; }
+    void ComputeBoW();                                             // host/KeyFrameHip.cc (src/KeyFrame.cc:64-73)
     std::vector<MapPoint*> mvpMapPoints;
     cv::Mat Tcw;                                                   // 4x4 float
     float fx = 0, fy = 0, cx = 0, cy = 0, mbf = 0;

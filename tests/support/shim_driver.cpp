@@ -185,6 +185,7 @@ struct World {
         return o;
     }
 };
+namespace ORB_SLAM2 { namespace hipshim { void ComputeDistinctiveDescriptors(const std::vector<MapPoint*>& points); } }
 static void dumpQueries(const std::string& p)
 {
     const std::vector<orb_proj_query>& q = hipshim::LastProjectionQueries();
@@ -237,6 +238,17 @@ static int runExtra(const std::string& scenePath, const std::string& out)
         for (size_t i = 0; i < W.mp.size(); i++) rep[i] = W.indexOf(W.mp[i]->mpReplaced);
         dumpInts(out + ".r5rep", rep);
     }
+    {   // 5b: the same with the first 150 MapPoints listed twice: by its second turn a point is in the keyframe or replaced, and
+        // the reference's per-iteration gates (:1386-1387) skip it
+        World W(S);
+        ORBmatcher m;
+        std::vector<MapPoint*> twice = W.mp;
+        for (size_t i = 0; i < 150 && i < W.mp.size(); i++) twice.push_back(W.mp[i]);
+        const int nf = m.Fuse(&W.kB, twice, 3.0f);
+        std::vector<int> r = W.indices(W.kB.mvpMapPoints);
+        r.push_back(nf);
+        dumpInts(out + ".r5b", r);
+    }
     {   // 6: Fuse with a Sim3 pose, :1483-1633
         World W(S);
         ORBmatcher m;
@@ -268,34 +280,83 @@ static int runExtra(const std::string& scenePath, const std::string& out)
         hipshim::LastEpipole(&e[0], &e[1]);
         dump(out + ".epi", e, 8);
     }
-    {   // 9: Frame::ComputeBoW, src/Frame.cc:425-433, on a k = 3, L = 5 vocabulary built from the scene's descriptors
+    {   // 9: Frame::ComputeBoW, src/Frame.cc:425-433, and KeyFrame::ComputeBoW, src/KeyFrame.cc:64-73, on a k = 3, L = 5
+        // vocabulary built from the scene's descriptors.  Node and m_nodes are protected in DBoW2: the driver fills the tree
+        // through a derived class, as the shims read it through one.
+        struct TestVocabulary : public ORBVocabulary {
+            TestVocabulary() : ORBVocabulary(3, 5, DBoW2::TF_IDF, DBoW2::L1_NORM) {}
+            void build(const Scene& S)
+            {
+                const int nInner = 1 + 3 + 9 + 27 + 81, nNodes = nInner + 243;
+                m_nodes.resize(nNodes);
+                unsigned word = 0;
+                for (int i = 0; i < nNodes; i++) {
+                    m_nodes[i].id = (unsigned)i;
+                    m_nodes[i].descriptor = cv::Mat(1, 32, CV_8U);
+                    memcpy(m_nodes[i].descriptor.data, S.dA.ptr<unsigned char>((i * 7) % S.nA), 32);
+                    if (i >= 1) m_nodes[i].parent = (unsigned)((i - 1) / 3);
+                    if (i < nInner) for (int c = 0; c < 3; c++) m_nodes[i].children.push_back((unsigned)(3 * i + 1 + c));
+                    else { m_nodes[i].word_id = word++; m_nodes[i].weight = (word % 5 == 0) ? 0.0 : 0.25 + 0.01 * (word % 17); }
+                }
+                m_words.clear();
+                for (int i = nInner; i < nNodes; i++) m_words.push_back(&m_nodes[i]);
+            }
+        };
         World W(S);
-        ORBVocabulary voc;
-        voc.m_k = 3; voc.m_L = 5;
-        std::vector<DBoW2::Vocabulary::Node>& nodes = voc.m_nodes_public_for_the_test_driver;
-        const int nInner = 1 + 3 + 9 + 27 + 81, nNodes = nInner + 243;
-        nodes.resize(nNodes);
-        unsigned word = 0;
-        for (int i = 0; i < nNodes; i++) {
-            nodes[i].id = (unsigned)i;
-            nodes[i].descriptor = cv::Mat(1, 32, CV_8U);
-            memcpy(nodes[i].descriptor.data, S.dA.ptr<unsigned char>((i * 7) % S.nA), 32);
-            if (i >= 1) nodes[i].parent = (unsigned)((i - 1) / 3);
-            if (i < nInner) for (int c = 0; c < 3; c++) nodes[i].children.push_back((unsigned)(3 * i + 1 + c));
-            else { nodes[i].word_id = word++; nodes[i].weight = (word % 5 == 0) ? 0.0 : 0.25 + 0.01 * (word % 17); }
-        }
+        TestVocabulary voc;
+        voc.build(S);
         W.fB.mpORBvocabulary = &voc;
         W.fB.mFeatVec.clear();                                               // a new Frame: ComputeBoW fills both containers
         W.fB.ComputeBoW();
-        std::vector<int> bowIds, fvFlat;
-        std::vector<double> bowVals;
-        for (DBoW2::BowVector::const_iterator it = W.fB.mBowVec.begin(); it != W.fB.mBowVec.end(); ++it) { bowIds.push_back((int)it->first); bowVals.push_back(it->second); }
-        for (DBoW2::FeatureVector::const_iterator it = W.fB.mFeatVec.begin(); it != W.fB.mFeatVec.end(); ++it)
-            for (size_t k = 0; k < it->second.size(); k++) { fvFlat.push_back((int)it->first); fvFlat.push_back((int)it->second[k]); }
-        dumpInts(out + ".bowids", bowIds);
-        dump(out + ".bowvals", bowVals.data(), bowVals.size() * 8);
-        dumpInts(out + ".fv", fvFlat);
-        counts.push_back((int)bowIds.size());
+        W.kB.mpORBvocabulary = &voc;
+        W.kB.mBowVec.clear();
+        W.kB.mFeatVec.clear();
+        W.kB.ComputeBoW();
+        auto dumpBow = [&](const std::string& tag, const DBoW2::BowVector& bv, const DBoW2::FeatureVector& fvec) {
+            std::vector<int> bowIds, fvFlat;
+            std::vector<double> bowVals;
+            for (DBoW2::BowVector::const_iterator it = bv.begin(); it != bv.end(); ++it) { bowIds.push_back((int)it->first); bowVals.push_back(it->second); }
+            for (DBoW2::FeatureVector::const_iterator it = fvec.begin(); it != fvec.end(); ++it)
+                for (size_t k = 0; k < it->second.size(); k++) { fvFlat.push_back((int)it->first); fvFlat.push_back((int)it->second[k]); }
+            dumpInts(out + "." + tag + "bowids", bowIds);
+            dump(out + "." + tag + "bowvals", bowVals.data(), bowVals.size() * 8);
+            dumpInts(out + "." + tag + "fv", fvFlat);
+            return (int)bowIds.size();
+        };
+        counts.push_back(dumpBow("", W.fB.mBowVec, W.fB.mFeatVec));
+        counts.push_back(dumpBow("k", W.kB.mBowVec, W.kB.mFeatVec));
+    }
+    {   // 10: MapPoint::ComputeDistinctiveDescriptors, src/MapPoint.cc:275-342, and the batch form over many MapPoints:
+        // 12 keyframes (number 5 bad), 200 MapPoints seen by 1..12 of them, descriptors = scene rows with a few bits flipped
+        const int K = 12, P = 200;
+        std::vector<KeyFrame> kfs(K);                                       // (contiguous: the observation map iterates in this order)
+        for (int k = 0; k < K; k++) {
+            kfs[k].mDescriptors = cv::Mat(P, 32, CV_8U);
+            kfs[k].mbBad = k == 5;
+            for (int p = 0; p < P; p++)
+                for (int b = 0; b < 32; b++) {
+                    unsigned char v = S.dA.ptr<unsigned char>(p % S.nA)[b];
+                    if ((p * 31 + k * 17 + b * 7) % 11 == 0) v ^= (unsigned char)(1u << ((p + k + b) % 8));
+                    kfs[k].mDescriptors.ptr<unsigned char>(p)[b] = v;
+                }
+        }
+        std::vector<unsigned char> chosen[2];
+        for (int pass = 0; pass < 2; pass++) {
+            std::vector<MapPoint*> pts;
+            for (int p = 0; p < P; p++) {
+                MapPoint* mp = new MapPoint(p % 41 == 40);                    // a few bad MapPoints: left alone (:285-286)
+                const int nObs = 1 + (p * 7) % K;
+                for (int j = 0; j < nObs; j++) mp->mObservations[&kfs[(p + 5 * j) % K]] = (size_t)p;
+                mp->mDescriptor = cv::Mat::zeros(1, 32, CV_8U);
+                pts.push_back(mp);
+            }
+            if (pass == 0) for (int p = 0; p < P; p++) pts[p]->ComputeDistinctiveDescriptors();
+            else hipshim::ComputeDistinctiveDescriptors(pts);
+            for (int p = 0; p < P; p++) chosen[pass].insert(chosen[pass].end(), pts[p]->mDescriptor.data, pts[p]->mDescriptor.data + 32);
+        }
+        dump(out + ".distinct1", chosen[0].data(), chosen[0].size());
+        dump(out + ".distinctN", chosen[1].data(), chosen[1].size());
+        counts.push_back(P);
     }
     dumpInts(out + ".counts", counts);
     return 0;

@@ -24,7 +24,8 @@ def build_driver():
            "-I" + os.path.join(PKG, "host"), "-I" + os.path.join(ROOT, "include"),
            os.path.join(SUP, "shim_driver.cpp"), os.path.join(PKG, "host", "ORBextractor.cc"),
            os.path.join(PKG, "host", "ORBmatcherHip.cc"), os.path.join(PKG, "host", "ORBmatcherHipExtra.cc"),
-           os.path.join(PKG, "host", "FrameHip.cc"), "-L" + PKG, "-lorbhip", "-Wl,-rpath," + PKG, "-o", DRIVER]
+           os.path.join(PKG, "host", "FrameHip.cc"), os.path.join(PKG, "host", "KeyFrameHip.cc"),
+           os.path.join(PKG, "host", "MapPointHip.cc"), "-L" + PKG, "-lorbhip", "-Wl,-rpath," + PKG, "-o", DRIVER]
     subprocess.check_call(cmd)
     return DRIVER
 
@@ -325,6 +326,27 @@ def test_optional_matcher_bindings_against_the_oracle(tmp_path):
             kf[bi[i]] = i
             obs[i] += 1
     assert np.array_equal(rd(".r5"), kf) and np.array_equal(rd(".r5rep"), rep)
+    # 5b: the first 150 MapPoints listed twice -- the gates of :1386-1387 evaluated per iteration, as the reference does
+    kf = mpB.copy(); obs = nobs.copy(); isbad = bad.copy(); nf = 0
+    in_kf = np.array([m["idxB"] >= 0 for m in mps])
+    for i in list(range(nMP)) + list(range(min(150, nMP))):
+        if bi[i] < 0 or isbad[i] or in_kf[i]:
+            continue
+        other = kf[bi[i]]
+        if other >= 0:
+            if not isbad[other]:
+                if obs[other] > obs[i]:
+                    isbad[i] = 1
+                else:
+                    isbad[other] = 1
+        else:
+            kf[bi[i]] = i
+            obs[i] += 1
+            in_kf[i] = True
+        nf += 1
+    r5b = rd(".r5b")
+    assert np.array_equal(r5b[:-1], kf) and r5b[-1] == nf
+    assert (bi[:150] >= 0).sum() > 8                                 # the duplicated entries do include fused points
 
     # 6: Fuse(KeyFrame, Scw, points, replace)
     q = rd(".q6", oracle.PROJ_DTYPE)
@@ -396,6 +418,34 @@ def test_optional_matcher_bindings_against_the_oracle(tmp_path):
     assert np.allclose(vals, [bow[k] / tot for k in sorted(bow)], rtol=1e-12)
     got_fv = rd(".fv").reshape(-1, 2)
     assert sorted(map(tuple, got_fv.tolist())) == sorted(fv) and np.all(np.diff(got_fv[:, 0]) >= 0)
+    # KeyFrame::ComputeBoW (src/KeyFrame.cc:64-73) on the keyframe made of the same frame: the same two containers
+    assert counts[9] == counts[8] and np.array_equal(rd(".kbowids"), ids) and np.array_equal(rd(".kbowvals", np.float64), vals)
+    assert np.array_equal(rd(".kfv"), rd(".fv"))
+
+    # 10: MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:275-342), one MapPoint per call and 200 in one call
+    K, P = 12, 200
+    kd = np.zeros((K, P, 32), np.uint8)
+    pp, kk, bb = np.meshgrid(np.arange(P), np.arange(K), np.arange(32), indexing="ij")
+    flip = ((pp * 31 + kk * 17 + bb * 7) % 11 == 0)
+    kd = (dA[np.arange(P) % nA][:, None, :] ^ np.where(flip, 1 << ((pp + kk + bb) % 8), 0).astype(np.uint8)).transpose(1, 0, 2)
+    want = np.zeros((P, 32), np.uint8)
+    rows, offs = [], [0]
+    obs_of = []
+    for p in range(P):
+        ks = sorted({(p + 5 * j) % K for j in range(1 + (p * 7) % K)} - {5})          # keyframe 5 is bad: skipped (:299)
+        if p % 41 == 40:
+            ks = []                                                                   # a bad MapPoint: left alone
+        obs_of.append(ks)
+        rows += [kd[k, p] for k in ks]
+        offs.append(len(rows))
+    best = oracle.distinctive_descriptors(np.stack(rows), np.array(offs, np.int32))
+    for p in range(P):
+        if obs_of[p]:
+            want[p] = kd[obs_of[p][best[p]], p]
+    assert counts[10] == P
+    assert np.array_equal(rd(".distinct1", np.uint8).reshape(P, 32), want)
+    assert np.array_equal(rd(".distinctN", np.uint8).reshape(P, 32), want)
+    assert len({len(k) for k in obs_of}) > 8 and (want.any(axis=1)).sum() > 180
 
 
 @pytest.mark.gpu
