@@ -77,6 +77,23 @@ int orb_extractor_set_pattern_device(orb_extractor* h, const int8_t* d_pattern_x
 /* Copies the built-in table to a caller buffer of 1024 bytes (what rank 0 broadcasts). */
 int orb_builtin_pattern(int8_t* pattern_xy_1024);
 
+/* The integer taps of cv::GaussianBlur(image, Size(7, 7), 2, 2, BORDER_REFLECT_101) on CV_8U (reference
+ * src/ORBextractor.cc:1129-1130; OpenCV is a third-party dependency whose version the reference does not pin): symmetric
+ * kernel k0 k1 k2 k3 k2 k1 k0 in 8.8 fixed point, row pass sum(k * pixel), column pass (sum(k * row) + 32768) >> 16,
+ * saturated.  Which integers OpenCV uses depends on its version:
+ *   ORB_GAUSS_OPENCV_LEGACY         {18, 34, 49, 55} (sum 257): cvRound(256 * float tap) -- OpenCV 2.4 ... 3.4.1's integer
+ *                                   filter engine AND the first fixed-point ("bit-exact") implementations of 3.4.2+ / 4.0+,
+ *                                   which round every tap to nearest as well.  The default of a new handle.
+ *   ORB_GAUSS_OPENCV_FIXEDPOINT_ED  {18, 34, 48, 56} (sum 256): the later fixed-point kernels, whose taps are rounded with
+ *                                   error diffusion so that they sum to exactly 256 (getGaussianKernelFixedPoint_ED).
+ * Both are restated from the builder's knowledge of OpenCV's sources, not checked against an OpenCV build (INTEGRATION.md 5;
+ * tools/pin_against_opencv tells on a machine that has one).  orb_extractor_set_gaussian takes any taps in 0..255 whose
+ * kernel sums to at most 257.  Synchronises the handle's stream. */
+#define ORB_GAUSS_OPENCV_LEGACY 0
+#define ORB_GAUSS_OPENCV_FIXEDPOINT_ED 1
+int orb_gaussian_preset(int preset, int32_t* taps4);
+int orb_extractor_set_gaussian(orb_extractor* h, const int32_t* taps4);
+
 /* ---------------------------------------------------------------- extraction ---------------
  * replaces: ORBextractor::operator()(image, mask, keypoints, descriptors),
  * reference src/ORBextractor.cc:1084-1150 (mask is ignored there too, include/ORBextractor.h:59).

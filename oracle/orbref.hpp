@@ -48,6 +48,8 @@ class Extractor {
 public:
     // reference ctor: src/ORBextractor.cc:498-559
     Extractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST);
+    // the integer taps cv::GaussianBlur(7x7, sigma 2) uses for CV_8U: OpenCV-version dependent, see orb_gaussian_preset
+    int gaussTaps[4] = {18, 34, 49, 55};
 
     // reference operator(): src/ORBextractor.cc:1084-1150
     void extract(const uint8_t* img, int rows, int cols, size_t stride,
@@ -76,7 +78,8 @@ int cvRoundD(double v);
 ResizeTab resizeTab(int srcLen, int dstLen);             // A.2
 void resizeLinear(const Image& src, Image& dst, int dw, int dh);   // cv::resize INTER_LINEAR 8UC1
 int fastScoreV(const uint8_t* p, int pitch);             // A.4: V(p) (may be <= 0)
-void gaussianBlur7(const Image& src, Image& dst);        // A.7
+// A.7; taps4 = {k0, k1, k2, k3} of the symmetric 8.8 fixed-point kernel k0 k1 k2 k3 k2 k1 k0 (nullptr: {18, 34, 49, 55})
+void gaussianBlur7(const Image& src, Image& dst, const int* taps4 = nullptr);
 float fastAtan2(float y, float x);                       // A.5
 
 // ---- matcher ----

@@ -19,6 +19,7 @@ static FeatVec makeFV(const uint32_t* ids, const int32_t* offs, const int32_t* i
 extern "C" {
 
 void* orbref_create(int nf, float sf, int nl, int iniTh, int minTh) { return new Extractor(nf, sf, nl, iniTh, minTh); }
+void orbref_set_gaussian(void* h, const int* taps4) { for (int i = 0; i < 4; i++) static_cast<Extractor*>(h)->gaussTaps[i] = taps4[i]; }
 void orbref_destroy(void* h) { delete (Extractor*)h; }
 
 // returns the number of keypoints (also when it exceeds cap; then nothing is copied)
@@ -126,6 +127,15 @@ void orbref_blur(const uint8_t* src, int w, int h, uint8_t* dst)
     s.w = w; s.h = h;
     s.px.assign(src, src + (size_t)w * h);
     gaussianBlur7(s, d);
+    std::memcpy(dst, d.px.data(), d.px.size());
+}
+
+void orbref_blur_taps(const uint8_t* src, int w, int h, uint8_t* dst, const int* taps4)
+{
+    Image s, d;
+    s.w = w; s.h = h;
+    s.px.assign(src, src + (size_t)w * h);
+    gaussianBlur7(s, d, taps4);
     std::memcpy(dst, d.px.data(), d.px.size());
 }
 

@@ -449,8 +449,10 @@ static inline int reflect101(int i, int n)
     return i;
 }
 
-void gaussianBlur7(const Image& src, Image& dst)
+void gaussianBlur7(const Image& src, Image& dst, const int* taps4)
 {
+    static const int legacy[4] = {18, 34, 49, 55};
+    const int* k = taps4 ? taps4 : legacy;
     // OpenCV 2.4 / 3.0-3.3 8-bit separable path: 8.8 fixed-point taps {18,34,49,55,49,34,18}.
     // Row pass on a REFLECT_101-padded copy of each row, column pass over seven row pointers; the
     // arithmetic (int32 sums, +32768 >> 16, saturate) is unchanged, only the loop structure is CPU-friendly
@@ -468,7 +470,7 @@ void gaussianBlur7(const Image& src, Image& dst)
         int* r = &rowbuf[(size_t)y * w];
         const uint8_t* p = pad.data();
         for (int x = 0; x < w; x++)
-            r[x] = 18 * (p[x] + p[x + 6]) + 34 * (p[x + 1] + p[x + 5]) + 49 * (p[x + 2] + p[x + 4]) + 55 * p[x + 3];
+            r[x] = k[0] * (p[x] + p[x + 6]) + k[1] * (p[x + 1] + p[x + 5]) + k[2] * (p[x + 2] + p[x + 4]) + k[3] * p[x + 3];
     }
     dst.w = w; dst.h = h;
     dst.px.resize((size_t)w * h);
@@ -477,7 +479,7 @@ void gaussianBlur7(const Image& src, Image& dst)
         for (int t = 0; t < 7; t++) r[t] = &rowbuf[(size_t)reflect101(y + t - 3, h) * w];
         uint8_t* d = &dst.px[(size_t)y * w];
         for (int x = 0; x < w; x++) {
-            const int acc = 18 * (r[0][x] + r[6][x]) + 34 * (r[1][x] + r[5][x]) + 49 * (r[2][x] + r[4][x]) + 55 * r[3][x];
+            const int acc = k[0] * (r[0][x] + r[6][x]) + k[1] * (r[1][x] + r[5][x]) + k[2] * (r[2][x] + r[4][x]) + k[3] * r[3][x];
             const int v = (acc + 32768) >> 16;
             d[x] = (uint8_t)(v > 255 ? 255 : v);
         }
@@ -552,7 +554,7 @@ void Extractor::extract(const uint8_t* img, int rows, int cols, size_t stride,
         levelCounts[level] = (int)lk.size();
         if (lk.empty()) continue;
         Image blurred;
-        gaussianBlur7(pyramid[level], blurred);
+        gaussianBlur7(pyramid[level], blurred, gaussTaps);
         for (auto& kp : lk) {
             uint8_t d[32];
             descriptor(blurred, cvRoundF(kp.x), cvRoundF(kp.y), kp.angle, d);

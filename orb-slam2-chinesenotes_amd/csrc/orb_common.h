@@ -73,6 +73,12 @@ struct OrbPyrChain {
     OrbPyrStep st[ORB_PYR_MAXCHAIN];
 };
 
+// the 7-tap Gaussian of the descriptor kernel (k0 k1 k2 k3 k2 k1 k0, 8.8 fixed point) packed as its dot4 / dot2 operands
+struct OrbGaussK {
+    unsigned h0, h1;            // horizontal pass (v_dot4_u32_u8): k0 | k1 << 8 | k2 << 16 | k3 << 24,  k2 | k1 << 8 | k0 << 16
+    unsigned v0, v1, v2, v3;    // vertical pass (v_dot2_u32_u16): k0 | k1 << 16, k2 | k3 << 16, k2 | k1 << 16, k0
+};
+
 // One work item of k_fast_strips: a run of `nc` horizontally adjacent FAST cells of one cell row (reference
 // :826-861: cell (ci, cj) has the ROI [16 + cj*wCell, +wCell+6) x [16 + ci*hCell, +hCell+6), clipped).  The detection
 // zones of adjacent cells (ROI minus cv::FAST's 3-px rim) tile the plane without overlap, so the strip is ONE tile

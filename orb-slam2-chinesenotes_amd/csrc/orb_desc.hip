@@ -57,11 +57,11 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
 }
 
 // 7-tap row blur at the 4 byte positions 4q..4q+3 of a row, from the 12-byte window (d0,d1,d2) =
-// bytes 4q-4 .. 4q+7.  Taps 18,34,49,55,49,34,18 (8.8 fixed point): two dot4 per output.
-__device__ __forceinline__ void hblur4(unsigned d0, unsigned d1, unsigned d2, unsigned out[4])
+// bytes 4q-4 .. 4q+7.  Taps k0 k1 k2 k3 k2 k1 k0 (8.8 fixed point; 18,34,49,55 unless the handle was given
+// another OpenCV version's): two dot4 per output.  K0 = k0 | k1 << 8 | k2 << 16 | k3 << 24 (bytes b-3 .. b),
+// K1 = k2 | k1 << 8 | k0 << 16 (bytes b+1 .. b+3).
+__device__ __forceinline__ void hblur4(unsigned d0, unsigned d1, unsigned d2, unsigned out[4], unsigned K0, unsigned K1)
 {
-    const unsigned K0 = 18u | (34u << 8) | (49u << 16) | (55u << 24);   // bytes b-3 .. b
-    const unsigned K1 = 49u | (34u << 8) | (18u << 16);                 // bytes b+1 .. b+3
     const unsigned lo0 = __builtin_amdgcn_alignbyte(d1, d0, 1), hi0 = __builtin_amdgcn_alignbyte(d2, d1, 1);
     const unsigned lo1 = __builtin_amdgcn_alignbyte(d1, d0, 2), hi1 = __builtin_amdgcn_alignbyte(d2, d1, 2);
     const unsigned lo2 = __builtin_amdgcn_alignbyte(d1, d0, 3), hi2 = __builtin_amdgcn_alignbyte(d2, d1, 3);
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
                                                       orb_keypoint* __restrict__ kpsOut,
                                                       uint8_t* __restrict__ descOut, int cap,
                                                       int32_t* __restrict__ countsOut, int* __restrict__ errFlags,
-                                                      int nFrames, unsigned invPerFrame)
+                                                      int nFrames, unsigned invPerFrame, OrbGaussK gk)
 {
     // ONE LDS region: first the raw patch (2 KB, dword rows with one dword of slack on both sides), later the
     // row-blurred patch H (4 KB, u16) written over it once every lane holds its blur outputs in registers.
@@ -203,8 +203,8 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
             if (items[i] != 0xffffffffu) {
                 const uint32_t* p = Pdw + (items[i] & 0xffffu);
                 unsigned o0[4], o1[4];
-                hblur4(p[0], p[1], p[2], o0);
-                hblur4(p[PDW], p[PDW + 1], p[PDW + 2], o1);
+                hblur4(p[0], p[1], p[2], o0, gk.h0, gk.h1);
+                hblur4(p[PDW], p[PDW + 1], p[PDW + 2], o1, gk.h0, gk.h1);
 #pragma unroll
                 for (int j = 0; j < 4; j++) hv[i][j] = o0[j] | (o1[j] << 16);
             }
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     const unsigned kBias = 0x4B400000u;
     // column index through a 24-bit multiply-add: the low 24 bits of the biased column are 0x400000 + ic
     const unsigned eC = (unsigned)((xoff + PR - 4 * qFirst) * HT_RP + (PR - 3)) - 0x400000u * (unsigned)HT_RP - kBias;
-    const unsigned K0 = 18u | (34u << 16), K1 = 49u | (55u << 16), K2 = 49u | (34u << 16), K3 = 18u;   // taps, two per dot2
+    const unsigned K0 = gk.v0, K1 = gk.v1, K2 = gk.v2, K3 = gk.v3;    // taps, two per dot2: k0 | k1 << 16, k2 | k3 << 16, k2 | k1 << 16, k0
     auto sample = [&](float px, float py) -> int {
         const float fr = __fadd_rn(__fmul_rn(px, b), __fmul_rn(py, a));
         const float fc = __fsub_rn(__fmul_rn(px, a), __fmul_rn(py, b));
@@ -311,14 +311,23 @@ void orb_desc_hblur_table(uint32_t* tab768)
 void orb_launch_orient_desc(hipStream_t st, const OrbGeom& G, const uint8_t* pyr, size_t pyrSlab,
                             const uint32_t* kpl, const int* kpCount, const float* patternF, const uint4* angTab, const uint32_t* hbTab,
                             orb_keypoint* kps, uint8_t* desc, int cap, int32_t* counts, int* errFlags,
-                            int nFrames)
+                            int nFrames, const int* gaussTaps4)
 {
+    static const int legacy[4] = {18, 34, 49, 55};
+    const int* t = gaussTaps4 ? gaussTaps4 : legacy;
+    OrbGaussK gk;                                                  // the taps packed as the kernel's dot4 / dot2 operands
+    gk.h0 = (unsigned)t[0] | ((unsigned)t[1] << 8) | ((unsigned)t[2] << 16) | ((unsigned)t[3] << 24);
+    gk.h1 = (unsigned)t[2] | ((unsigned)t[1] << 8) | ((unsigned)t[0] << 16);
+    gk.v0 = (unsigned)t[0] | ((unsigned)t[1] << 16);
+    gk.v1 = (unsigned)t[2] | ((unsigned)t[3] << 16);
+    gk.v2 = (unsigned)t[2] | ((unsigned)t[1] << 16);
+    gk.v3 = (unsigned)t[0];
     unsigned inv = 0;
     const unsigned wgs = orb_xcd_grid((unsigned)G.kpSlab, nFrames, &inv);
     if (wgs)
         hipLaunchKernelGGL(k_orient_desc, dim3(wgs), dim3(WAVE), 0, st, G, pyr, pyrSlab, kpl, kpCount, reinterpret_cast<const float4*>(patternF), angTab, hbTab, kps,
-                           desc, cap, counts, errFlags, nFrames, inv);
+                           desc, cap, counts, errFlags, nFrames, inv, gk);
     else
         hipLaunchKernelGGL(k_orient_desc, dim3(G.kpSlab, nFrames), dim3(WAVE), 0, st, G, pyr, pyrSlab, kpl, kpCount,
-                           reinterpret_cast<const float4*>(patternF), angTab, hbTab, kps, desc, cap, counts, errFlags, nFrames, 0u);
+                           reinterpret_cast<const float4*>(patternF), angTab, hbTab, kps, desc, cap, counts, errFlags, nFrames, 0u, gk);
 }

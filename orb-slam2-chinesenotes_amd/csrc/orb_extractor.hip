@@ -308,6 +308,30 @@ extern "C" int orb_extractor_set_pattern_device(orb_extractor* h, const int8_t* 
     return ORB_OK;
 }
 
+extern "C" int orb_gaussian_preset(int preset, int32_t* taps4)
+{
+    if (!taps4) return ORB_ERR_INVALID;
+    static const int32_t legacy[4] = {18, 34, 49, 55}, ed[4] = {18, 34, 48, 56};
+    if (preset != ORB_GAUSS_OPENCV_LEGACY && preset != ORB_GAUSS_OPENCV_FIXEDPOINT_ED) return ORB_ERR_INVALID;
+    std::memcpy(taps4, preset == ORB_GAUSS_OPENCV_LEGACY ? legacy : ed, sizeof(legacy));
+    return ORB_OK;
+}
+
+extern "C" int orb_extractor_set_gaussian(orb_extractor* h, const int32_t* taps4)
+{
+    if (!h || !taps4) return ORB_ERR_INVALID;
+    const int sum = 2 * (taps4[0] + taps4[1] + taps4[2]) + taps4[3];
+    for (int i = 0; i < 4; i++)
+        if (taps4[i] < 0 || taps4[i] > 255) { orb_set_error("Gaussian taps must be 8.8 fixed-point values in 0..255"); return ORB_ERR_UNSUPPORTED; }
+    // the row pass keeps its sums in 16 bits (255 * 257 = 65535 is the largest that fits: OpenCV's own 8.8 kernels sum to 256 or 257)
+    if (sum < 1 || sum > 257) { orb_set_error("Gaussian taps sum to %d: the row pass holds 255 * sum in 16 bits (sum <= 257)", sum); return ORB_ERR_UNSUPPORTED; }
+    ORB_HIP_TRY(hipSetDevice(h->device));
+    ORB_HIP_TRY(hipStreamSynchronize(h->stream));
+    for (int i = 0; i < 4; i++) h->gaussTaps[i] = taps4[i];
+    h->geomVersion++;                                  // (a captured single-frame graph baked the old taps in: re-capture)
+    return ORB_OK;
+}
+
 extern "C" int orb_extractor_set_profiling(orb_extractor* h, int enable)
 {
     if (!h) return ORB_ERR_INVALID;
@@ -471,7 +495,7 @@ extern "C" int orb_extract_batch_device(orb_extractor* h, const uint8_t* d_imgs,
                         h->qtGlobal ? (unsigned char*)h->dQt.p : nullptr);
     if (prof) ORB_HIP_TRY(hipEventRecord(pe[3], st));
     orb_launch_orient_desc(st, G, pyr, h->pyrSlab, skpl, skc, (const float*)h->dPatternF.p, (const uint4*)h->dAngTab.p, (const uint32_t*)((const uint8_t*)h->dAngTab.p + 16 * 2 * 32), d_kps, d_desc, cap,
-                           d_counts, serr, n);
+                           d_counts, serr, n, h->gaussTaps);
     if (prof) {
         ORB_HIP_TRY(hipEventRecord(pe[4], st));
         h->profCount++;

@@ -42,6 +42,7 @@ struct orb_extractor {
     std::vector<float> scale, invScale, sigma2, invSigma2;
     std::vector<int> quota;
     int umax[16];
+    int gaussTaps[4] = {18, 34, 49, 55};    // orb_extractor_set_gaussian
     OrbHostTables tables;                   // the same, as orb_geometry_host.h computes them
 
     // geometry for the current image size

@@ -27,5 +27,5 @@ size_t orb_quadtree_scratch_stride(int nodeCap);
 void orb_launch_orient_desc(hipStream_t st, const OrbGeom& G, const uint8_t* pyr, size_t pyrSlab,
                             const uint32_t* kpl, const int* kpCount, const float* patternF, const uint4* angTab, const uint32_t* hbTab,
                             orb_keypoint* kps, uint8_t* desc, int cap, int32_t* counts, int* errFlags,
-                            int nFrames);
+                            int nFrames, const int* gaussTaps4 = nullptr);
 void orb_desc_hblur_table(uint32_t* tab768);

@@ -18,6 +18,8 @@ static_assert(sizeof(cv::KeyPoint) == sizeof(orb_keypoint), "cv::KeyPoint must b
 
 static int gDefaultDevice = -1;
 void ORBextractor::SetDefaultDevice(int device) { gDefaultDevice = device; }
+static int gGaussPreset = -1;
+void ORBextractor::SetGaussianPreset(int preset) { gGaussPreset = preset; }
 static int defaultDevice()
 {
     if (gDefaultDevice >= 0) return gDefaultDevice;
@@ -42,6 +44,15 @@ ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int
     p.ini_th_fast = _iniThFAST;
     p.min_th_fast = _minThFAST;
     orbCheck(orb_extractor_create(&p, defaultDevice(), &mpHandle), "orb_extractor_create");
+    {
+        const char* e = std::getenv("ORB_HIP_GAUSS");
+        const int preset = gGaussPreset >= 0 ? gGaussPreset : (e ? std::atoi(e) : 0);
+        if (preset != 0) {
+            int32_t taps[4];
+            orbCheck(orb_gaussian_preset(preset, taps), "orb_gaussian_preset");
+            orbCheck(orb_extractor_set_gaussian(mpHandle, taps), "orb_extractor_set_gaussian");
+        }
+    }
     mvScaleFactor.resize(nlevels);
     mvInvScaleFactor.resize(nlevels);
     mvLevelSigma2.resize(nlevels);

@@ -46,6 +46,10 @@ public:
     // GPU that extractors constructed from now on live on (the constructor signature is the reference's and has no
     // room for it); also read from the environment variable ORB_HIP_DEVICE.  Default 0.
     static void SetDefaultDevice(int device);
+    // Additional: which OpenCV generation's integer Gaussian the descriptors are blurred with (orb_gaussian_preset in orb_hip.h:
+    // 0 = {18,34,49,55}, OpenCV 2.4 ... the first fixed-point versions; 1 = {18,34,48,56}, the error-diffused fixed-point kernel of
+    // later 3.4.x / 4.x).  Applies to extractors constructed afterwards; also read from ORB_HIP_GAUSS.  Default 0.
+    static void SetGaussianPreset(int preset);
 
 protected:
     int nfeatures;

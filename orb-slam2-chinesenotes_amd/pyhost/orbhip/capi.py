@@ -65,7 +65,7 @@ SYMBOLS = [
     "orb_hamming", "orb_three_maxima", "orb_matcher_create", "orb_matcher_destroy", "orb_matcher_sync",
     "orb_match_bow", "orb_match_bow_kk", "orb_match_init", "orb_match_projection", "orb_match_projection_best", "orb_match_triangulation", "orb_vocab_create", "orb_vocab_destroy", "orb_vocab_level_nodes", "orb_bow_transform",
     "orb_bow_transform_device", "orb_distinctive_descriptors", "orb_distinctive_descriptors_device", "orb_bow_assign_device", "orb_match_bow_batch_device", "orb_bow_build_csr_device",
-    "orb_bow_build_csr_desc_device", "orb_match_bow_query_device", "orb_matcher_set_stage_stamps",
+    "orb_bow_build_csr_desc_device", "orb_match_bow_query_device", "orb_matcher_set_stage_stamps", "orb_gaussian_preset", "orb_extractor_set_gaussian",
     "orb_matcher_stream", "orb_stereo_match", "orb_stereo_match_device", "orb_stereo_match_batch_device", "orb_extractor_wait_for", "orb_matcher_wait_for", "orb_last_error", "orb_version", "orb_abi_version", "orb_sizeof_featstore", "orb_multi_create", "orb_multi_destroy", "orb_multi_devices", "orb_multi_handle",
     "orb_multi_set_pattern", "orb_multi_extract_batch", "orb_shard_range", "orb_multi_db_create", "orb_multi_db_destroy",
     "orb_multi_db_shards", "orb_multi_match_bow_batch",
@@ -90,6 +90,8 @@ def lib():
     L.orb_extractor_get_tables.argtypes = [vp] * 6
     L.orb_extractor_max_keypoints.argtypes = [vp]
     L.orb_extractor_set_pattern.argtypes = [vp, vp]
+    L.orb_gaussian_preset.argtypes = [ci, vp]
+    L.orb_extractor_set_gaussian.argtypes = [vp, vp]
     L.orb_extractor_set_pattern_device.argtypes = [vp, vp]
     L.orb_builtin_pattern.argtypes = [vp]
     L.orb_extract.argtypes = [vp, vp, ci, ci, sz, vp, vp, ci, C.POINTER(ci)]
@@ -223,6 +225,16 @@ class Extractor:
         quota = np.zeros(n, np.int32)
         _check(self.L.orb_extractor_get_tables(self.h, _p(sc), _p(inv), _p(s2), _p(is2), _p(quota)))
         return dict(scale=sc, inv_scale=inv, sigma2=s2, inv_sigma2=is2, quota=quota)
+
+    def set_gaussian(self, taps4_or_preset):
+        """an int = one of the presets (0 legacy {18,34,49,55}, 1 error-diffused {18,34,48,56}); else the four taps k0..k3"""
+        t = np.zeros(4, np.int32)
+        if np.isscalar(taps4_or_preset):
+            _check(self.L.orb_gaussian_preset(int(taps4_or_preset), _p(t)))
+        else:
+            t[:] = taps4_or_preset
+        _check(self.L.orb_extractor_set_gaussian(self.h, _p(t)))
+        return t
 
     def set_pattern(self, pattern):
         pattern = np.ascontiguousarray(pattern, np.int8)

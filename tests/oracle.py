@@ -52,6 +52,8 @@ def lib():
         L.orbref_resize.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
         L.orbref_resize_tab.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orbref_blur.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.orbref_blur_taps.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.orbref_set_gaussian.argtypes = [C.c_void_p, C.c_void_p]
         L.orbref_fast_vmap.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.orbref_fast_atan2.restype = C.c_float
         L.orbref_fast_atan2.argtypes = [C.c_float, C.c_float]
@@ -119,6 +121,12 @@ class Extractor:
         if getattr(self, "h", None):
             self.L.orbref_destroy(self.h)
             self.h = None
+
+    def set_gaussian(self, taps4):
+        """taps k0..k3 of the symmetric 8.8 fixed-point 7-tap kernel: OpenCV-version dependent"""
+        t = np.ascontiguousarray(taps4, np.int32)
+        assert t.shape == (4,)
+        self.L.orbref_set_gaussian(self.h, _p(t))
 
     def tables(self):
         n = self.nlevels
@@ -193,10 +201,14 @@ def resize_tab(src_len, dst_len):
     return ofs, c0, c1
 
 
-def blur(src):
+def blur(src, taps4=None):
     src = np.ascontiguousarray(src, dtype=np.uint8)
     dst = np.zeros_like(src)
-    lib().orbref_blur(_p(src), src.shape[1], src.shape[0], _p(dst))
+    if taps4 is None:
+        lib().orbref_blur(_p(src), src.shape[1], src.shape[0], _p(dst))
+    else:
+        t = np.ascontiguousarray(taps4, np.int32)
+        lib().orbref_blur_taps(_p(src), src.shape[1], src.shape[0], _p(dst), _p(t))
     return dst
 
 

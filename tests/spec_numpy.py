@@ -52,11 +52,13 @@ def resize(src, dw, dh):
 TAPS = np.array([18, 34, 49, 55, 49, 34, 18], np.int64)
 
 
-def blur(src):
+def blur(src, taps4=None):
+    """taps4 = (k0, k1, k2, k3) of another OpenCV version's integer kernel (A.7's closing remark); default: TAPS"""
+    T = TAPS if taps4 is None else np.array(list(taps4) + list(taps4[2::-1]), np.int64)
     S = np.pad(np.asarray(src, np.uint8).astype(np.int64), 3, mode="reflect")     # numpy 'reflect' == BORDER_REFLECT_101
     h, w = src.shape
-    R = sum(TAPS[i] * S[:, i:i + w] for i in range(7))                             # rows (padded rows included)
-    D = sum(TAPS[j] * R[j:j + h, :] for j in range(7))
+    R = sum(T[i] * S[:, i:i + w] for i in range(7))                                # rows (padded rows included)
+    D = sum(T[j] * R[j:j + h, :] for j in range(7))
     return np.clip((D + 32768) >> 16, 0, 255).astype(np.uint8)
 
 

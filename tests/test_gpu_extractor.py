@@ -8,9 +8,11 @@ from orbhip import capi, synth
 pytestmark = pytest.mark.gpu
 
 
-def _cmp(img, nfeatures=1000, levels=8, ini=20, mn=7, sf=1.2):
+def _cmp(img, nfeatures=1000, levels=8, ini=20, mn=7, sf=1.2, gauss=None):
     ex = capi.Extractor(nfeatures, sf, levels, ini, mn)
     ref = oracle.Extractor(nfeatures, sf, levels, ini, mn)
+    if gauss is not None:                                          # another OpenCV version's integer Gaussian (orb_gaussian_preset)
+        ref.set_gaussian(ex.set_gaussian(gauss))
     kps, desc = ex.extract(img)
     rk, rd = ref.extract(img)
     # stage by stage first, so a failure names the stage
@@ -27,6 +29,34 @@ def _cmp(img, nfeatures=1000, levels=8, ini=20, mn=7, sf=1.2):
     assert np.array_equal(desc, rd), "descriptors"
     ex.close()
     return len(kps)
+
+
+@pytest.mark.parametrize("preset", [0, 1])
+def test_gaussian_presets_of_both_opencv_generations(preset):
+    """cv::GaussianBlur's integer taps depend on the OpenCV version (include/orb_hip.h: orb_gaussian_preset): both presets,
+    end to end against the oracle with the same taps; single frames (graph replay picks the new taps up), a device batch, and
+    the two presets do give different descriptors."""
+    frames = [synth.synth_frame(70 + i, 640, 480) for i in range(3)] + [synth.synth_natural(5, 752, 480)]
+    for im in frames:
+        assert _cmp(im, gauss=preset) > 900
+    ex, ref = capi.Extractor(), oracle.Extractor()
+    base = [ex.extract(frames[0]) for _ in range(3)][-1]           # (third call: the captured graph, default taps)
+    taps = ex.set_gaussian(preset)
+    ref.set_gaussian(taps)
+    assert taps.tolist() == ([18, 34, 49, 55] if preset == 0 else [18, 34, 48, 56])
+    for _ in range(3):
+        kps, desc = ex.extract(frames[0])
+        rk, rd = ref.extract(frames[0])
+        assert kps.tobytes() == rk.tobytes() and np.array_equal(desc, rd)
+    assert kps.tobytes() == base[0].tobytes()                      # the blur touches descriptors only
+    assert (preset == 0) == np.array_equal(desc, base[1])
+    batch = np.stack(frames[:3])
+    for f, (kb, db) in enumerate(ex.extract_batch(batch)):
+        rk, rd = ref.extract(batch[f])
+        assert kb.tobytes() == rk.tobytes() and np.array_equal(db, rd)
+    with pytest.raises(capi.OrbError):
+        ex.set_gaussian([30, 40, 50, 60])                          # sums to 300: the 16-bit row sums would overflow
+    ex.close()
 
 
 def test_tables_match_oracle():
