@@ -39,7 +39,7 @@ public:
     size_t step;                                  // bytes per row
     Mat() : rows(0), cols(0), data(nullptr), step(0), type_(CV_8U) {}
     Mat(int r, int c, int type) : rows(0), cols(0), data(nullptr), step(0), type_(CV_8U) { create(r, c, type); }
-    Mat(int r, int c, int type, void* ext, size_t st) : rows(r), cols(c), data((unsigned char*)ext), step(st), type_(type) {}
+    Mat(int r, int c, int type, void* ext, size_t st = 0) : rows(r), cols(c), data((unsigned char*)ext), step(st ? st : (size_t)c * esz(type)), type_(type) {}   // (0 = AUTO_STEP)
     static size_t esz(int type) { return type == CV_32F ? 4 : 1; }
     void create(int r, int c, int type)
     {
