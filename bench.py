@@ -94,11 +94,12 @@ def parse():
     ap.add_argument("--content", default="shapes", choices=["shapes", "natural"],
                     help="synthetic frame content: drawn rectangles + discs + noise (SURVEY 8d, default) or natural image statistics "
                          "(1/f texture, occluding objects, blur, illumination ramp: orbhip.synth.synth_natural)")
-    ap.add_argument("--c3-one-handle", action="store_true",
-                    help="config c3: ONE batch of 2 S frames (left views, then right views) through one extractor handle instead of two "
-                         "handles on two streams (the default, the shape of the reference's two threads, src/Frame.cc:82-85; measured: "
-                         "156 k frames/s with two handles, 144 k with one -- the two chains overlap each other's latency-bound kernels)")
+    ap.add_argument("--c3-two-handles", action="store_true",
+                    help="config c3: left and right images through two extractor handles on two streams (the reference's two "
+                         "ORBextractor objects, src/Frame.cc:82-85) instead of ONE 64-frame batch [L0..L31, R0..R31] through one "
+                         "handle (the default since round 4: 207 k against 190 k frames/s)")
     ap.add_argument("--c5-pair-kernel", action="store_true", help="config 5: SearchByBoW with the pair kernel (one workgroup per (keyframe, frame) pair) instead of the query form")
+    ap.add_argument("--c5-no-minibatch", action="store_true", help="config 5: skip the mini-batch variant (the counter passes: every search launch is one query)")
     ap.add_argument("--c5-extractors", type=int, default=2, help="config 5: extractor handles that consecutive stream frames alternate between")
     ap.add_argument("--c5-matchers", type=int, default=1, help="config 5: matcher handles that consecutive stream frames alternate between")
     ap.add_argument("--c5-slots", type=int, default=4, help="config 5: query slots in the ring between the extractor and the matcher stream")
@@ -111,6 +112,8 @@ def parse():
     ap.add_argument("--no-cpu-all-cores", action="store_true")
     ap.add_argument("--no-live-traffic", action="store_true", help="do not measure roofline.traffic live (two rocprofv3 --pmc child "
                     "runs of a 3-step bench); use the committed profiles/pmc_traffic.json instead")
+    ap.add_argument("--no-natural", action="store_true", help="skip config.natural_content_fps (a child run of the same workload on "
+                    "natural-statistics content)")
     ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive host_in_host_out_fps measurement "
                     "(profiling runs: keeps every kernel launch at the benchmark's batch size)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) or gloo (CPU rehearsal of the N>1 path)")
@@ -127,7 +130,7 @@ def load_profile(name):
         return None
 
 
-def live_counters(kernel, launch_frames, content="shapes"):
+def live_counters(kernel, launch_frames, content="shapes", child_args=None):
     """Counters of `kernel` per launch, measured NOW: three child runs of this script under `rocprofv3 --pmc` (FETCH_SIZE and
     WRITE_SIZE need separate passes, the SQ counters a third; counter passes carry --kernel-trace only), 3 steps each,
     parsed like tools/pmc_summary.py (full-batch launches only; FETCH x2, profiles/r02_fetch_calibration.json).
@@ -154,8 +157,10 @@ def live_counters(kernel, launch_frames, content="shapes"):
         for tag, ctrs in passes.items():
             out = os.path.join(tmp, tag)
             cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + ctrs + ["--output-format", "csv", "-d", out, "-o", "run", "--",
-                   sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--pipeline", "1", "--no-cpu-baseline",
-                   "--no-host-path", "--no-live-traffic", "--frames-per-gpu", str(launch_frames), "--content", content]
+                   sys.executable, os.path.abspath(__file__)]
+            cmd += child_args if child_args is not None else ["--steps", "3", "--warmup", "1", "--pipeline", "1", "--no-cpu-baseline",
+                                                              "--no-host-path", "--no-live-traffic", "--no-natural", "--frames-per-gpu", str(launch_frames),
+                                                              "--content", content]
             r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
             if r.returncode != 0:
                 continue
@@ -511,6 +516,21 @@ def run_c4(args, rank, local_rank, world, dev, comm_dev, dist):
         out["config"]["other_scaling"] = other
     if rv:
         out["roofline_valu"] = rv
+    # the same workload on natural-statistics content (what TUM / KITTI / EuRoC frames look like to the FAST kernel: more pixels
+    # survive its cheap rejection than on the drawn shapes), measured by a child run outside this run's timed region
+    if world == 1 and args.content == "shapes" and not args.no_natural:
+        try:
+            cmd = [sys.executable, os.path.abspath(__file__), "--content", "natural", "--no-natural", "--no-cpu-baseline", "--no-host-path",
+                   "--no-live-traffic", "--steps", str(max(10, min(args.steps, 60))), "--warmup", "5", "--frames-per-gpu", str(args.frames_per_gpu),
+                   "--width", str(W), "--height", str(H), "--nfeatures", str(args.nfeatures)]
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode == 0 and line:
+                nat = json.loads(line[-1])
+                out["config"]["natural_content_fps"] = nat["value"]
+                out["config"]["natural_content_stage_ms_single_lane"] = nat["config"]["stage_ms_per_launch_single_lane"]
+        except Exception:
+            pass
     if world == 1 and not args.no_cpu_baseline:
         cb = cpu_baseline_c4(args, frames_sets[ln0["set"]], first, ln0, counts, cap, nm, tree, valid_np)
         cb["gpu_over_cpu_port"] = {"extract_plus_match": round(fps / cb["value"], 1),
@@ -612,13 +632,15 @@ def run_c3(args, rank, local_rank, world, dev, comm_dev, dist):
     rights = np.stack([synth.synth_stereo_right(100 + base + i, W, H) for i in range(S)])
     d_l, d_r = torch.from_numpy(lefts).to(dev), torch.from_numpy(rights).to(dev)
     buf = lambda n, dt: torch.zeros(n, dtype=dt, device=dev)
-    one = args.c3_one_handle
+    one = not args.c3_two_handles
     d_lr = torch.cat([d_l, d_r]) if one else None
     # Lanes: independent (left handle, right handle, output buffers) sets that consecutive steps alternate between, as in
     # config c4.  Inside a lane everything is ordered (the stereo search of a step reads the right handle's pyramid and
     # keypoints, so the library orders the right handle's next extraction behind it); the search of one lane runs beside
     # the extractions of the other.
-    n_lanes = args.pipeline if args.pipeline > 0 else 3          # (measured 1 / 2 / 3 / 4 / 6 lanes: 174 / 181 / 192 / 187 / 189 k frames/s)
+    # (two handles per lane, measured 1 / 2 / 3 / 4 / 6 lanes: 174 / 181 / 192 / 187 / 189 k frames/s; one handle per lane, round 4:
+    # 2 / 3 / 4 lanes 207 / 201 / 190 k)
+    n_lanes = args.pipeline if args.pipeline > 0 else (2 if one else 3)
 
     def make_lane():
         ln = {"exl": capi.Extractor(nf, device=local_rank)}
@@ -684,6 +706,13 @@ def run_c3(args, rank, local_rank, world, dev, comm_dev, dist):
     nl, nr = cl.cpu().numpy(), cr.cpu().numpy()
     if rank != 0:
         return None
+    # content statistics of the last synchronised batch, per handle: FAST strips that overflowed their candidate queue (redone by
+    # k_fast_strips_dense: same results, more time), strips per frame, candidates per level of frame 0
+    content = {}
+    for side, e in (("left", exl), ("right", exr)):
+        ovf, spf = e.fast_overflows()
+        content[side] = {"fast_strips_overflowed_per_level": [int(v) for v in ovf], "fast_strips_per_frame_per_level": [int(v) for v in spf],
+                         "fast_candidates_per_level_frame0": [int(v) for v in e.level_counts(0)[1]]}
     pyr_px = sum(int(exl.pyramid_level(0, l).size) for l in range(8))
     u = ur.cpu().numpy().reshape(S, cap)
     z = dp.cpu().numpy().reshape(S, cap)
@@ -704,7 +733,8 @@ def run_c3(args, rank, local_rank, world, dev, comm_dev, dist):
                       "lanes": n_lanes, "pairs_per_step": S, "pairs_per_s": round(pairs / elapsed, 2),
                       "ms_per_pair": round(elapsed / (pairs / world) * 1e3, 4), "mean_keypoints_left": round(mean_kp, 1),
                       "mean_stereo_matches": round(float((u[:, :] >= 0).sum() / S), 1),
-                      "stage_ms_per_launch_left_handle": {n: round(float(v), 4) for n, v in zip(STAGES + ["extract_total"], stage_ms)}},
+                      "stage_ms_per_launch_left_handle": {n: round(float(v), 4) for n, v in zip(STAGES + ["extract_total"], stage_ms)},
+                      "content_stats": content},
            "roofline": rf}
     if rv:
         out["roofline_valu"] = rv
@@ -803,7 +833,7 @@ def run_c5(args, rank, local_rank, world, dev, comm_dev, dist):
     mts = [mt] + [capi.Matcher(0.7, True, device=local_rank) for _ in range(max(1, args.c5_matchers) - 1)]
     NMT = len(mts)
 
-    def match(i):
+    def match(i, between=None):
         s, q = i % NSLOT, Q[0]
         f0 = n_kf + s * QMAX
         mt = mts[i % NMT]
@@ -812,6 +842,8 @@ def run_c5(args, rank, local_rank, world, dev, comm_dev, dist):
         mt.build_csr_desc_device(d_node.data_ptr() + f0 * cap * 2, d_counts.data_ptr() + f0 * 4, d_desc.data_ptr() + f0 * cap * 32, q, cap,
                                  n_nodes, d_ckeys.data_ptr() + f0 * cap * 4, d_cstart.data_ptr() + f0 * n_nodes * 2,
                                  d_ccnt.data_ptr() + f0 * n_nodes * 2, d_cdesc.data_ptr() + f0 * cap * 32)
+        if between is not None:
+            between()
         if args.c5_pair_kernel:                    # round 3's form: one workgroup per (keyframe, frame) pair
             mt.match_bow_batch_device(store, kf_pairs.data_ptr(), f_pairs[s].data_ptr(), q * n_kf, d_match[s].data_ptr(), d_nm[s].data_ptr())
         else:                                      # one query against many keyframes (csrc/orb_matcher_query.hip)
@@ -853,30 +885,51 @@ def run_c5(args, rank, local_rank, world, dev, comm_dev, dist):
     elapsed = shard.max_over_ranks(dist, time.perf_counter() - t0, comm_dev)
     done = shard.sum_over_ranks(dist, args.steps, comm_dev)
     # the same stream in mini-batches of QMAX frames per step (offline sequence processing): throughput, not `value`
-    Q[0] = QMAX
-    run(3)
-    [e.sync() for e in exs]; [m.sync() for m in mts]; torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    n_mb = max(10, args.steps // QMAX)
-    run(n_mb)
-    [e.sync() for e in exs]; [m.sync() for m in mts]; torch.cuda.synchronize()
-    mini_fps = n_mb * QMAX / (time.perf_counter() - t1)
-    Q[0] = 1
-    # non-overlapped match duration (the dominant kernel of this configuration is k_match_bow over 1000 pairs)
-    t_m = []
-    for i in range(4):
+    mini_fps = 0.0
+    if not args.c5_no_minibatch:
+        Q[0] = QMAX
+        run(3)
+        [e.sync() for e in exs]; [m.sync() for m in mts]; torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        n_mb = max(10, args.steps // QMAX)
+        run(n_mb)
+        [e.sync() for e in exs]; [m.sync() for m in mts]; torch.cuda.synchronize()
+        mini_fps = n_mb * QMAX / (time.perf_counter() - t1)
+        Q[0] = 1
+    # non-overlapped durations: descent + feature vector + search as the host sees them, and the search kernel alone by HIP
+    # events on the matcher's own stream (the dominant kernel of this configuration: k_match_bow_query over 1000 keyframes)
+    t_m, t_k = [], []
+    N_ALONE = 12
+    for i in range(N_ALONE):
         exs[i % NEX].wait_for(mts[i % NMT].stream); extract(i); exs[i % NEX].sync()
-        t1 = time.perf_counter(); match(i); mts[i % NMT].sync(); t_m.append(time.perf_counter() - t1)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t1 = time.perf_counter(); match(i, between=lambda: e0.record(mt_ss[i % NMT])); e1.record(mt_ss[i % NMT]); mts[i % NMT].sync()
+        t_m.append(time.perf_counter() - t1)
+        t_k.append(e0.elapsed_time(e1))
     match_ms = statistics.median(t_m) * 1e3
+    kernel_ms = statistics.median(t_k[4:])
     if rank != 0:
         return None
-    last, last_q = 3 % NSLOT, 3 % n_q              # slot / stream frame of the last match above (i = 3)
+    last, last_q = (N_ALONE - 1) % NSLOT, (N_ALONE - 1) % n_q      # slot / stream frame of the last match above
     fq = n_kf + last * QMAX                        # store index of that stream frame
     nm = d_nm[last][:n_kf].cpu().numpy()
     cnts = d_counts.cpu().numpy()
     n1 = float(cnts[:n_kf].mean())
     bytes_query = n_kf * (n1 * (32 + 4 + 1 + 4) + 8 * n_nodes + 4 * float(cnts[fq]))     # B_bow per pair
-    ach = bytes_query / (match_ms * 1e-3) / 1e9
+    ach = bytes_query / (kernel_ms * 1e-3) / 1e9
+    kern = "k_match_bow_store" if args.c5_pair_kernel else "k_match_bow_query"
+    traffic, traffic_src, valu = None, None, None
+    if world == 1 and not args.no_live_traffic:
+        lc = live_counters(kern, 1, child_args=["--config", "c5", "--steps", "24", "--warmup", "4", "--no-cpu-baseline", "--no-live-traffic",
+                                                "--c5-no-minibatch"] + (["--c5-pair-kernel"] if args.c5_pair_kernel else []))
+        traffic, valu = lc["traffic"], lc["valu"]
+        if traffic is not None:
+            traffic_src = "measured in this run: child runs of bench.py --config c5 (24 steps) under rocprofv3 --pmc FETCH_SIZE / --pmc " \
+                          "WRITE_SIZE, per launch of the search kernel; FETCH x2 (profiles/r02_fetch_calibration.json)"
+    if traffic is None:
+        tr = load_profile("c5_pmc_traffic.json")
+        if tr and kern in tr.get("bytes_per_launch", {}):
+            traffic, traffic_src = int(tr["bytes_per_launch"][kern]), "profiles/c5_pmc_traffic.json"
     out = {"metric": "frames/sec ORB extract + SearchByBoW vs 1000-keyframe DB, 752x480 8-level 1000-feat; HBM GB/s vs peak",
            "value": round(done / elapsed, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -889,11 +942,13 @@ def run_c5(args, rank, local_rank, world, dev, comm_dev, dist):
                       "frames_per_s_in_mini_batches_of_%d" % QMAX: round(mini_fps, 1),
                       "transform_plus_match_ms_alone": round(match_ms, 4),
                       "host_submit_ms_per_step": round(t_submit / args.steps * 1e3, 4)},
-           "roofline": {"bound": "hbm", "kernel": "k_match_bow (+ k_vocab_transform of the query)", "achieved": round(ach, 2),
-                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
-                        "algorithmic_bytes_per_query": int(bytes_query), "kernel_ms_per_launch": round(match_ms, 4),
-                        "binding": "vector-instruction issue in the per-node matching loop (51 % VALU-busy over the whole kernel, ~1900 "
-                                   "instructions per wave; profiles/r02_valu.json), not HBM"}}
+           "roofline": {"bound": "hbm", "kernel": kern, "achieved": round(ach, 2),
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+                        "traffic_source": traffic_src, "algorithmic_bytes_per_query": int(bytes_query),
+                        "kernel_ms_per_launch": round(kernel_ms, 4), "counters": valu,
+                        "binding": "latency: a workgroup's keyframe pair is a chain of barrier-separated stages (staging, phase 1 at the "
+                                   "issue rate of 21 instructions per 64 distances, the per-node replay, histogram, write-out; "
+                                   "tools/qk_stamps.py), one 16-wave workgroup per CU -- not HBM"}}
     if world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle

@@ -42,6 +42,8 @@ def test_single_gpu_line_has_every_contract_field():
     assert len(cs["fast_candidates_per_level"]) == 8 and 0 < cs["phase_a_surviving_pair_rate"] < 1
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["gpu_matches_oracle_on_sample"] is True
+    # the same workload on natural-statistics content, next to `value`: a child run outside the timed region
+    assert d["config"]["natural_content_fps"] > 0 and "k_fast_strips_p" in d["config"]["natural_content_stage_ms_single_lane"]
 
 
 @pytest.mark.parametrize("cfg,steps", [("c3", "2"), ("c5", "6")])
@@ -52,6 +54,13 @@ def test_other_baseline_configs_print_the_contract_line_with_parity(cfg, steps):
     d = _last_json(r.stdout)
     assert d["value"] > 0 and d["unit"] == "frames/s" and d["roofline"]["bound"] == "hbm"
     assert d["cpu_baseline"]["gpu_matches_oracle_on_sample"] is True
+    if cfg == "c5":          # the search kernel's HBM-side traffic is measured live (a non-null roofline.traffic for c5)
+        rf = d["roofline"]
+        assert rf["kernel"] == "k_match_bow_query" and rf["traffic"] is not None and rf["traffic"] > 0
+        assert "measured in this run" in rf["traffic_source"] and rf["kernel_ms_per_launch"] > 0
+        assert d["config"]["extractor_handles"] == 2
+    else:
+        assert len(d["config"]["content_stats"]["left"]["fast_strips_overflowed_per_level"]) == 8
 
 
 def _two_ranks(extra):
