@@ -461,7 +461,9 @@ extern "C" int orb_extract_batch_device(orb_extractor* h, const uint8_t* d_imgs,
         // ORB_PYR_SET=batch|few|one pins the variant (tests: every variant on the same frames)
         const char* pin = std::getenv("ORB_PYR_SET");
         const int which = pin ? (pin[0] == 'b' ? 0 : pin[0] == 'f' ? 1 : 2)
-                          : n <= oneMax ? 2 : (long long)h->pyrChains[0].bands * n < 2560 ? 1 : 0;
+                          : n <= oneMax ? 2 : 0;     // (round 4, on the round-3 chains: the 4-row-band set no longer wins anywhere --
+                                                     //  16 / 32 frames: one 0.032 / 0.043 ms, few 0.035 / 0.047, batch 0.042 / 0.046;
+                                                     //  40 / 64 / 96 frames: batch 0.049 / 0.061 / 0.071, few 0.051 / 0.069 / 0.093)
         const std::vector<OrbPyrChain>& chains = which == 2 ? h->pyrChainsOne : which == 1 ? h->pyrChainsLat : h->pyrChains;
         for (size_t c = 0; c < chains.size(); c++)
             orb_launch_pyr_chain(st, chains[c], d_imgs, rowStride, frameStride, pyr, h->pyrSlab, (const uint4*)h->dXq.p,
