@@ -100,6 +100,8 @@ def parse():
                          "handle (the default since round 4: 207 k against 190 k frames/s)")
     ap.add_argument("--c5-pair-kernel", action="store_true", help="config 5: SearchByBoW with the pair kernel (one workgroup per (keyframe, frame) pair) instead of the query form")
     ap.add_argument("--c5-no-minibatch", action="store_true", help="config 5: skip the mini-batch variant (the counter passes: every search launch is one query)")
+    ap.add_argument("--c5-bow-early", action="store_true", help="config 5: vocabulary descent + feature vector of a frame behind its extraction "
+                    "(own handle per extractor) instead of in front of its search (measured slower)")
     ap.add_argument("--c5-extractors", type=int, default=2, help="config 5: extractor handles that consecutive stream frames alternate between")
     ap.add_argument("--c5-matchers", type=int, default=1, help="config 5: matcher handles that consecutive stream frames alternate between")
     ap.add_argument("--c5-slots", type=int, default=4, help="config 5: query slots in the ring between the extractor and the matcher stream")
@@ -823,11 +825,28 @@ def run_c5(args, rank, local_rank, world, dev, comm_dev, dist):
     exs = [ex] + [capi.Extractor(args.nfeatures, device=local_rank) for _ in range(max(1, args.c5_extractors) - 1)]
     NEX = len(exs)
 
+    # Frame::ComputeBoW (descent 7 us + feature vector 6 us) runs in front of the frame's search on the searching stream.
+    # --c5-bow-early moves it behind the frame's extraction, onto a matcher handle of its own per extractor (ordered behind that
+    # extractor's stream), so that the searching stream carries nothing but the 1000 matchings -- measured: 0.0947 against
+    # 0.0841 ms per frame, the extra cross-stream wait costs more than the 13 us it takes off the searching stream
+    bow_early = args.c5_bow_early
+    mbs = [capi.Matcher(0.7, True, device=local_rank) for _ in exs] if bow_early else []
+
+    def compute_bow(m, f0, q):
+        voc.transform_device(m, d_desc.data_ptr() + f0 * cap * 32, d_counts.data_ptr() + f0 * 4, q, cap, 4,
+                             d_node_of=d_node.data_ptr() + f0 * cap * 2)
+        m.build_csr_desc_device(d_node.data_ptr() + f0 * cap * 2, d_counts.data_ptr() + f0 * 4, d_desc.data_ptr() + f0 * cap * 32, q, cap,
+                                n_nodes, d_ckeys.data_ptr() + f0 * cap * 4, d_cstart.data_ptr() + f0 * n_nodes * 2,
+                                d_ccnt.data_ptr() + f0 * n_nodes * 2, d_cdesc.data_ptr() + f0 * cap * 32)
+
     def extract(i):                                # stream frames i*Q .. i*Q+Q-1 -> query slot i % NSLOT
         s, q = i % NSLOT, Q[0]
         f0 = n_kf + s * QMAX
         exs[i % NEX].extract_batch_device(stream.data_ptr() + ((i * q) % (n_q - q + 1)) * W * H, q, H, W, W, W * H, d_kps.data_ptr() + f0 * cap * 28,
                                 d_desc.data_ptr() + f0 * cap * 32, cap, d_counts.data_ptr() + f0 * 4)
+        if bow_early:
+            mbs[i % NEX].wait_for(exs[i % NEX].stream)
+            compute_bow(mbs[i % NEX], f0, q)
 
     # likewise the matcher side: descent (7 us) + feature vector (6 us) of frame i + 1 run beside frame i's 1000 matchings
     mts = [mt] + [capi.Matcher(0.7, True, device=local_rank) for _ in range(max(1, args.c5_matchers) - 1)]
@@ -837,11 +856,8 @@ def run_c5(args, rank, local_rank, world, dev, comm_dev, dist):
         s, q = i % NSLOT, Q[0]
         f0 = n_kf + s * QMAX
         mt = mts[i % NMT]
-        voc.transform_device(mt, d_desc.data_ptr() + f0 * cap * 32, d_counts.data_ptr() + f0 * 4, q, cap, 4,
-                             d_node_of=d_node.data_ptr() + f0 * cap * 2)
-        mt.build_csr_desc_device(d_node.data_ptr() + f0 * cap * 2, d_counts.data_ptr() + f0 * 4, d_desc.data_ptr() + f0 * cap * 32, q, cap,
-                                 n_nodes, d_ckeys.data_ptr() + f0 * cap * 4, d_cstart.data_ptr() + f0 * n_nodes * 2,
-                                 d_ccnt.data_ptr() + f0 * n_nodes * 2, d_cdesc.data_ptr() + f0 * cap * 32)
+        if not bow_early:
+            compute_bow(mt, f0, q)
         if between is not None:
             between()
         if args.c5_pair_kernel:                    # round 3's form: one workgroup per (keyframe, frame) pair
@@ -849,7 +865,9 @@ def run_c5(args, rank, local_rank, world, dev, comm_dev, dist):
         else:                                      # one query against many keyframes (csrc/orb_matcher_query.hip)
             mt.match_bow_query_device(store, kf_idx.data_ptr(), n_kf, f_idx[s].data_ptr(), q, d_match[s].data_ptr(), d_nm[s].data_ptr())
 
-    ex_ss = [torch.cuda.ExternalStream(e.stream, device=dev) for e in exs]
+    # (the stream a slot's "extracted" event is recorded on: the ComputeBoW handle's when it runs behind the extraction)
+    ex_ss = [torch.cuda.ExternalStream((mbs[k] if bow_early else exs[k]).stream, device=dev) for k in range(NEX)]
+    ex_wait = [torch.cuda.ExternalStream(e.stream, device=dev) for e in exs]
     mt_ss = [torch.cuda.ExternalStream(m.stream, device=dev) for m in mts]
     ev_ex, ev_mt = [torch.cuda.Event() for _ in range(NSLOT)], [torch.cuda.Event() for _ in range(NSLOT)]
 
@@ -862,7 +880,7 @@ def run_c5(args, rank, local_rank, world, dev, comm_dev, dist):
         for i in range(i0, i0 + n):
             j = i + 1
             if j - NSLOT >= i0:
-                ex_ss[j % NEX].wait_event(ev_mt[j % NSLOT])        # match(j - NSLOT) has let go of the slot
+                ex_wait[j % NEX].wait_event(ev_mt[j % NSLOT])      # match(j - NSLOT) has let go of the slot
             extract(j)
             ev_ex[j % NSLOT].record(ex_ss[j % NEX])
             mt_ss[i % NMT].wait_event(ev_ex[i % NSLOT])
@@ -871,15 +889,15 @@ def run_c5(args, rank, local_rank, world, dev, comm_dev, dist):
 
     for _ in range(3):                             # (synchronised calls first: the FAST strip lengths settle)
         run(1)
-        [e.sync() for e in exs]; [m.sync() for m in mts]
+        [e.sync() for e in exs]; [m.sync() for m in mbs + mts]
     run(max(args.warmup, 2))
-    [e.sync() for e in exs]; [m.sync() for m in mts]; torch.cuda.synchronize()
+    [e.sync() for e in exs]; [m.sync() for m in mbs + mts]; torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
     run(args.steps)
     t_submit = time.perf_counter() - t0            # host side alone: when it is close to `elapsed` the step is bound by the launches
-    [e.sync() for e in exs]; [m.sync() for m in mts]; torch.cuda.synchronize()
+    [e.sync() for e in exs]; [m.sync() for m in mbs + mts]; torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     elapsed = shard.max_over_ranks(dist, time.perf_counter() - t0, comm_dev)
@@ -889,11 +907,11 @@ def run_c5(args, rank, local_rank, world, dev, comm_dev, dist):
     if not args.c5_no_minibatch:
         Q[0] = QMAX
         run(3)
-        [e.sync() for e in exs]; [m.sync() for m in mts]; torch.cuda.synchronize()
+        [e.sync() for e in exs]; [m.sync() for m in mbs + mts]; torch.cuda.synchronize()
         t1 = time.perf_counter()
         n_mb = max(10, args.steps // QMAX)
         run(n_mb)
-        [e.sync() for e in exs]; [m.sync() for m in mts]; torch.cuda.synchronize()
+        [e.sync() for e in exs]; [m.sync() for m in mbs + mts]; torch.cuda.synchronize()
         mini_fps = n_mb * QMAX / (time.perf_counter() - t1)
         Q[0] = 1
     # non-overlapped durations: descent + feature vector + search as the host sees them, and the search kernel alone by HIP
@@ -901,7 +919,7 @@ def run_c5(args, rank, local_rank, world, dev, comm_dev, dist):
     t_m, t_k = [], []
     N_ALONE = 12
     for i in range(N_ALONE):
-        exs[i % NEX].wait_for(mts[i % NMT].stream); extract(i); exs[i % NEX].sync()
+        exs[i % NEX].wait_for(mts[i % NMT].stream); extract(i); exs[i % NEX].sync(); [m.sync() for m in mbs]
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t1 = time.perf_counter(); match(i, between=lambda: e0.record(mt_ss[i % NMT])); e1.record(mt_ss[i % NMT]); mts[i % NMT].sync()
         t_m.append(time.perf_counter() - t1)
@@ -938,7 +956,7 @@ def run_c5(args, rank, local_rank, world, dev, comm_dev, dist):
                                   "a %d-keyframe DB in HBM (moving-camera sequence of 125 scenes x 8 views; the stream revisits "
                                   "them)" % n_kf, "pair_matchings_per_s": round(n_kf * done / elapsed, 0),
                       "mean_matches_per_pair": round(float(nm.mean()), 2), "max_matches_per_pair": int(nm.max()),
-                      "distinct_stream_frames": n_q, "extractor_handles": NEX, "matcher_handles": NMT,
+                      "distinct_stream_frames": n_q, "extractor_handles": NEX, "matcher_handles": NMT, "compute_bow": "behind the extraction" if bow_early else "in front of the search",
                       "frames_per_s_in_mini_batches_of_%d" % QMAX: round(mini_fps, 1),
                       "transform_plus_match_ms_alone": round(match_ms, 4),
                       "host_submit_ms_per_step": round(t_submit / args.steps * 1e3, 4)},

@@ -106,7 +106,7 @@ struct BowSide {
 // ascending index inside a node (DBoW2's push order).  A counting sort -- six barrier steps instead of the ~45 of a
 // bitonic network over ~1000 keys, which used to be 40 % of this latency-bound kernel:
 //   1 histogram of the nodes with LDS atomics (the returned slot is an arbitrary order inside the node)
-//   2 exclusive scan of the histogram by one wave (DPP)            -> start[], cnt[]
+//   2 exclusive scan of the histogram by one wave (DPP), groups by descending size  -> start[], cnt[]
 //   3 scatter the indices to tmp[start[node] + slot]
 //   4 rank every index inside its node's segment (segments are ~10 long; O(m) per feature) -> keys[]
 // Features whose node is not in [0, nNodes) take no part (they are in no feature vector).
@@ -129,20 +129,35 @@ __device__ void build_csr(const uint16_t* __restrict__ nodeOf, int n, int nNodes
         }
     }
     __syncthreads();
-    if (tid < 64) {                                    // exclusive scan over the nodes: lane owns a contiguous chunk
+    // The node groups are laid out by DESCENDING size (ties: ascending node), not by node: start[] / cnt[] stay indexed by node,
+    // so no consumer sees the order -- except k_match_bow_query's phase 1, whose lanes walk a keyframe's positions 64 at a time
+    // and run as long as the LARGEST query-side node among them: nodes that are large in the keyframe are large in the query
+    // too, so neighbours in this order have similar scan lengths (round 4).
+    for (int t = tid; t < nNodes; t += T) {            // rank of node t by (count descending, node ascending) -> cnt[rank] = t
+        const unsigned c = cntw[t];
+        int r = 0;
+        for (int u = 0; u < nNodes; u++) {
+            const unsigned cu = cntw[u];
+            r += (cu > c) || (cu == c && u < t);
+        }
+        cnt[r] = (uint16_t)t;
+    }
+    __syncthreads();
+    if (tid < 64) {                                    // exclusive scan over the nodes in that order: lane owns a contiguous chunk
         const int C = (nNodes + 63) / 64;
         const int b = min(tid * C, nNodes), e = min(b + C, nNodes);
         int sum = 0;
-        for (int t = b; t < e; t++) sum += (int)cntw[t];
+        for (int r = b; r < e; r++) sum += (int)cntw[cnt[r]];
         const int incl = orb_wave_scan_incl(sum);
         int run = incl - sum;
-        for (int t = b; t < e; t++) {
-            const int c = (int)cntw[t];
+        for (int r = b; r < e; r++) {
+            const int t = cnt[r];
             start[t] = (uint16_t)run;
-            cnt[t] = (uint16_t)c;
-            run += c;
+            run += (int)cntw[t];
         }
     }
+    __syncthreads();
+    for (int t = tid; t < nNodes; t += T) cnt[t] = (uint16_t)cntw[t];
     __syncthreads();
 #pragma unroll
     for (int m = 0; m < ORB_CSR_MAXPT; m++)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One-off parity stress on the GPU box (not part of the suites): many seeded random SearchByBoW cases built to make the
 features of a vocabulary node COMPETE for the same partner (the greedy "already taken" rule, the row-coupling test of the
-4-row kernel path, nodes of 1..40 features), both variants, against the oracle.   usage: stress_parity.py [trials] | --extract [trials]"""
+4-row kernel path, nodes of 1..40 features), both variants, against the oracle.   usage: stress_parity.py [trials] | --extract [trials] | --query [trials]"""
 import os
 import sys
 
@@ -83,9 +83,45 @@ def extract_stress(trials):
     print("stress_parity --extract: %d trials identical to the oracle, %d keypoints" % (trials, total))
 
 
+def query_stress(trials):
+    """orb_match_bow_query_device (one query against many keyframes) on random feature stores: node counts, node-size skew, reuse
+    of partners, capacities, ratios; every pair against the oracle (tests/test_gpu_matcher_query.py holds the store builder)."""
+    import test_gpu_matcher_query as tq
+    rng = np.random.default_rng(4096)
+    total = pairs = 0
+    for t in range(trials):
+        n_nodes = int(rng.choice([8, 40, 100, 100, 250]))
+        w = rng.random(n_nodes) ** float(rng.choice([0.5, 2.0, 6.0]))      # flat ... a few heavy nodes
+        if t % 5 == 0:
+            w[: int(rng.integers(1, 4))] = float(rng.choice([5.0, 20.0, 60.0])) * w.max()
+        cap, n_kf, n_q = int(rng.choice([64, 300, 700, 1100])), int(rng.integers(1, 200)), int(rng.integers(1, 4))
+        ratio, ori = float(rng.choice([0.6, 0.7, 0.9, 1.0])), bool(rng.integers(0, 2))
+        desc, kps, valid, node, counts = tq._store(rng, n_kf, n_q, cap, n_nodes, w, reuse=float(rng.choice([0.05, 0.3, 1.0])),
+                                                   maxflip=int(rng.choice([2, 12, 40])), p_valid=float(rng.choice([0.3, 0.7, 1.0])))
+        mt = capi.Matcher(ratio, ori)
+        kf_list = list(range(n_kf))
+        q_list = list(range(n_kf, n_kf + n_q))
+        m, n, m2, n2 = tq._run(mt, desc, kps, valid, node, counts, n_nodes, kf_list, q_list, True)
+        assert np.array_equal(n, n2), ("query vs pair kernel", t)
+        for qi, fq in enumerate(q_list):
+            for ki in rng.choice(n_kf, min(n_kf, 25), replace=False):
+                wn, wm = tq._oracle_pair(desc, kps, valid, node, counts, int(ki), fq, ratio, ori, True)
+                nb = int(counts[fq])
+                assert n[qi, ki] == wn and np.array_equal(m[qi, ki, :nb], wm), (t, qi, int(ki), n_nodes, cap, ratio, ori)
+                total += wn
+                pairs += 1
+            assert np.array_equal(m[qi][:, :int(counts[fq])], m2[qi][:, :int(counts[fq])]), ("rows vs pair kernel", t, qi)
+        mt.close()
+        if t % 20 == 19:
+            print("query trial %d ok, %d pairs vs oracle, %d matches so far" % (t + 1, pairs, total), flush=True)
+    print("stress_parity --query: %d stores, %d pairs identical to the oracle (every pair identical to the pair kernel), %d matches" % (trials, pairs, total))
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--extract":
         return extract_stress(int(sys.argv[2]) if len(sys.argv) > 2 else 150)
+    if len(sys.argv) > 1 and sys.argv[1] == "--query":
+        return query_stress(int(sys.argv[2]) if len(sys.argv) > 2 else 100)
     trials = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     rng = np.random.default_rng(20261004)
     matches = 0
