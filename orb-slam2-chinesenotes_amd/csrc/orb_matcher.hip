@@ -135,8 +135,15 @@ __device__ void build_csr(const uint16_t* __restrict__ nodeOf, int n, int nNodes
     // too, so neighbours in this order have similar scan lengths (round 4).
     for (int t = tid; t < nNodes; t += T) {            // rank of node t by (count descending, node ascending) -> cnt[rank] = t
         const unsigned c = cntw[t];
-        int r = 0;
-        for (int u = 0; u < nNodes; u++) {
+        int r = 0, u = 0;
+        for (; u + 8 <= nNodes; u += 8) {              // 8 independent broadcast reads in flight (one dependent read per
+            unsigned v[8];                             // iteration is a chain of LDS round trips: +3 us on a one-frame launch)
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[k] = cntw[u + k];
+#pragma unroll
+            for (int k = 0; k < 8; k++) r += (v[k] > c) || (v[k] == c && u + k < t);
+        }
+        for (; u < nNodes; u++) {
             const unsigned cu = cntw[u];
             r += (cu > c) || (cu == c && u < t);
         }

@@ -9,7 +9,7 @@
 //
 //   once per workgroup   the query side -- descriptors in feature-vector order (csr_desc), the feature index of every
 //                        position, node starts / counts, angles -- is staged in LDS and kept for all keyframes the
-//                        workgroup handles (one workgroup per CU, looping; two keyframes in flight, one per half of its waves).
+//                        workgroup handles (two 512-thread workgroups per CU, each taking keyframes from a counter).
 //   phase 1 (parallel)   a LANE = one keyframe feature, taken in feature-vector order, so a wave reads 64 consecutive rows
 //                        of the keyframe's csr_desc (2 KB, coalesced; waves take such chunks from a counter) and nothing in
 //                        the loop depends on a load: the lane
@@ -29,10 +29,10 @@
 //                        row leaves LDS once, coalesced -- no fill pass, no second kernel.
 //
 // Results are identical to the pair kernel's and the oracle's.  Measured on an MI355X (tools/qk_stamps.py, one 752x480 frame
-// against 1000 keyframes, nothing else on the GPU): 59-70 us per query, the pair kernel 78; per keyframe pair of a workgroup
-// ~1.5 us staging, ~12 phase 1 (at the issue rate of its 21 instructions per 64 distances: ~26 columns per wave because a
-// wave's lanes sit in ~5 nodes of different sizes), 0.4-4 phase 2 (16 for the keyframe of the query's own scene: an acceptance
-// in nearly every node), ~6 finish + write-out.
+// against 1000 keyframes, nothing else on the GPU): 50-54 us per query, the pair kernel 78; per keyframe of a workgroup
+// ~9.4 us phase 1 + 1.4 waiting for its slowest wave (at the issue rate of its 21 instructions per 64 distances: ~24 columns
+// per wave because a wave's lanes sit in several nodes of different sizes), 0.6 replay (16 for the keyframe of the query's own
+// scene: an acceptance in nearly every node) + 2.6 waiting, 2.3 histogram + filter + write-out; 4.7 once for the query side.
 #include <algorithm>
 #include <cstdlib>
 #include <new>
@@ -42,7 +42,6 @@
 
 #pragma clang fp contract(off)
 
-#define QK_THREADS 1024        // 16 waves share one staged query side
 // G keyframes are in flight per workgroup, one per 1 / G of its threads (template parameter: 2, or 1 where two do not fit
 // the LDS; 4 -- one round over a 1000-keyframe list -- measured slower: 86 against 64-70 us, every barrier then waits for the
 // slowest of four keyframes)
@@ -105,7 +104,7 @@ static size_t query_lds_bytes(int cap, int nNodes, int G)
 // with a fixed two groups per workgroup those few set the kernel's end 15-20 us after everyone else's.  y = query
 // ONE workgroup per CU is resident (hipOccupancyMaxActiveBlocksPerMultiprocessor): the fused kernel needs ~100 scalar and ~96 vector
 // registers, a second 16-wave workgroup would need 8 waves per SIMD (<= 96 / 64), and forcing that (amdgpu_waves_per_eu) spills.
-template <int QK_G>
+template <int QK_G, int QK_THREADS>
 __global__ __launch_bounds__(QK_THREADS) void k_match_bow_query(orb_featstore S, const int32_t* __restrict__ kfIndex, int nKf,
                                                                const int32_t* __restrict__ fIndex, int nNodes, float ratio, int checkOri,
                                                                int32_t* __restrict__ match, int32_t* __restrict__ nmatches,
@@ -472,9 +471,20 @@ extern "C" int orb_match_bow_query_device(orb_matcher* m, const orb_featstore* s
     if (n_queries > 65535 || (unsigned long long)n_kf * (unsigned long long)n_queries >= (1ull << 31)) return ORB_ERR_UNSUPPORTED;
     const int nNodes = store->n_nodes > 0 ? store->n_nodes : 128;
     ORB_HIP_TRY(hipSetDevice(m->device));
-    static const int envG = getenv("ORB_QK_G") ? atoi(getenv("ORB_QK_G")) : 2, envDbg = getenv("ORB_QK_DBG") ? atoi(getenv("ORB_QK_DBG")) : 0;
-    int G = (envG == 1 || envG == 4) ? envG : 2;
+    // (G keyframes in flight, threads per workgroup, workgroups per CU): ORB_QK_CFG=g,t,b overrides (tuning)
+    static const char* envCfg = getenv("ORB_QK_CFG");
+    static const int envDbg = getenv("ORB_QK_DBG") ? atoi(getenv("ORB_QK_DBG")) : 0;
+    // Default: ONE keyframe per 512-thread workgroup, two workgroups per CU (each stages the query side itself): independent
+    // workgroups drift apart, so the issue-bound phase 1 of one runs beside the latency-bound replay / histogram / write-out of
+    // the other -- 54 against 65 us per 1000 keyframes for two keyframes in flight in one 1024-thread workgroup, whose halves
+    // wait for each other at every barrier (256 threads x 2: 71 us).  Frames too large for two such workgroups per CU
+    // (> ~1450 features) take the 1024-thread forms.
+    int G = 1, TH = 512, perCu = 2;
+    if (2 * query_lds_bytes(store->cap, nNodes, 1) > 160 * 1024) { G = 2; TH = 1024; perCu = 1; }
+    if (envCfg) sscanf(envCfg, "%d,%d,%d", &G, &TH, &perCu);
+    if (!((G == 1 && (TH == 256 || TH == 512 || TH == 1024)) || (G == 2 && TH == 1024) || (G == 4 && TH == 1024))) { G = 2; TH = 1024; perCu = 1; }
     while (G > 1 && query_lds_bytes(store->cap, nNodes, G) > 156 * 1024) G >>= 1;
+    if (G == 1 && TH != 512 && TH != 256) TH = 1024;
     const size_t lds = query_lds_bytes(store->cap, nNodes, G);
     if (lds > 156 * 1024) {
         // frames of more than ~2900 features: the same pairs through the pair kernel (17 bytes of LDS per feature)
@@ -488,15 +498,17 @@ extern "C" int orb_match_bow_query_device(orb_matcher* m, const orb_featstore* s
         ORB_HIP_TRY(hipGetLastError());
         return orb_match_bow_batch_device(m, store, kfPairs, fPairs, (int)nPairs, ratio, check_ori, d_match, d_nmatches);
     }
-    const void* fn = G == 4 ? reinterpret_cast<const void*>(k_match_bow_query<4>)
-                   : G == 2 ? reinterpret_cast<const void*>(k_match_bow_query<2>) : reinterpret_cast<const void*>(k_match_bow_query<1>);
+    const void* fn = G == 4 ? reinterpret_cast<const void*>(k_match_bow_query<4, 1024>)
+                   : G == 2 ? reinterpret_cast<const void*>(k_match_bow_query<2, 1024>)
+                   : TH == 512 ? reinterpret_cast<const void*>(k_match_bow_query<1, 512>)
+                   : TH == 256 ? reinterpret_cast<const void*>(k_match_bow_query<1, 256>) : reinterpret_cast<const void*>(k_match_bow_query<1, 1024>);
     if (lds > 64 * 1024) ORB_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    // a workgroup stages the query side once and keeps it for its keyframes: one workgroup per CU, each looping over its share
-    const int perCu = 1;
+    // a workgroup stages the query side once and keeps it for its keyframes: perCu resident workgroups per CU, each taking groups
+    perCu = std::max(1, std::min(perCu, (int)((size_t)(160 * 1024) / lds)));
     const long long slots = (long long)m->cus * perCu;
     const int blocks = (int)std::max<long long>(1, std::min<long long>((n_kf + G - 1) / G, std::max<long long>(1, slots / n_queries)));      // per query
     unsigned long long* stamps = (unsigned long long)blocks * n_queries * 8 <= m->stampCap ? m->stamps : nullptr;
-    const dim3 grid(blocks, n_queries), block(QK_THREADS);
+    const dim3 grid(blocks, n_queries), block(TH);
     if ((size_t)n_queries > m->qctrStride) {                       // the counter ring (zeroed once; every launch clears a slot for a later one)
         const size_t stride = std::max<size_t>(64, (size_t)n_queries);
         ORB_HIP_TRY(hipStreamSynchronize(m->stream));
@@ -511,18 +523,17 @@ extern "C" int orb_match_bow_query_device(orb_matcher* m, const orb_featstore* s
     m->qserial++;
     if (envDbg) {
         int nb = -1;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, QK_THREADS, lds);
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, TH, lds);
         fprintf(stderr, "[orb] k_match_bow_query<%d>: lds %zu B, blocks %d, occupancy %d workgroups per CU (%s)\n", G, lds, blocks, nb, hipGetErrorString(e));
     }
-    if (G == 4)
-        hipLaunchKernelGGL(k_match_bow_query<4>, grid, block, lds, m->stream, *store, d_kf_index, n_kf, d_f_index, nNodes, ratio, check_ori,
-                           d_match, d_nmatches, groupCtr, ctrToClear, stamps);
-    else if (G == 2)
-        hipLaunchKernelGGL(k_match_bow_query<2>, grid, block, lds, m->stream, *store, d_kf_index, n_kf, d_f_index, nNodes, ratio, check_ori,
-                           d_match, d_nmatches, groupCtr, ctrToClear, stamps);
-    else
-        hipLaunchKernelGGL(k_match_bow_query<1>, grid, block, lds, m->stream, *store, d_kf_index, n_kf, d_f_index, nNodes, ratio, check_ori,
-                           d_match, d_nmatches, groupCtr, ctrToClear, stamps);
+#define QK_LAUNCH(GG, TT) hipLaunchKernelGGL((k_match_bow_query<GG, TT>), grid, block, lds, m->stream, *store, d_kf_index, n_kf, d_f_index, nNodes, \
+                                             ratio, check_ori, d_match, d_nmatches, groupCtr, ctrToClear, stamps)
+    if (G == 4) QK_LAUNCH(4, 1024);
+    else if (G == 2) QK_LAUNCH(2, 1024);
+    else if (TH == 512) QK_LAUNCH(1, 512);
+    else if (TH == 256) QK_LAUNCH(1, 256);
+    else QK_LAUNCH(1, 1024);
+#undef QK_LAUNCH
     ORB_HIP_TRY(hipGetLastError());
     return ORB_OK;
 }
