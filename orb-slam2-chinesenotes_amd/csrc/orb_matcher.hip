@@ -112,7 +112,7 @@ struct BowSide {
 // Features whose node is not in [0, nNodes) take no part (they are in no feature vector).
 #define ORB_CSR_MAXPT 8        // features per thread: cap <= 8192, 1024 threads
 __device__ void build_csr(const uint16_t* __restrict__ nodeOf, int n, int nNodes, uint32_t* keys, uint32_t* tmp,
-                          uint32_t* cntw, uint16_t* start, uint16_t* cnt)
+                          uint32_t* cntw, uint16_t* start, uint16_t* cnt, bool bySize)
 {
     const int T = blockDim.x, tid = threadIdx.x;
     for (int t = tid; t < nNodes; t += T) cntw[t] = 0;
@@ -132,8 +132,11 @@ __device__ void build_csr(const uint16_t* __restrict__ nodeOf, int n, int nNodes
     // The node groups are laid out by DESCENDING size (ties: ascending node), not by node: start[] / cnt[] stay indexed by node,
     // so no consumer sees the order -- except k_match_bow_query's phase 1, whose lanes walk a keyframe's positions 64 at a time
     // and run as long as the LARGEST query-side node among them: nodes that are large in the keyframe are large in the query
-    // too, so neighbours in this order have similar scan lengths (round 4).
+    // too, so neighbours in this order have similar scan lengths (round 4).  Only where that kernel will read the result
+    // (bySize: the store's CSR with the node-sorted descriptor copy); elsewhere plain node order (cnt[rank] = rank) -- the
+    // ranking and its barriers doubled k_build_csr on a 512-frame batch (8.4 -> 17.2 us).
     for (int t = tid; t < nNodes; t += T) {            // rank of node t by (count descending, node ascending) -> cnt[rank] = t
+        if (!bySize) { cnt[t] = (uint16_t)t; continue; }
         const unsigned c = cntw[t];
         int r = 0, u = 0;
         for (; u + 8 <= nNodes; u += 8) {              // 8 independent broadcast reads in flight (one dependent read per
@@ -191,7 +194,7 @@ __device__ __forceinline__ void load_or_build_csr(const BowSide& S, int nNodes, 
         for (int t = threadIdx.x; t < nNodes; t += blockDim.x) { start[t] = gload(S.csrStart + t); cnt[t] = gload(S.csrCnt + t); }
         __syncthreads();
     } else {
-        build_csr(S.nodeOf, S.n, nNodes, keys, tmp, cntw, start, cnt);
+        build_csr(S.nodeOf, S.n, nNodes, keys, tmp, cntw, start, cnt, false);
     }
 }
 
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(1024) void k_build_csr(const uint16_t* __restrict__
     const int f = blockIdx.x;
     const int n = min(max(counts[f], 0), cap);
     for (int i = threadIdx.x; i < cap; i += blockDim.x) keys[i] = 0xFFFFFFFFu;
-    build_csr(nodeOf + (size_t)f * cap, n, nNodes, keys, tmp, cntw, start, cnt);
+    build_csr(nodeOf + (size_t)f * cap, n, nNodes, keys, tmp, cntw, start, cnt, descOut != nullptr);
     for (int i = threadIdx.x; i < cap; i += blockDim.x) keysOut[(size_t)f * cap + i] = keys[i];
     for (int t = threadIdx.x; t < nNodes; t += blockDim.x) {
         startOut[(size_t)f * nNodes + t] = start[t];
