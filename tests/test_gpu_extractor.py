@@ -54,6 +54,12 @@ def test_gaussian_presets_of_both_opencv_generations(preset):
     for f, (kb, db) in enumerate(ex.extract_batch(batch)):
         rk, rd = ref.extract(batch[f])
         assert kb.tobytes() == rk.tobytes() and np.array_equal(db, rd)
+    for custom in ([10, 20, 60, 77], [0, 0, 64, 127], [1, 0, 0, 0], [0, 0, 1, 255]):   # (sum 257 with other taps; large taps; two taps only)
+        ref.set_gaussian(ex.set_gaussian(custom))
+        for im in frames[:2]:
+            kps, desc = ex.extract(im)
+            rk, rd = ref.extract(im)
+            assert kps.tobytes() == rk.tobytes() and np.array_equal(desc, rd), custom
     with pytest.raises(capi.OrbError):
         ex.set_gaussian([30, 40, 50, 60])                          # sums to 300: the 16-bit row sums would overflow
     ex.close()

@@ -23,13 +23,20 @@ run() {   # name, rocprofv3 options...
     tail -1 "$OUT/$name.log" | cut -c1-200
 }
 
-run stats --kernel-trace --stats &&
-run sq1 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU GRBM_GUI_ACTIVE &&
-run sq2 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD &&
-run fetch --kernel-trace --pmc FETCH_SIZE &&
-run write --kernel-trace --pmc WRITE_SIZE &&
-run tcc --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum
-rc=$?
+# PROF_PASSES="stats sq1 sq2" restricts the passes (default: all six)
+PASSES=${PROF_PASSES:-stats sq1 sq2 fetch write tcc}
+rc=0
+for pass in $PASSES; do
+    case $pass in
+        stats) run stats --kernel-trace --stats ;;
+        sq1) run sq1 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU GRBM_GUI_ACTIVE ;;
+        sq2) run sq2 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD ;;
+        fetch) run fetch --kernel-trace --pmc FETCH_SIZE ;;
+        write) run write --kernel-trace --pmc WRITE_SIZE ;;
+        tcc) run tcc --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum ;;
+        *) echo "[prof_collect] unknown pass $pass"; false ;;
+    esac || { rc=1; break; }
+done
 # keep only what the summary needs (the merge back is capped at 64 MiB)
 find "$OUT" -name '*agent_info.csv' -delete
 du -sh "$OUT" | cut -f1
