@@ -102,3 +102,45 @@ def test_vocab_transform_randomized_trees_and_sizes():
                 gw, gn = v.transform(m, desc, levelsup)
                 assert np.array_equal(gw, ww) and np.array_equal(gn, wn), (t, k, L, n, levelsup)
         v.close()
+
+
+@pytest.mark.parametrize("k,L", [(10, 4), (12, 3), (16, 3), (7, 5)])
+def test_vocab_transform_device_batches_with_ragged_counts(k, L):
+    """orb_bow_transform_device over a batch of 20 frames with ragged per-frame counts (0, 1, around the wave width, the full
+    capacity), a quarter of the descriptors exact copies of node descriptors (distance ties): word, node id and compact
+    node index against the oracle; slots past a frame's count keep 0xFFFF / stay untouched."""
+    import torch
+    tree = synth.synth_vocab_tree(k, L, seed=4000 + k, prune=0.1)
+    levelsup = 1
+    F, cap = 20, 1003
+    rng = np.random.default_rng(k * 7 + L)
+    counts = np.array([0, 1, 3, 63, 64, 65, cap, cap - 1, 500, 777] + [int(x) for x in rng.integers(0, cap + 1, F - 10)], np.int32)
+    desc = rng.integers(0, 256, (F, cap, 32), dtype=np.uint8)
+    # ties on purpose: a quarter of the descriptors are exact copies of tree nodes' descriptors
+    nd = np.asarray(tree["node_desc"], np.uint8).reshape(-1, 32)
+    pick = rng.integers(0, nd.shape[0], (F, cap))
+    copy = rng.random((F, cap)) < 0.25
+    desc[copy] = nd[pick[copy]]
+    dev = torch.device("cuda:0")
+    dD = torch.from_numpy(desc).to(dev)
+    dC = torch.from_numpy(counts).to(dev)
+    dW = torch.full((F, cap), -7, dtype=torch.int32, device=dev)
+    dN = torch.full((F, cap), -7, dtype=torch.int32, device=dev)
+    dO = torch.full((F, cap), 0x1234, dtype=torch.int16, device=dev)
+    m = capi.Matcher()
+    v = capi.Vocabulary(tree)
+    v.transform_device(m, dD.data_ptr(), dC.data_ptr(), F, cap, levelsup, dW.data_ptr(), dN.data_ptr(), dO.data_ptr())
+    m.sync()
+    gW, gN, gO = dW.cpu().numpy(), dN.cpu().numpy(), dO.cpu().numpy().view(np.uint16)
+    for f in range(F):
+        n = int(counts[f])
+        ww, wn = oracle.vocab_transform(tree, desc[f, :n], levelsup)
+        assert np.array_equal(gW[f, :n], ww) and np.array_equal(gN[f, :n], wn), (f, n)
+        assert (gO[f, n:] == 0xFFFF).all() and (gW[f, n:] == -7).all()
+        # compact index: ascending node id over the nodes of that level
+        if n:
+            reached = gN[f, :n] >= 0                                  # (a pruned branch can end above that level: node id -1)
+            assert ((gO[f, :n] != 0xFFFF) == reached).all()
+            order = np.argsort(gN[f, :n][reached], kind="stable")
+            assert (np.diff(gO[f, :n][reached][order].astype(np.int64)) >= 0).all()
+    v.close()
