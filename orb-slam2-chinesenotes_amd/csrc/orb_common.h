@@ -150,6 +150,10 @@ static inline unsigned orb_xcd_grid(unsigned perFrame, int nFrames, unsigned* in
 {
     const unsigned long long groups = ((unsigned long long)nFrames + 7) / 8;
     const unsigned long long total = groups * 8ull * perFrame;
+    // Few frames: frame -> XCD leaves XCDs idle (a single frame would run on ONE of the eight: 32 CUs for its ~300 strips /
+    // ~1000 keypoint waves, the other 224 idle); the plain grid deals its workgroups over all of them.  A frame's pyramid
+    // is then read through up to eight L2s -- irrelevant when a handful of frames is all there is.
+    if ((unsigned long long)nFrames * 5 < groups * 8ull * 4) return 0;      // less than 80 % of the frame slots used
     if (perFrame < 2 || total >= (1ull << 31) || groups * perFrame * (unsigned long long)perFrame >= (1ull << 32)) return 0;
     *invPerFrame = (unsigned)(((1ull << 32) + perFrame - 1) / perFrame);
     return (unsigned)total;
