@@ -29,6 +29,7 @@
 //   * the quadtree path of a candidate is two table look-ups (x and y bisect independently);
 //   * everything derived from the strip rectangle alone comes precomputed in the 48-byte OrbStrip record.
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 #include "orb_kernels.h"
@@ -787,6 +788,298 @@ __global__ __launch_bounds__(WAVE) void k_fast_strips_p(const OrbGeom G, const u
     }
 }
 
+// =====================================================================================================================
+// k_fast_strips_mw<P>: the strip detector of k_fast_strips_p for launches of a FEW frames (single frames, config 5's
+// stream), where a frame's ~300 strips are all the chip has to do and the time of the launch is the time of ONE strip's
+// chain of ~1600 dependent-ish instructions on one wave.  Here FOUR waves share a strip: the tile is staged by all 256
+// threads, the steps of phase A (8 rows x 8 quads each) are dealt round-robin over the waves, every wave keeps its own
+// two pair rings and drains them itself (phase B), candidates go to ONE queue through an LDS counter (their order is
+// irrelevant: the NMS reads the score map, the quadtree sorts the keys), and the tail (zeroing, scatter, NMS, emission)
+// runs over the queue with 256 threads.  Same arithmetic, same results; real barriers between the stages.
+#define MW_WAVES 4
+template <int P>
+struct FastMW {
+    static constexpr int ROWB = 4 * P;
+    static constexpr int RINGB = MW_WAVES * 2 * F2_RING * 2;                // per wave: ring A 256 B | ring B 256 B
+    static constexpr int HDR = ((RINGB + 16 + ROWB - 1) / ROWB) * ROWB;
+    static constexpr int CL = FastP<P>::CL;
+    static constexpr int RI = (WAVE * MW_WAVES) / CL;                       // rows per staging step
+    static constexpr int MAXIT = (66 + RI - 1) / RI;
+};
+size_t orb_fast_mw_lds_bytes(int P, int rowsMax, int candCap)
+{
+    const int rowb = 4 * P, hdr = ((MW_WAVES * 2 * F2_RING * 2 + 16 + rowb - 1) / rowb) * rowb;
+    const size_t tail = std::max<size_t>((((size_t)3 * candCap + 3) & ~(size_t)3) + 32, (size_t)8 * rowb + 32);   // (see orb_fast_p_lds_bytes)
+    return (size_t)hdr + (size_t)rowsMax * rowb + 16 + tail;
+}
+
+template <int P>
+__global__ __launch_bounds__(WAVE * MW_WAVES) void k_fast_strips_mw(const OrbGeom G, const uint8_t* __restrict__ pyr, size_t pyrSlab,
+                                                                   const OrbStrip* __restrict__ strips,
+                                                                   const uint32_t* __restrict__ pathTab,
+                                                                   unsigned long long* __restrict__ cand, size_t candSlab,
+                                                                   int* __restrict__ candCount, int* __restrict__ errFlags,
+                                                                   int* __restrict__ ovfCount, int* __restrict__ ovfList, int iniTh,
+                                                                   int minTh, int rowsMax, int candCap)
+{
+    // dynamic LDS (bytes): [4 x (ring A 256 | ring B 256) | pad .. HDR) | tile rowsMax x ROWB | 16 | candPos 2 candCap |
+    //                       candScore candCap (rounded up to 4) | shared: candidate counter, cells-with-a-keypoint mask, the
+    //                       waves' keypoint counts, the output base]
+    extern __shared__ uint32_t fsm[];
+    constexpr int ROWB = FastMW<P>::ROWB, TB = FastMW<P>::HDR, T = WAVE * MW_WAVES;
+    uint8_t* lds = reinterpret_cast<uint8_t*>(fsm);
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int f = blockIdx.y, si = blockIdx.x;
+    if ((unsigned)(uintptr_t)((__attribute__((address_space(3))) uint32_t*)fsm) != 0u) {   // see lds_dw
+        if (tid == 0) orb_flag_error(errFlags, f, 1);
+        return;
+    }
+    const OrbStrip S = strips[si];
+    const OrbLevelGeom& L = G.L[S.level];
+    const int CB = TB + rowsMax * ROWB + 16;                       // candidate positions (u16: row << 8 | col), then scores (u8)
+    uint16_t* candPos = reinterpret_cast<uint16_t*>(lds + CB);
+    uint8_t* candScore = lds + CB + 2 * candCap;
+    int* shared = reinterpret_cast<int*>(lds + CB + ((3 * candCap + 3) & ~3));
+    if (tid == 0) { shared[0] = 0; shared[1] = 0; }
+
+    // ---- stage rows [y0, y0 + h): 16 bytes per thread, T / CL rows per step
+    {
+        constexpr int CL = FastMW<P>::CL, RI = FastMW<P>::RI, MAXIT = FastMW<P>::MAXIT, NC = P / 4;
+        const int rr = tid / CL, c = tid % CL;
+        const int h = S.h, pitch = L.pitch;
+        const uint8_t* src = pyr + (size_t)f * pyrSlab + L.pyrOff + (size_t)(S.y0 + rr) * pitch + (S.x0 - S.xoff) + 16 * c;
+        uint8_t* dst = lds + TB + rr * ROWB + 16 * c;
+        const bool act = c < NC;
+        orb_u32x4 v[MAXIT];
+#pragma unroll
+        for (int it = 0; it < MAXIT; it++)
+            if (it * RI < h) {
+                if (act && it * RI + rr < h) v[it] = *reinterpret_cast<const orb_u32x4_a8*>(src + (size_t)it * RI * pitch);
+            }
+#pragma unroll
+        for (int it = 0; it < MAXIT; it++)
+            if (it * RI < h) {
+                if (act && it * RI + rr < h) *reinterpret_cast<orb_u32x4*>(dst + it * RI * ROWB) = v[it];
+            }
+    }
+    __syncthreads();
+
+    const int lowTh = min(iniTh, minTh);
+    {
+        const unsigned ringBase = (unsigned)wv * (unsigned)(4 * F2_RING);      // this wave's rings (bytes)
+        const uint16_t* ringA = reinterpret_cast<const uint16_t*>(lds + ringBase);
+        const uint16_t* ringB = ringA + F2_RING;
+        const int zh = S.zh, nq = S.nq, qLo = S.qLo;
+        unsigned thKV = (unsigned)(0x7fff - lowTh) * 0x10001u;
+        asm volatile("" : "+v"(thKV));
+        const int nsc = (nq + 7) >> 3, nSteps = ((zh + 7) >> 3) * nsc;        // steps of 8 rows x 8 quads; wave w takes w, w + 4, ...
+        int cntA = 0, cntB = 0, headA = 0, headB = 0;                           // wave-uniform ring state
+        constexpr unsigned kRowMagic = (unsigned)(((1ull << 32) + ROWB - 1) / ROWB);
+        auto bstep = [&](auto Htag, int head, int n, int nB2) {                 // (as in k_fast_strips_p)
+            constexpr int H = decltype(Htag)::value;
+            const bool fromB = H == 2 && lane >= n;
+            const bool act = lane < n + (H == 2 ? nB2 : 0);
+            unsigned s2 = 0, a = 0;
+            if (act) {
+                a = fromB ? ringB[(headB + lane - n) & (F2_RING - 1)] : (H == 1 ? ringB : ringA)[(head + lane) & (F2_RING - 1)];
+                const orb_lds_u32* p = lds_dw(a);
+                unsigned W[7][3];
+#pragma unroll
+                for (int r = 0; r < 7; r++) { W[r][0] = p[r * P]; W[r][1] = p[r * P + 1]; W[r][2] = p[r * P + 2]; }
+                if (H == 2) {
+                    const unsigned shB = fromB ? 2u : 0u;
+#pragma unroll
+                    for (int r = 0; r < 7; r++) {
+                        W[r][0] = __builtin_amdgcn_alignbyte(W[r][1], W[r][0], shB);
+                        W[r][1] = __builtin_amdgcn_alignbyte(W[r][2], W[r][1], shB);
+                        W[r][2] >>= 8u * shB;
+                    }
+                }
+                s2 = H == 1 ? fast_pair<6>(W) : fast_pair<4>(W);
+            }
+            const int sLo = (int)(s2 & 0xffffu), sHi = (int)(s2 >> 16);
+            const bool pLo = sLo > lowTh, pHi = sHi > lowTh;
+            const unsigned long long bLo = __ballot(pLo), bHi = __ballot(pHi);
+            if ((bLo | bHi) == 0) return;
+            const int nLo = __popcll(bLo), nHi = __popcll(bHi);
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&shared[0], nLo + nHi);            // the workgroup's candidate queue
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (base + nLo + nHi <= candCap) {
+                const unsigned a4 = a + 4u, rowAbs = __umulhi(a4, kRowMagic);
+                const unsigned e = ((rowAbs + (unsigned)(3 - TB / ROWB)) << 8) + (a4 - rowAbs * (unsigned)ROWB) +
+                                   (H == 2 ? (fromB ? 2u : 0u) : (unsigned)(2 * H));
+                if (pLo) {
+                    const int w = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bLo >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bLo, (unsigned)base));
+                    candPos[w] = (uint16_t)e;
+                    candScore[w] = (uint8_t)sLo;
+                }
+                if (pHi) {
+                    const int w = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bHi >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bHi, (unsigned)(base + nLo)));
+                    candPos[w] = (uint16_t)(e + 1);
+                    candScore[w] = (uint8_t)sHi;
+                }
+            }
+        };
+        for (int st = wv;; st += MW_WAVES) {
+            const bool more = st < nSteps;
+            if (more) {
+                const int blk = st / nsc, cs = (st - blk * nsc) * 8;            // (wave-uniform)
+                const int col = cs + (lane >> 3), row = blk * 8 + (lane & 7);
+                const bool valid = col < nq && row < zh;
+                const unsigned a = (unsigned)(TB + (row * P + qLo + min(col, nq - 1) - 1) * 4);
+                const orb_lds_u32* p = lds_dw(a);
+                const unsigned c0 = p[3 * P], c1 = p[3 * P + 1], c2 = p[3 * P + 2];           // row y
+                const unsigned u1 = p[1], d1 = p[6 * P + 1];                                  // rows y-3, y+3: x .. x+3
+                const unsigned a0 = p[P], a1 = p[P + 1], a2 = p[P + 2];                       // row y-2
+                const unsigned b0 = p[5 * P], b1 = p[5 * P + 1], b2 = p[5 * P + 2];           // row y+2
+                unsigned u[2];
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const unsigned cc = h ? pick2<6>(c0, c1, c2) : pick2<4>(c0, c1, c2);
+                    const unsigned r0 = h ? pick2<6>(0, d1, 0) : pick2<4>(0, d1, 0);
+                    const unsigned r8 = h ? pick2<6>(0, u1, 0) : pick2<4>(0, u1, 0);
+                    const unsigned r4 = h ? pick2<9>(c0, c1, c2) : pick2<7>(c0, c1, c2);
+                    const unsigned r12 = h ? pick2<3>(c0, c1, c2) : pick2<1>(c0, c1, c2);
+                    const unsigned r2 = h ? pick2<8>(b0, b1, b2) : pick2<6>(b0, b1, b2);
+                    const unsigned r10 = h ? pick2<4>(a0, a1, a2) : pick2<2>(a0, a1, a2);
+                    const unsigned r6 = h ? pick2<8>(a0, a1, a2) : pick2<6>(a0, a1, a2);
+                    const unsigned r14 = h ? pick2<4>(b0, b1, b2) : pick2<2>(b0, b1, b2);
+                    const unsigned mlo = pk_max3(pk_min2(r0, r8), pk_min2(r4, r12), pk_max2(pk_min2(r2, r10), pk_min2(r6, r14)));
+                    const unsigned mhi = pk_min3(pk_max2(r0, r8), pk_max2(r4, r12), pk_min2(pk_max2(r2, r10), pk_max2(r6, r14)));
+                    u[h] = pk_max_i16(pk_sub_i16(cc, mlo), pk_sub_i16(mhi, cc));
+                }
+                const bool qa = (pk_add_u16_n(u[0], thKV) & 0x80008000u) != 0, qb = (pk_add_u16_n(u[1], thKV) & 0x80008000u) != 0;
+                const unsigned long long bv = __ballot(valid), ba = __ballot(qa) & bv, bb = __ballot(qb) & bv;
+                const unsigned ra = __builtin_amdgcn_mbcnt_hi((unsigned)(ba >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ba, 0u));
+                const unsigned rb = __builtin_amdgcn_mbcnt_hi((unsigned)(bb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bb, 0u));
+                if (qa & valid) *lds_hw(ringBase + (((ra << 1) + (unsigned)(2 * (headA + cntA))) & (2 * F2_RING - 2))) = (uint16_t)a;
+                if (qb & valid) *lds_hw(ringBase + 2 * F2_RING + (((rb << 1) + (unsigned)(2 * (headB + cntB))) & (2 * F2_RING - 2))) = (uint16_t)a;
+                cntA += __popcll(ba);
+                cntB += __popcll(bb);
+            }
+            // LDS operations of one wave execute in order: this only keeps the compiler from moving the ring reads of phase B
+            // above the ring writes (NOT a workgroup barrier: the waves run different numbers of steps)
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            while (cntA >= WAVE) {
+                bstep(std::integral_constant<int, 0>(), headA, WAVE, 0);
+                headA = (headA + WAVE) & (F2_RING - 1);
+                cntA -= WAVE;
+            }
+            while (cntB >= WAVE) {
+                bstep(std::integral_constant<int, 1>(), headB, WAVE, 0);
+                headB = (headB + WAVE) & (F2_RING - 1);
+                cntB -= WAVE;
+            }
+            if (!more) {
+                if (cntA > 0 && cntB > 0 && cntA + cntB <= WAVE) {
+                    bstep(std::integral_constant<int, 2>(), headA, cntA, cntB);
+                } else {
+                    if (cntA > 0) bstep(std::integral_constant<int, 0>(), headA, cntA, 0);
+                    if (cntB > 0) bstep(std::integral_constant<int, 1>(), headB, cntB, 0);
+                }
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    const int nCand = shared[0];
+    if (nCand == 0) return;
+    if (nCand > candCap) {                                         // redone by k_fast_strips_dense
+        if (tid == 0) {
+            ovfList[atomicAdd(ovfCount, 1)] = (int)(((unsigned)f << 16) | (unsigned)si);
+            atomicAdd(&ovfCount[8 + S.level], 1);
+        }
+        return;
+    }
+
+    // ---- the tile is dead: it becomes the score map (0 everywhere but at the candidates inside the zone)
+    {
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        uint4* t4 = reinterpret_cast<uint4*>(lds + TB - 16);
+        const int n4 = (16 + S.h * ROWB + 16) >> 4;
+        for (int i = tid; i < n4; i += T) t4[i] = z;
+    }
+    __syncthreads();
+    uint8_t* smap = lds + TB;
+    const int zLo = S.zLo, zHi = S.zHi, wCell = S.wCell;
+    for (int e = tid; e < nCand; e += T) {
+        const unsigned ent = candPos[e];
+        const unsigned col = ent & 0xff;
+        if (col - (unsigned)zLo < (unsigned)(zHi - zLo)) smap[(ent >> 8) * ROWB + col] = candScore[e];
+        else candScore[e] = 0;
+    }
+    __syncthreads();
+
+    // ---- cell-local 3x3 strict NMS over the candidate queue, both thresholds at once (as k_fast_strips)
+    unsigned keep0 = 0, keep1 = 0;                                 // one bit per queue step (candCap <= 4096: <= 16 steps)
+    unsigned has = 0;
+    {
+        int it = 0;
+        for (int base = 0; base < nCand; base += T, it++) {
+            const int e = base + tid;
+            if (e < nCand) {
+                const unsigned ent = candPos[e];
+                const int row = ent >> 8, col = ent & 0xff;
+                const int c = (int)(((unsigned)(col - zLo) * S.invW) >> 16);
+                const int cs = zLo + c * wCell, ce = min(cs + wCell, zHi);
+                const int Sv = candScore[e];
+                const bool ok = fast_nms_ok(smap + row * ROWB + col, ROWB, col == cs, col == ce - 1, Sv);
+                const unsigned k0 = ok && Sv > iniTh, k1 = ok && Sv > minTh;
+                keep0 |= k0 << it;
+                keep1 |= k1 << it;
+                has |= k0 << c;
+            }
+        }
+    }
+    has = orb_wave_or(has);
+    if (lane == 0 && has) atomicOr(&shared[1], (int)has);
+    __syncthreads();
+    const unsigned fb = ~(unsigned)shared[1];                      // cells without a keypoint at iniTh
+    unsigned keepF = 0;
+    int mine = 0;
+    for (unsigned mm = keep0 | keep1; mm;) {
+        const int it = __ffs((int)mm) - 1;
+        mm &= mm - 1;
+        const int col = candPos[it * T + tid] & 0xff;
+        const unsigned c = ((unsigned)(col - zLo) * S.invW) >> 16;
+        const unsigned k = ((((fb >> c) & 1u) ? keep1 : keep0) >> it) & 1u;
+        keepF |= k << it;
+        mine += (int)k;
+    }
+    const int incl = orb_wave_scan_incl(mine);
+    // ONE atomic per workgroup on the level's counter: the ~300 strips of a frame finish within a microsecond of each other
+    // and their returning atomics on the 8 counters of a frame (one cache line) are served one after the other (~4.4 ns
+    // each: 5.4 us of a 14 us launch with one atomic per wave)
+    if (lane == WAVE - 1) shared[2 + wv] = incl;
+    __syncthreads();
+    const int t0 = shared[2], t1 = shared[3], t2 = shared[4], t3 = shared[5];
+    const int total = t0 + t1 + t2 + t3;
+    if (total == 0) return;
+    if (tid == 0) shared[6] = atomicAdd(&candCount[f * ORB_MAX_LEVELS + S.level], total);
+    __syncthreads();
+    if (shared[6] + total > L.candCap) {                           // cannot happen: candCap is the NMS bound
+        if (tid == 0) orb_flag_error(errFlags, f, 1);
+        return;
+    }
+    const int base0 = shared[6] + (wv > 0 ? t0 : 0) + (wv > 1 ? t1 : 0) + (wv > 2 ? t2 : 0);
+    const uint32_t* xtab = pathTab + L.pathXOff;
+    const uint32_t* ytab = pathTab + L.pathYOff;
+    unsigned long long* out = cand + (size_t)f * candSlab + L.candBase;
+    const int cy0 = S.ci * L.hCell;
+    int w = base0 + incl - mine;
+    while (keepF) {
+        const int it = __ffs((int)keepF) - 1;
+        keepF &= keepF - 1;
+        const unsigned ent = candPos[it * T + tid];
+        const int row = ent >> 8, col = ent & 0xff;
+        const int c = (int)(((unsigned)(col - zLo) * S.invW) >> 16);
+        const int Sv = candScore[it * T + tid];
+        out[w++] = FAST_KEY(row, col, c, Sv);
+    }
+}
+
 // The strips of ovfList ((frame << 16 | strip) entries) again, with a full score map next to the tile and
 // a dense scan of it, one cell at a time: any number of candidates.  One wave per workgroup, grid-stride over the list.
 __global__ __launch_bounds__(WAVE) void k_fast_strips_dense(const OrbGeom G, const uint8_t* __restrict__ pyr,
@@ -912,6 +1205,17 @@ void orb_launch_fast_strips(hipStream_t st, const OrbGeom& G, const uint8_t* pyr
     const unsigned wgs = orb_xcd_grid((unsigned)nStrips, nFrames, &inv);
     const dim3 grid = wgs ? dim3(wgs) : dim3(nStrips, nFrames);
     if (fixedPitch && orb_fast_p_lds_bytes(fixedPitch, rowsMax, candCap) > 64 * 1024) fixedPitch = 0;
+    // a few frames: four waves per strip (k_fast_strips_mw) -- the launch lasts as long as one strip's chain.  ORB_FAST_MW=0|1 pins.
+    static const int mwPin = [] { const char* e = std::getenv("ORB_FAST_MW"); return e ? std::atoi(e) : -1; }();
+    const bool mw = fixedPitch && candCap <= 4096 && orb_fast_mw_lds_bytes(fixedPitch, rowsMax, candCap) <= 64 * 1024 &&
+                    (mwPin >= 0 ? mwPin != 0 : (long long)nStrips * nFrames <= 1536);
+    if (mw && fixedPitch == 28)
+        hipLaunchKernelGGL(k_fast_strips_mw<28>, dim3(nStrips, nFrames), dim3(WAVE * MW_WAVES), orb_fast_mw_lds_bytes(28, rowsMax, candCap), st, G, pyr,
+                           pyrSlab, strips, pathTab, cand, candSlab, candCount, errFlags, ovfCount, ovfList, iniTh, minTh, rowsMax, candCap);
+    else if (mw && fixedPitch == 20)
+        hipLaunchKernelGGL(k_fast_strips_mw<20>, dim3(nStrips, nFrames), dim3(WAVE * MW_WAVES), orb_fast_mw_lds_bytes(20, rowsMax, candCap), st, G, pyr,
+                           pyrSlab, strips, pathTab, cand, candSlab, candCount, errFlags, ovfCount, ovfList, iniTh, minTh, rowsMax, candCap);
+    else
     if (fixedPitch == 28)
         hipLaunchKernelGGL(k_fast_strips_p<28>, grid, dim3(WAVE), orb_fast_p_lds_bytes(28, rowsMax, candCap), st, G, pyr, pyrSlab, strips, pathTab,
                            cand, candSlab, candCount, errFlags, ovfCount, ovfList, iniTh, minTh, rowsMax, candCap, nStrips, nFrames, inv);

@@ -177,14 +177,20 @@ def test_two_handles_two_threads():
     imgs = [synth.synth_frame(30), synth.synth_frame(31)]
     res = [None, None]
 
+    errs = [None, None]
+
     def work(i):
-        ex = capi.Extractor()
-        for _ in range(6):                              # eager, graph capture and graph replay all happen on both threads
-            res[i] = ex.extract(imgs[i])
+        try:
+            ex = capi.Extractor()
+            for _ in range(6):                          # eager, graph capture and graph replay all happen on both threads
+                res[i] = ex.extract(imgs[i])
+        except BaseException as e:                      # (an exception in a thread would otherwise only show as a warning)
+            errs[i] = e
 
     ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
     [t.start() for t in ts]
     [t.join() for t in ts]
+    assert errs == [None, None], errs
     ref = oracle.Extractor()
     for i in range(2):
         rk, rd = ref.extract(imgs[i])
