@@ -21,6 +21,21 @@ void orb_set_error(const char* fmt, ...);
         }                                                                                  \
     } while (0)
 
+// Blocking copies / fills go through a stream of the caller's (hipMemcpyAsync + hipStreamSynchronize), never through the
+// legacy null stream: hipMemcpy / hipMemset on the null stream FAIL while any stream of the process is being captured into
+// a graph -- and invalidate that capture -- even a thread-local capture of another thread's non-blocking stream (two
+// extractor handles on two threads, src/Frame.cc:82-85: one thread's table upload met the other's graph capture).
+static inline hipError_t orb_copy_blocking(void* dst, const void* src, size_t n, hipMemcpyKind kind, hipStream_t st)
+{
+    const hipError_t e = hipMemcpyAsync(dst, src, n, kind, st);
+    return e != hipSuccess ? e : hipStreamSynchronize(st);
+}
+static inline hipError_t orb_fill_blocking(void* dst, int v, size_t n, hipStream_t st)
+{
+    const hipError_t e = hipMemsetAsync(dst, v, n, st);
+    return e != hipSuccess ? e : hipStreamSynchronize(st);
+}
+
 // ---- geometry of one pyramid level, shared by host set-up code and all kernels ----
 struct OrbLevelGeom {
     int w, h, pitch;            // image size and row pitch (bytes, multiple of 64)

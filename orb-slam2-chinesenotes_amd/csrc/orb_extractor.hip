@@ -206,7 +206,7 @@ extern "C" int orb_extractor_create(const orb_extractor_params* p, int device_id
     if (hipHostMalloc((void**)&h->ovfHost, orb_extractor::kOvfInts * 4, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); h->ovfHost = nullptr; }
     int rc = h->dPattern.ensure(1024);
     if (rc == ORB_OK) {
-        if (hipMemcpy(h->dPattern.p, ORB_BRIEF_PATTERN_XY, 1024, hipMemcpyHostToDevice) != hipSuccess) rc = ORB_ERR_HIP;
+        if (orb_copy_blocking(h->dPattern.p, ORB_BRIEF_PATTERN_XY, 1024, hipMemcpyHostToDevice, h->stream) != hipSuccess) rc = ORB_ERR_HIP;
     }
     if (rc == ORB_OK) rc = h->dPatternF.ensure(256 * 16);
     if (rc == ORB_OK) rc = h->dAngTab.ensure(16 * 2 * 32 + 768 * 4);     // + the descriptor kernel's horizontal-blur item table
@@ -222,12 +222,12 @@ extern "C" int orb_extractor_create(const orb_extractor_params* p, int device_id
                     tab[a][hh][b] = in ? 1 : 0;
                     tab[a][hh][16 + b] = in ? (uint8_t)(u + 15) : 0;
                 }
-        if (hipMemcpy(h->dAngTab.p, tab, sizeof(tab), hipMemcpyHostToDevice) != hipSuccess) rc = ORB_ERR_HIP;
+        if (orb_copy_blocking(h->dAngTab.p, tab, sizeof(tab), hipMemcpyHostToDevice, h->stream) != hipSuccess) rc = ORB_ERR_HIP;
         uint32_t hb[768];
         orb_desc_hblur_table(hb);
-        if (rc == ORB_OK && hipMemcpy((uint8_t*)h->dAngTab.p + sizeof(tab), hb, sizeof(hb), hipMemcpyHostToDevice) != hipSuccess) rc = ORB_ERR_HIP;
+        if (rc == ORB_OK && orb_copy_blocking((uint8_t*)h->dAngTab.p + sizeof(tab), hb, sizeof(hb), hipMemcpyHostToDevice, h->stream) != hipSuccess) rc = ORB_ERR_HIP;
     }
-    if (rc != ORB_OK) { orb_extractor_destroy(h); return rc; }
+    if (rc != ORB_OK) { orb_set_error("extractor tables: upload failed: %s", hipGetErrorString(hipGetLastError())); orb_extractor_destroy(h); return rc; }
     h->patternPtr = (const int8_t*)h->dPattern.p;
     *out = h;
     return ORB_OK;
@@ -548,10 +548,10 @@ extern "C" int orb_extractor_sync(orb_extractor* h)
     ORB_HIP_TRY(hipStreamSynchronize(h->stream));
     if (h->lastFrames > 0 && !h->statFetched) {
         h->hStat.resize(orb_extractor::statInts(h->lastFrames));
-        ORB_HIP_TRY(hipMemcpy(h->hStat.data(), h->dStat.p, h->hStat.size() * 4, hipMemcpyDeviceToHost));
+        ORB_HIP_TRY(orb_copy_blocking(h->hStat.data(), h->dStat.p, h->hStat.size() * 4, hipMemcpyDeviceToHost, h->stream));
         h->statFetched = true;
         h->statSerial = 0;
-        if (h->hStat[orb_extractor::kStickyInts - 1]) ORB_HIP_TRY(hipMemset(h->dStat.p, 0, orb_extractor::kStickyInts * 4));
+        if (h->hStat[orb_extractor::kStickyInts - 1]) ORB_HIP_TRY(orb_fill_blocking(h->dStat.p, 0, orb_extractor::kStickyInts * 4, h->stream));
         return orb_check_status(h);
     }
     return ORB_OK;
@@ -680,9 +680,27 @@ extern "C" int orb_extract_batch(orb_extractor* h, const uint8_t* imgs, int nFra
             else if (g) (void)hipGraphDestroy(g);
         }
         if (!ok) {                                             // stay eager for the rest of the handle's life
+            if (std::getenv("ORB_DEBUG_CAPTURE")) {
+                hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+                const hipError_t q = hipStreamIsCapturing(h->stream, &cs);
+                std::fprintf(stderr, "[orb] capture failed on handle %p: last error '%s', isCapturing -> %s, status %d; message '%s'\n", (void*)h,
+                             hipGetErrorString(hipPeekAtLastError()), hipGetErrorString(q), (int)cs, orb_last_error());
+            }
             (void)hipGetLastError();
             Gr.broken = true;
             Gr.exec = nullptr;
+            // a capture that something outside this library invalidated can leave the stream in the "invalidated" state even
+            // after hipStreamEndCapture (seen on ROCm 7.2: every later launch on it fails): the stream is idle here, replace it
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(h->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+                (void)hipGetLastError();
+                hipStream_t fresh = nullptr;
+                if (hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) == hipSuccess) {
+                    (void)hipStreamDestroy(h->stream);
+                    h->stream = fresh;
+                }
+                (void)hipGetLastError();
+            }
         }
     }
     if (sameKey && Gr.exec) {
@@ -714,7 +732,7 @@ extern "C" int orb_extract_batch(orb_extractor* h, const uint8_t* imgs, int nFra
     h->hStat.assign((const int*)stg, (const int*)stg + orb_extractor::statInts(nFrames));
     h->statFetched = true;
     h->statSerial = 0;                                         // = the batch just run
-    if (h->hStat[orb_extractor::kStickyInts - 1]) ORB_HIP_TRY(hipMemset(h->dStat.p, 0, orb_extractor::kStickyInts * 4));
+    if (h->hStat[orb_extractor::kStickyInts - 1]) ORB_HIP_TRY(orb_fill_blocking(h->dStat.p, 0, orb_extractor::kStickyInts * 4, h->stream));
     std::memcpy(counts, stg + statB, cntB);
     if ((rc = orb_check_status(h)) != ORB_OK) return rc;
     for (int f = 0; f < nFrames; f++) {
@@ -829,11 +847,11 @@ extern "C" int orb_get_level_counts(orb_extractor* h, int frame, int32_t* kept, 
     ORB_HIP_TRY(hipStreamSynchronize(h->stream));
     int32_t buf[ORB_MAX_LEVELS];
     if (kept) {
-        ORB_HIP_TRY(hipMemcpy(buf, h->kpCountP() + (size_t)ORB_MAX_LEVELS * frame, sizeof(buf), hipMemcpyDeviceToHost));
+        ORB_HIP_TRY(orb_copy_blocking(buf, h->kpCountP() + (size_t)ORB_MAX_LEVELS * frame, sizeof(buf), hipMemcpyDeviceToHost, h->stream));
         for (int l = 0; l < h->prm.nlevels; l++) kept[l] = buf[l];
     }
     if (cands) {
-        ORB_HIP_TRY(hipMemcpy(buf, h->candCountP() + (size_t)ORB_MAX_LEVELS * frame, sizeof(buf), hipMemcpyDeviceToHost));
+        ORB_HIP_TRY(orb_copy_blocking(buf, h->candCountP() + (size_t)ORB_MAX_LEVELS * frame, sizeof(buf), hipMemcpyDeviceToHost, h->stream));
         for (int l = 0; l < h->prm.nlevels; l++) cands[l] = buf[l];
     }
     return ORB_OK;

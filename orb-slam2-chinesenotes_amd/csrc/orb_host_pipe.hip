@@ -229,6 +229,6 @@ int orb_extract_batch_pipelined(orb_extractor* h, const uint8_t* imgs, int nFram
     h->lastFrames = nFrames - h->frameBase;
     h->statFetched = true;
     const int hadSticky = h->hStat.empty() ? 0 : h->hStat[orb_extractor::kStickyInts - 1];
-    if (hadSticky) ORB_HIP_TRY(hipMemset(h->dStat.p, 0, orb_extractor::kStickyInts * 4));
+    if (hadSticky) ORB_HIP_TRY(orb_fill_blocking(h->dStat.p, 0, orb_extractor::kStickyInts * 4, h->stream));
     return ORB_OK;
 }

@@ -223,10 +223,15 @@ extern "C" int orb_vocab_create(int device, const uint8_t* node_desc, const int3
         orb_vocab_destroy(v);
         return rc;
     }
-    if (hipMemcpy(v->slotDesc.p, sdesc.data(), (size_t)32 * nSlots, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(v->slotKids.p, kids.data(), (size_t)8 * nSlots, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(v->slotNode.p, slotNode.data(), (size_t)4 * nSlots, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(v->slotWord.p, sword.data(), (size_t)4 * nSlots, hipMemcpyHostToDevice) != hipSuccess) {
+    // (uploads through a stream of their own, not the null stream: see orb_copy_blocking)
+    hipStream_t up = nullptr;
+    bool upOk = hipStreamCreateWithFlags(&up, hipStreamNonBlocking) == hipSuccess;
+    upOk = upOk && orb_copy_blocking(v->slotDesc.p, sdesc.data(), (size_t)32 * nSlots, hipMemcpyHostToDevice, up) == hipSuccess &&
+           orb_copy_blocking(v->slotKids.p, kids.data(), (size_t)8 * nSlots, hipMemcpyHostToDevice, up) == hipSuccess &&
+           orb_copy_blocking(v->slotNode.p, slotNode.data(), (size_t)4 * nSlots, hipMemcpyHostToDevice, up) == hipSuccess &&
+           orb_copy_blocking(v->slotWord.p, sword.data(), (size_t)4 * nSlots, hipMemcpyHostToDevice, up) == hipSuccess;
+    if (up) (void)hipStreamDestroy(up);
+    if (!upOk) {
         orb_set_error("vocabulary upload failed: %s", hipGetErrorString(hipGetLastError()));
         orb_vocab_destroy(v);
         return ORB_ERR_HIP;
@@ -260,7 +265,11 @@ static int compact_table(orb_vocab* v, int levelsup, const int32_t** dTab, int* 
         std::pair<MBuf, int> entry;
         int rc = entry.first.ensure((size_t)4 * nSlots);
         if (rc != ORB_OK) return rc;
-        if (hipMemcpy(entry.first.p, tabSlot.data(), (size_t)4 * nSlots, hipMemcpyHostToDevice) != hipSuccess) {
+        hipStream_t up = nullptr;
+        const bool upOk = hipStreamCreateWithFlags(&up, hipStreamNonBlocking) == hipSuccess &&
+                          orb_copy_blocking(entry.first.p, tabSlot.data(), (size_t)4 * nSlots, hipMemcpyHostToDevice, up) == hipSuccess;
+        if (up) (void)hipStreamDestroy(up);
+        if (!upOk) {
             entry.first.release();
             orb_set_error("vocabulary level table upload failed");
             return ORB_ERR_HIP;

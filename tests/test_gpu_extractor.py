@@ -197,6 +197,50 @@ def test_two_handles_two_threads():
         assert res[i][0].tobytes() == rk.tobytes() and np.array_equal(res[i][1], rd)
 
 
+def test_two_threads_while_a_third_creates_and_destroys_handles():
+    """The stereo pair of threads again, while a third thread creates, uses once and destroys handles: handle set-up used to
+    upload its tables through the legacy null stream, which fails -- and invalidates the graph capture another thread is
+    in the middle of -- on ROCm 7.2 (seen as a flaky ORB_ERR_HIP in the test above when the garbage collector destroyed
+    handles of earlier tests meanwhile).  Everything must succeed, results bit-exact."""
+    import threading
+    imgs = [synth.synth_frame(40), synth.synth_frame(41)]
+    small = [np.ascontiguousarray(im[:240, :320]) for im in imgs]
+    ref = oracle.Extractor()
+    want = [ref.extract(im) for im in imgs]
+    for rnd in range(6):
+        res, errs, stop = [None, None], [None, None, None], [False]
+
+        def work(i):
+            try:
+                ex = capi.Extractor()
+                for _ in range(6):
+                    res[i] = ex.extract(imgs[i])
+            except BaseException as e:
+                errs[i] = e
+
+        def churn():
+            try:
+                k = 0
+                while not stop[0]:
+                    e = capi.Extractor(nfeatures=300 + 50 * (k % 3))
+                    e.extract(small[k & 1])
+                    del e
+                    k += 1
+            except BaseException as e:
+                errs[2] = e
+
+        tc = threading.Thread(target=churn)
+        tc.start()
+        ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        stop[0] = True
+        tc.join()
+        assert errs == [None, None, None], (rnd, errs)
+        for i in range(2):
+            assert res[i][0].tobytes() == want[i][0].tobytes() and np.array_equal(res[i][1], want[i][1])
+
+
 @pytest.mark.parametrize("w,h,levels", [(160, 120, 8), (100, 100, 8), (97, 64, 6), (70, 70, 3)])
 def test_tiny_images_with_degenerate_levels(w, h, levels):
     # upper pyramid levels shrink below the 30-px cell grid / the 32-px border (the reference would divide by zero

@@ -123,3 +123,20 @@ extern "C" int orb_good(orb_matcher* m)
     assert [f[1] for f in funcs] == ["helper", "orb_bad", "orb_good"] and [f[0] for f in funcs] == [False, True, True]
     assert _first_device_call(funcs[1][3], {"helper"})[1] == "helper"
     assert _first_device_call(funcs[2][3], {"helper"})[1] == "hipSetDevice"
+
+
+def test_no_legacy_stream_operations_in_the_library():
+    """hipMemcpy / hipMemset / hipMemcpy2D (the synchronous forms) and hipDeviceSynchronize go through the legacy null stream.
+    On ROCm 7.2 they FAIL while any stream of the process is being captured into a graph -- and invalidate that capture --,
+    even a thread-local capture of another thread's non-blocking stream: with two extractor handles on two threads
+    (reference src/Frame.cc:82-85) one thread's table upload met the other thread's capture of its single-frame chain.
+    The library copies through a stream of the caller's (orb_copy_blocking / orb_fill_blocking, csrc/orb_common.h)."""
+    import glob
+    import re
+    bad = []
+    pat = re.compile(r"\b(hipMemcpy|hipMemset|hipMemcpy2D|hipMemcpyToSymbol|hipMemcpyFromSymbol|hipDeviceSynchronize)\s*\(")
+    for path in sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h"))):
+        for ln, line in enumerate(_strip(open(path).read()).splitlines(), 1):
+            if pat.search(line):
+                bad.append("%s:%d: %s" % (os.path.basename(path), ln, line.strip()[:100]))
+    assert not bad, "\n".join(bad)
