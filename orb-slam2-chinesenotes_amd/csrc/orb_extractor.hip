@@ -209,6 +209,8 @@ extern "C" int orb_extractor_create(const orb_extractor_params* p, int device_id
         if (orb_copy_blocking(h->dPattern.p, ORB_BRIEF_PATTERN_XY, 1024, hipMemcpyHostToDevice, h->stream) != hipSuccess) rc = ORB_ERR_HIP;
     }
     if (rc == ORB_OK) rc = h->dPatternF.ensure(256 * 16);
+    if (rc == ORB_OK) rc = h->dDone.ensure((size_t)orb_extractor::kDoneFrames * ORB_MAX_LEVELS * 4);
+    if (rc == ORB_OK && hipMemsetAsync(h->dDone.p, 0, h->dDone.bytes, h->stream) != hipSuccess) rc = ORB_ERR_HIP;   // (ordered before every launch of the handle)
     if (rc == ORB_OK) rc = h->dAngTab.ensure(16 * 2 * 32 + 768 * 4);     // + the descriptor kernel's horizontal-blur item table
     if (rc == ORB_OK) {
         // IC_Angle tables (k_orient_desc): per (|v|, half row) 16 mask bytes (1 inside |u| <= umax[|v|]) and
@@ -243,7 +245,7 @@ extern "C" void orb_extractor_destroy(orb_extractor* h)
     }
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    DevBuf* bufs[] = {&h->dPattern, &h->dPatternF, &h->dAngTab, &h->dCells, &h->dXtab, &h->dYtab, &h->dXq, &h->dPath, &h->dBand, &h->dPyr, &h->dCand, &h->dKpl, &h->dOvf, &h->dQt,
+    DevBuf* bufs[] = {&h->dPattern, &h->dPatternF, &h->dAngTab, &h->dDone, &h->dCells, &h->dXtab, &h->dYtab, &h->dXq, &h->dPath, &h->dBand, &h->dPyr, &h->dCand, &h->dKpl, &h->dOvf, &h->dQt,
                       &h->dStat, &h->dImgs, &h->dKps, &h->dDesc, &h->dCounts,
                       &h->dStereo, &h->dStereoIn};
     for (DevBuf* b : bufs) b->release();
@@ -489,10 +491,19 @@ extern "C" int orb_extract_batch_device(orb_extractor* h, const uint8_t* d_imgs,
     }
     }
     if (prof) ORB_HIP_TRY(hipEventRecord(pe[1], st));
-    orb_launch_fast_strips(st, G, pyr, h->pyrSlab, (const OrbStrip*)h->dCells.p, (int)h->strips.size(),
+    // single frames without the dense launch: the last FAST workgroup of a level runs the level's quadtree (one launch less)
+    OrbFastFuse fuse{};
+    const bool wantFuse = h->specNoDense && !h->qtGlobal && n <= orb_extractor::kDoneFrames && h->dDone.p;
+    if (wantFuse) {
+        fuse.kpl = skpl; fuse.kpCount = skc; fuse.done = (int*)h->dDone.p; fuse.sortCap = h->sortCap; fuse.nodeCap = h->nodeCap;
+        for (const OrbStrip& sp : h->strips) fuse.stripsOfLevel[sp.level]++;
+    }
+    const bool qtDone = orb_launch_fast_strips(st, G, pyr, h->pyrSlab, (const OrbStrip*)h->dCells.p, (int)h->strips.size(),
                            (const uint32_t*)h->dPath.p, scand, h->candSlab, scc, serr, h->ovfCountP(), (int*)h->dOvf.p,
-                           h->prm.ini_th_fast, h->prm.min_th_fast, h->fastPdw, h->fastRows, h->fastSdw, h->fastCandCap, n, h->fastP, h->specNoDense);
+                           h->prm.ini_th_fast, h->prm.min_th_fast, h->fastPdw, h->fastRows, h->fastSdw, h->fastCandCap, n, h->fastP, h->specNoDense,
+                           wantFuse ? &fuse : nullptr);
     if (prof) ORB_HIP_TRY(hipEventRecord(pe[2], st));
+    if (!qtDone)
     orb_launch_quadtree(st, G, scand, h->candSlab, scc, skpl, skc, serr, h->sortCap, h->nodeCap, n, h->ovfCountP(),
                         h->qtGlobal ? (unsigned char*)h->dQt.p : nullptr);
     if (prof) ORB_HIP_TRY(hipEventRecord(pe[3], st));

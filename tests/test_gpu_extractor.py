@@ -648,12 +648,16 @@ def test_every_pyramid_chain_variant_on_the_same_frames(monkeypatch, variant, w,
     ex.close()
 
 
-@pytest.mark.parametrize("knob", ["ORB_NO_GRAPH", "ORB_NO_ZEROCOPY", "ORB_NO_SPEC", "ORB_NO_ZEROCOPY+ORB_NO_GRAPH"])
+@pytest.mark.parametrize("knob", ["ORB_NO_GRAPH", "ORB_NO_ZEROCOPY", "ORB_NO_SPEC", "ORB_NO_ZEROCOPY+ORB_NO_GRAPH", "ORB_FUSE_QT",
+                                  "ORB_FAST_MW=0", "ORB_FUSE_QT+ORB_NO_GRAPH", "ORB_FAST_MW=0+ORB_NO_SPEC"])
 def test_single_frame_path_switches_do_not_change_results(monkeypatch, knob):
-    """The single-frame host call has three accelerations that can be switched off one by one (graph replay, zero-copy pinned
-    staging, the chain without the dense-strip launch): every combination returns what the oracle returns, call after call."""
+    """The single-frame host call has accelerations that can be switched off one by one (graph replay, zero-copy pinned
+    staging, the chain without the dense-strip launch, four waves per FAST strip) and one that can be switched on (ORB_FUSE_QT: the
+    quadtree of a level run by the FAST workgroup that finishes the level's last strip):
+    every combination returns what the oracle returns, call after call."""
     for k in knob.split("+"):
-        monkeypatch.setenv(k, "1")
+        name, _, val = k.partition("=")
+        monkeypatch.setenv(name, val or "1")
     imgs = [synth.synth_frame(50), synth.synth_natural(51), np.random.default_rng(52).integers(0, 256, (480, 640)).astype(np.uint8)]
     ref = oracle.Extractor()
     want = [ref.extract(im) for im in imgs]
