@@ -165,8 +165,32 @@ def lib():
     L.orb_shard_range.restype = None
     L.orb_last_error.restype = C.c_char_p
     L.orb_version.restype = C.c_char_p
+    if ORDER_BEHIND_TORCH:
+        _order_behind_torch(L)
     _lib = L
     return L
+
+
+# The library's streams are non-blocking: nothing orders them behind work that torch has queued on ITS stream (a fill of an
+# output buffer, an index tensor still being written).  The C contract is the caller's: buffers handed to a *_device entry
+# are ready.  Tests set ORDER_BEHIND_TORCH before the first call, and every entry that takes device pointers then waits for
+# torch's current stream first (bench.py does not: its timed loops order their buffers themselves).
+ORDER_BEHIND_TORCH = False
+
+
+def _order_behind_torch(L):
+    import torch
+
+    def wrap(fn):
+        def call(*a):
+            if torch.cuda.is_initialized():
+                torch.cuda.current_stream().synchronize()
+            return fn(*a)
+        return call
+
+    for name in SYMBOLS:
+        if "_device" in name or name in ("orb_multi_extract_batch", "orb_multi_match_bow_batch", "orb_bow_transform_device"):
+            setattr(L, name, wrap(getattr(L, name)))
 
 
 def _check(rc):

@@ -11,6 +11,10 @@ sys.path.insert(0, ROOT)
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # tests build their device buffers with torch (fills, index tensors: asynchronous on torch's stream) and hand them to the
+    # library, whose streams are non-blocking: every *_device call of the ctypes layer first waits for torch's stream
+    from orbhip import capi
+    capi.ORDER_BEHIND_TORCH = True
 
 
 @pytest.fixture(scope="session")

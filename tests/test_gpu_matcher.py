@@ -597,7 +597,12 @@ def test_c5_full_size_1000_keyframe_db():
     ex, mt = capi.Extractor(), capi.Matcher(0.75, True)
     cap = ex.max_keypoints
     F = n_kf + nq
-    z = lambda n, dt: torch.zeros(n, dtype=dt, device=dev)
+    def z(n, dt):
+        # torch fills on ITS stream; the library's streams are non-blocking and nothing orders them behind it: a fill still in
+        # flight would overwrite what the library writes (seen once as rows of zeros in a result) -- wait for it here
+        t = torch.zeros(n, dtype=dt, device=dev)
+        torch.cuda.synchronize()
+        return t
     d_kps, d_desc, d_counts, d_node = z(F * cap * 28, torch.uint8), z(F * cap * 32, torch.uint8), z(F, torch.int32), z(F * cap, torch.int16)
     valid_np = np.stack([synth.synth_valid_flags(cap, 7000 + i) for i in range(F)])
     d_valid = torch.from_numpy(valid_np).to(dev)
@@ -673,7 +678,12 @@ def test_keyframe_db_sharded_by_keyframe(devices):
     ex, mt = capi.Extractor(600), capi.Matcher(0.75, True)
     cap = ex.max_keypoints
     F = n_kf + 2
-    z = lambda n, dt: torch.zeros(n, dtype=dt, device=dev)
+    def z(n, dt):
+        # torch fills on ITS stream; the library's streams are non-blocking and nothing orders them behind it: a fill still in
+        # flight would overwrite what the library writes (seen once as rows of zeros in a result) -- wait for it here
+        t = torch.zeros(n, dtype=dt, device=dev)
+        torch.cuda.synchronize()
+        return t
     d_kps, d_desc, d_counts, d_node = z(F * cap * 28, torch.uint8), z(F * cap * 32, torch.uint8), z(F, torch.int32), z(F * cap, torch.int16)
     frames = np.concatenate([synth.synth_sequence(0, n_kf, W, H), synth.synth_sequence(11, 1, W, H, noise=5), synth.synth_sequence(26, 1, W, H, noise=4)])
     d_b = torch.from_numpy(frames).to(dev)

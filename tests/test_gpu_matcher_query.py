@@ -63,7 +63,12 @@ def _run(mt, desc, kps, valid, node, counts, n_nodes, kf_list, q_list, use_valid
     F, cap = counts.shape[0], desc.shape[1]
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     d_desc, d_kps, d_valid, d_node, d_counts = t(desc), t(kps.view(np.uint8)), t(valid), t(node.view(np.int16)), t(counts)
-    z = lambda n, dt: torch.zeros(n, dtype=dt, device=dev)
+    def z(n, dt):
+        # torch fills on ITS stream; the library's streams are non-blocking and nothing orders them behind it: a fill still in
+        # flight would overwrite what the library writes (seen once as rows of zeros in a result) -- wait for it here
+        t = torch.zeros(n, dtype=dt, device=dev)
+        torch.cuda.synchronize()
+        return t
     d_ck, d_cs, d_cc, d_cd = z(F * cap, torch.int32), z(F * n_nodes, torch.int16), z(F * n_nodes, torch.int16), z(F * cap * 32, torch.uint8)
     mt.build_csr_desc_device(d_node.data_ptr(), d_counts.data_ptr(), d_desc.data_ptr(), F, cap, n_nodes, d_ck.data_ptr(),
                              d_cs.data_ptr(), d_cc.data_ptr(), d_cd.data_ptr())

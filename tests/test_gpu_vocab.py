@@ -127,6 +127,7 @@ def test_vocab_transform_device_batches_with_ragged_counts(k, L):
     dW = torch.full((F, cap), -7, dtype=torch.int32, device=dev)
     dN = torch.full((F, cap), -7, dtype=torch.int32, device=dev)
     dO = torch.full((F, cap), 0x1234, dtype=torch.int16, device=dev)
+    torch.cuda.synchronize()                                          # (torch's fills are on its own stream)
     m = capi.Matcher()
     v = capi.Vocabulary(tree)
     v.transform_device(m, dD.data_ptr(), dC.data_ptr(), F, cap, levelsup, dW.data_ptr(), dN.data_ptr(), dO.data_ptr())
