@@ -502,7 +502,7 @@ typedef __attribute__((address_space(3))) uint16_t orb_lds_u16;
 __device__ __forceinline__ const orb_lds_u32* lds_dw(unsigned byteAddr) { return reinterpret_cast<const orb_lds_u32*>(byteAddr); }
 __device__ __forceinline__ orb_lds_u16* lds_hw(unsigned byteAddr) { return reinterpret_cast<orb_lds_u16*>(byteAddr); }
 
-template <int P>
+template <int P, int OCC>
 __global__ __launch_bounds__(WAVE) void k_fast_strips_p(const OrbGeom G, const uint8_t* __restrict__ pyr, size_t pyrSlab,
                                                         const OrbStrip* __restrict__ strips,
                                                         const uint32_t* __restrict__ pathTab,
@@ -512,6 +512,12 @@ __global__ __launch_bounds__(WAVE) void k_fast_strips_p(const OrbGeom G, const u
                                                         int minTh, int rowsMax, int candCap, int nStrips, int nFrames,
                                                         unsigned invPerFrame)
 {
+    // OCC: a clobbered high register makes the kernel claim 80 / 96 / 128 VGPRs, i.e. at most 6 / 5 / 4 waves per SIMD (see
+    // orb_launch_fast_strips: 5 balances the CU's SIMDs; 4 -- 48 KB of LDS left to other kernels' workgroups -- was tried for
+    // co-scheduling with the other lanes' kernels and lost: 0.498 ms, step 1.348 against 1.311 ms)
+    if (OCC == 6) asm volatile("" ::: "v79");
+    if (OCC == 5) asm volatile("" ::: "v95");
+    if (OCC == 4) asm volatile("" ::: "v127");
     // dynamic LDS (bytes): [ring A 256 | ring B 256 | pad .. HDR) | tile rowsMax x ROWB | 16 | candPos 2 candCap | candScore candCap]
     extern __shared__ uint32_t fsm[];
     constexpr int ROWB = FastP<P>::ROWB, TB = FastP<P>::HDR;
@@ -1256,6 +1262,12 @@ bool orb_launch_fast_strips(hipStream_t st, const OrbGeom& G, const uint8_t* pyr
     const int mwPin = mwEnv ? std::atoi(mwEnv) : -1;
     const bool mw = (fixedPitch == 28 || fixedPitch == 20) && candCap <= 4096 && orb_fast_mw_lds_bytes(fixedPitch, rowsMax, candCap) <= 64 * 1024 &&
                     (mwPin >= 0 ? mwPin != 0 : (long long)nStrips * nFrames <= 1536);
+    // waves per SIMD of k_fast_strips_p<28> (ORB_FAST_OCC=0|4|5|6): 5 by default.  Its single-wave workgroups are limited by LDS
+    // (7 KB each: 22 per CU), and the dispatcher does not spread 22 waves evenly over the CU's four SIMDs; claiming 96 VGPRs
+    // caps every SIMD at 5 -- 20 per CU, evenly -- and the launch is 3 % SHORTER with fewer waves (0.466 against 0.480 ms per 512
+    // frames, natural content 0.540 against 0.555; 20 waves per CU reached through LDS padding instead: 0.506)
+    static const int occ = [] { const char* e = std::getenv("ORB_FAST_OCC"); return e ? std::atoi(e) : 5; }();
+    static const size_t ldsPad = [] { const char* e = std::getenv("ORB_FAST_LDSPAD"); return e ? (size_t)std::atoi(e) : (size_t)0; }();
     bool fused = false;
     if (mw) {
         FastFuse FZ{};
@@ -1281,12 +1293,12 @@ bool orb_launch_fast_strips(hipStream_t st, const OrbGeom& G, const uint8_t* pyr
 #undef ORB_FAST_MW_LAUNCH
     }
     else
-    if (fixedPitch == 28)
-        hipLaunchKernelGGL(k_fast_strips_p<28>, grid, dim3(WAVE), orb_fast_p_lds_bytes(28, rowsMax, candCap), st, G, pyr, pyrSlab, strips, pathTab,
-                           cand, candSlab, candCount, errFlags, ovfCount, ovfList, iniTh, minTh, rowsMax, candCap, nStrips, nFrames, inv);
-    else if (fixedPitch == 20)
-        hipLaunchKernelGGL(k_fast_strips_p<20>, grid, dim3(WAVE), orb_fast_p_lds_bytes(20, rowsMax, candCap), st, G, pyr, pyrSlab, strips, pathTab,
-                           cand, candSlab, candCount, errFlags, ovfCount, ovfList, iniTh, minTh, rowsMax, candCap, nStrips, nFrames, inv);
+#define ORB_FAST_P_LAUNCH(PP, OO)                                                                                               \
+    hipLaunchKernelGGL((k_fast_strips_p<PP, OO>), grid, dim3(WAVE), orb_fast_p_lds_bytes(PP, rowsMax, candCap) + ldsPad, st, G, pyr, pyrSlab, strips, pathTab, \
+                       cand, candSlab, candCount, errFlags, ovfCount, ovfList, iniTh, minTh, rowsMax, candCap, nStrips, nFrames, inv)
+    if (fixedPitch == 28) { if (occ == 4) ORB_FAST_P_LAUNCH(28, 4); else if (occ == 5) ORB_FAST_P_LAUNCH(28, 5); else if (occ == 6) ORB_FAST_P_LAUNCH(28, 6); else ORB_FAST_P_LAUNCH(28, 0); }
+    else if (fixedPitch == 20) ORB_FAST_P_LAUNCH(20, 0);
+#undef ORB_FAST_P_LAUNCH
     else
     hipLaunchKernelGGL(k_fast_strips, grid, dim3(WAVE),
                        orb_fast_lds_bytes(pdw, rowsMax, candCap), st, G, pyr, pyrSlab, strips, pathTab, cand, candSlab,
