@@ -24,6 +24,7 @@ struct orb_vocab {
     MBuf slotWord;          // int32 per slot: word id of the slot's node (one load at the end of a descent, not two)
     std::vector<int> depth;                         // host: depth of every node
     int maxKids = 0;                                // largest number of children of a node
+    int nTop = 0;                                   // slots of depth <= 2 (a prefix of the breadth-first order), at most 400: staged in LDS by the descent
     std::vector<int32_t> slotNodeHost;              // host copy of slotNode
     std::map<int, std::pair<MBuf, int>> compact;    // levelsup -> (device int32 compactOfSlot[nSlots], K)
 };
@@ -107,8 +108,16 @@ __global__ __launch_bounds__(256) void k_vocab_transform_k16(const uint4* __rest
                                                              const uint8_t* __restrict__ desc,
                                                              const int32_t* __restrict__ counts, int cap,
                                                              int32_t* __restrict__ wordOf, int32_t* __restrict__ nodeId,
-                                                             uint16_t* __restrict__ nodeOf)
+                                                             uint16_t* __restrict__ nodeOf, int nTop)
 {
+    // The first nTop slots (breadth-first: the root and the top two levels, 111 nodes of 40 bytes for k = 10) are staged in
+    // LDS: two of a descent's six levels then cost no global load at all (the kernel is bound by the memory side: a third
+    // of its 16-byte lanes through the texture path gone)
+    extern __shared__ uint4 vsm[];
+    int2* kidsL = reinterpret_cast<int2*>(vsm + 2 * nTop);
+    for (int i = threadIdx.x; i < 2 * nTop; i += 256) vsm[i] = slotDesc[i];
+    for (int i = threadIdx.x; i < nTop; i += 256) kidsL[i] = slotKids[i];
+    if (nTop) __syncthreads();
     const int f = blockIdx.y, r = threadIdx.x & 15, rowIdx = threadIdx.x >> 4;
     const int base = blockIdx.x * (16 * NF);
     const int n = counts ? min(counts[f], cap) : cap;
@@ -137,9 +146,15 @@ __global__ __launch_bounds__(256) void k_vocab_transform_k16(const uint4* __rest
 #pragma unroll
         for (int j = 0; j < NF; j++) {                            // all loads of this level
             const int s2 = kids[j].x + min(r, max(kids[j].y - 1, 0));
-            nl[j] = slotDesc[(size_t)s2 * 2];
-            nh[j] = slotDesc[(size_t)s2 * 2 + 1];
-            mine[j] = slotKids[s2];
+            if (s2 < nTop) {
+                nl[j] = vsm[2 * s2];
+                nh[j] = vsm[2 * s2 + 1];
+                mine[j] = kidsL[s2];
+            } else {
+                nl[j] = slotDesc[(size_t)s2 * 2];
+                nh[j] = slotDesc[(size_t)s2 * 2 + 1];
+                mine[j] = slotKids[s2];
+            }
         }
 #pragma unroll
         for (int j = 0; j < NF; j++) {
@@ -217,6 +232,8 @@ extern "C" int orb_vocab_create(int device, const uint8_t* node_desc, const int3
     if (!v) return ORB_ERR_INTERNAL;
     v->device = device; v->nNodes = n_nodes; v->L = L; v->depth = depth; v->slotNodeHost = slotNode;
     for (int i = 0; i < n_nodes; i++) v->maxKids = std::max(v->maxKids, child_begin[i + 1] - child_begin[i]);
+    while (v->nTop < nSlots && v->nTop < 400 && depth[order[v->nTop]] <= 2) v->nTop++;
+    if (std::getenv("ORB_VOCAB_NO_LDS")) v->nTop = 0;
     int rc;
     if ((rc = v->slotDesc.ensure((size_t)32 * nSlots)) != ORB_OK || (rc = v->slotKids.ensure((size_t)8 * nSlots)) != ORB_OK ||
         (rc = v->slotNode.ensure((size_t)4 * nSlots)) != ORB_OK || (rc = v->slotWord.ensure((size_t)4 * nSlots)) != ORB_OK) {
@@ -306,9 +323,9 @@ extern "C" int orb_bow_transform_device(orb_matcher* m, orb_vocab* v, const uint
         if (K > 65534) { orb_set_error("more than 65534 vocabulary nodes at that level"); return ORB_ERR_UNSUPPORTED; }
     }
     if (v->maxKids <= 16)
-        hipLaunchKernelGGL(k_vocab_transform_k16<2>, dim3((cap + 31) / 32, n_frames), dim3(256), 0, m->stream,
+        hipLaunchKernelGGL(k_vocab_transform_k16<2>, dim3((cap + 31) / 32, n_frames), dim3(256), (size_t)v->nTop * 40, m->stream,
                            (const uint4*)v->slotDesc.p, (const int2*)v->slotKids.p, (const int32_t*)v->slotNode.p,
-                           (const int32_t*)v->slotWord.p, v->L - levelsup, tab, d_desc, d_counts, cap, d_word_of, d_node_id, d_node_of);
+                           (const int32_t*)v->slotWord.p, v->L - levelsup, tab, d_desc, d_counts, cap, d_word_of, d_node_id, d_node_of, v->nTop);
     else
         hipLaunchKernelGGL(k_vocab_transform, dim3((cap + 15) / 16, n_frames), dim3(256), 0, m->stream,
                            (const uint4*)v->slotDesc.p, (const int2*)v->slotKids.p, (const int32_t*)v->slotNode.p,
