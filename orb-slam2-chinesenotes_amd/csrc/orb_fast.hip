@@ -1267,7 +1267,6 @@ bool orb_launch_fast_strips(hipStream_t st, const OrbGeom& G, const uint8_t* pyr
     // caps every SIMD at 5 -- 20 per CU, evenly -- and the launch is 3 % SHORTER with fewer waves (0.466 against 0.480 ms per 512
     // frames, natural content 0.540 against 0.555; 20 waves per CU reached through LDS padding instead: 0.506)
     static const int occ = [] { const char* e = std::getenv("ORB_FAST_OCC"); return e ? std::atoi(e) : 5; }();
-    static const size_t ldsPad = [] { const char* e = std::getenv("ORB_FAST_LDSPAD"); return e ? (size_t)std::atoi(e) : (size_t)0; }();
     bool fused = false;
     if (mw) {
         FastFuse FZ{};
@@ -1294,7 +1293,7 @@ bool orb_launch_fast_strips(hipStream_t st, const OrbGeom& G, const uint8_t* pyr
     }
     else
 #define ORB_FAST_P_LAUNCH(PP, OO)                                                                                               \
-    hipLaunchKernelGGL((k_fast_strips_p<PP, OO>), grid, dim3(WAVE), orb_fast_p_lds_bytes(PP, rowsMax, candCap) + ldsPad, st, G, pyr, pyrSlab, strips, pathTab, \
+    hipLaunchKernelGGL((k_fast_strips_p<PP, OO>), grid, dim3(WAVE), orb_fast_p_lds_bytes(PP, rowsMax, candCap), st, G, pyr, pyrSlab, strips, pathTab, \
                        cand, candSlab, candCount, errFlags, ovfCount, ovfList, iniTh, minTh, rowsMax, candCap, nStrips, nFrames, inv)
     if (fixedPitch == 28) { if (occ == 4) ORB_FAST_P_LAUNCH(28, 4); else if (occ == 5) ORB_FAST_P_LAUNCH(28, 5); else if (occ == 6) ORB_FAST_P_LAUNCH(28, 6); else ORB_FAST_P_LAUNCH(28, 0); }
     else if (fixedPitch == 20) ORB_FAST_P_LAUNCH(20, 0);
