@@ -158,15 +158,19 @@ __global__ __launch_bounds__(QK_THREADS) void k_match_bow_query(orb_featstore S,
     }
     for (int n = t; n < nNodes; n += QK_HALF) firstAcc[n] = 0xFFFFFFFFu;      // (again after every phase 2)
 
+    // The first group of a workgroup is its own index (all workgroups of a launch used to ask the counter for it within the same
+    // microsecond: ~512 returning atomics on one address, served one after the other); the groups after it come from the
+    // counter when the workgroup is free -- asking for the next group EARLY, behind the current one's work, was measured and
+    // lost 4 us: a workgroup that drew an expensive keyframe then sits on a group that idle workgroups could have taken.
     __shared__ int nextGroup;
     const int nGroups = (nKf + QK_G - 1) / QK_G;
     if (blockIdx.x == 0 && tid == 0) ctrToClear[q] = 0;            // (the counter a later launch will use; this launch's is groupCtr[q])
     int iter = 0;
     QK_STAMP(0);
     for (;; iter++) {
-        if (tid == 0) nextGroup = (int)atomicAdd(&groupCtr[q], 1u);
+        if (iter > 0 && tid == 0) nextGroup = (int)gridDim.x + (int)atomicAdd(&groupCtr[q], 1u);
         __syncthreads();
-        const int s0 = nextGroup;
+        const int s0 = iter == 0 ? (int)blockIdx.x : nextGroup;
         if (s0 >= nGroups) break;
         const int slot = s0 + g * nGroups;
         const size_t pair = (size_t)q * nKf + (size_t)min(slot, nKf - 1);
