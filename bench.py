@@ -103,6 +103,8 @@ def parse():
     ap.add_argument("--c5-bow-early", action="store_true", help="config 5: vocabulary descent + feature vector of a frame behind its extraction "
                     "(own handle per extractor) instead of in front of its search (measured slower)")
     ap.add_argument("--c5-extractors", type=int, default=2, help="config 5: extractor handles that consecutive stream frames alternate between")
+    ap.add_argument("--c5-three-calls", action="store_true", help="config 5: ComputeBoW and the search as three calls of the C ABI "
+                    "(descent, feature vector, search) instead of the fused orb_bow_query_frames_device")
     ap.add_argument("--c5-matchers", type=int, default=1, help="config 5: matcher handles that consecutive stream frames alternate between")
     ap.add_argument("--c5-slots", type=int, default=4, help="config 5: query slots in the ring between the extractor and the matcher stream")
     ap.add_argument("--stream-frames", type=int, default=256,
@@ -856,6 +858,11 @@ def run_c5(args, rank, local_rank, world, dev, comm_dev, dist):
         s, q = i % NSLOT, Q[0]
         f0 = n_kf + s * QMAX
         mt = mts[i % NMT]
+        if not bow_early and between is None and not args.c5_pair_kernel and not args.c5_three_calls:
+            # Frame::ComputeBoW + the 1000 matchings in ONE call of the C ABI (orb_bow_query_frames_device): what a C++
+            # caller's loop body costs the host, not three trips through the interpreter
+            mt.bow_query_frames_device(voc, store, f0, q, 4, kf_idx.data_ptr(), n_kf, f_idx[s].data_ptr(), d_match[s].data_ptr(), d_nm[s].data_ptr())
+            return
         if not bow_early:
             compute_bow(mt, f0, q)
         if between is not None:

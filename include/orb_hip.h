@@ -372,6 +372,17 @@ int orb_bow_transform(orb_matcher* m, orb_vocab* v, const uint8_t* desc, int n, 
 int orb_bow_transform_device(orb_matcher* m, orb_vocab* v, const uint8_t* d_desc, const int32_t* d_counts, int n_frames,
                              int cap, int levelsup, int32_t* d_word_of, int32_t* d_node_id, uint16_t* d_node_of);
 
+/* Frame::ComputeBoW of the query frames + the search, in ONE call: the body of the Relocalization loop as the reference
+ * runs it per frame (src/Tracking.cc:1471-1492: mCurrentFrame.ComputeBoW(), then SearchByBoW per candidate keyframe).
+ * Frames [first_query, first_query + n_queries) of the store already hold descriptors, keypoints and counts (written by
+ * orb_extract_batch_device); this call fills their node_of / csr_* rows IN THE STORE (orb_bow_transform_device with
+ * `levelsup`, orb_bow_build_csr_desc_device -- the store's pointers are written through) and then runs
+ * orb_match_bow_query_device with d_f_index.  Same results as the three calls; two host round trips less per frame. */
+int orb_bow_query_frames_device(orb_matcher* m, orb_vocab* v, const orb_featstore* store, int first_query, int n_queries,
+                                int levelsup, const int32_t* d_kf_index, int n_kf, const int32_t* d_f_index, float ratio,
+                                int check_ori, int32_t* d_match, int32_t* d_nmatches);
+
+
 /* ---------------------------------------------------------------- stereo search -------------
  * Additional entry point (Frame.cc links unchanged and keeps its own CPU body): the whole of
  * void Frame::ComputeStereoMatches(), reference src/Frame.cc:513-699, on the pyramids that the LEFT and

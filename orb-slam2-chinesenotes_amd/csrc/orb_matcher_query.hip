@@ -541,3 +541,27 @@ extern "C" int orb_match_bow_query_device(orb_matcher* m, const orb_featstore* s
     ORB_HIP_TRY(hipGetLastError());
     return ORB_OK;
 }
+
+// Frame::ComputeBoW of the query frames (descent + feature vector, written into the store) and the search, one call
+// (reference src/Tracking.cc:1471-1492 per frame: ComputeBoW, then SearchByBoW against every candidate keyframe).
+extern "C" int orb_bow_query_frames_device(orb_matcher* m, orb_vocab* v, const orb_featstore* store, int first_query, int n_queries,
+                                           int levelsup, const int32_t* d_kf_index, int n_kf, const int32_t* d_f_index, float ratio,
+                                           int check_ori, int32_t* d_match, int32_t* d_nmatches)
+{
+    if (!m || !v || !store || first_query < 0 || n_queries < 0 || first_query + n_queries > store->n_frames) return ORB_ERR_INVALID;
+    if (!store->desc || !store->counts || !store->node_of || !store->csr_keys || !store->csr_start || !store->csr_cnt || !store->csr_desc ||
+        store->cap <= 0 || store->n_nodes <= 0)
+        return ORB_ERR_INVALID;
+    ORB_HIP_TRY(hipSetDevice(m->device));
+    if (n_queries == 0) return ORB_OK;
+    const size_t cap = (size_t)store->cap, f0 = (size_t)first_query, nn = (size_t)store->n_nodes;
+    int rc = orb_bow_transform_device(m, v, store->desc + f0 * cap * 32, store->counts + f0, n_queries, store->cap, levelsup, nullptr, nullptr,
+                                      const_cast<uint16_t*>(store->node_of) + f0 * cap);
+    if (rc != ORB_OK) return rc;
+    rc = orb_bow_build_csr_desc_device(m, store->node_of + f0 * cap, store->counts + f0, store->desc + f0 * cap * 32, n_queries, store->cap,
+                                       store->n_nodes, const_cast<uint32_t*>(store->csr_keys) + f0 * cap,
+                                       const_cast<uint16_t*>(store->csr_start) + f0 * nn, const_cast<uint16_t*>(store->csr_cnt) + f0 * nn,
+                                       const_cast<uint8_t*>(store->csr_desc) + f0 * cap * 32);
+    if (rc != ORB_OK) return rc;
+    return orb_match_bow_query_device(m, store, d_kf_index, n_kf, d_f_index, n_queries, ratio, check_ori, d_match, d_nmatches);
+}

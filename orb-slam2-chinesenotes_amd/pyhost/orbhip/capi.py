@@ -65,7 +65,7 @@ SYMBOLS = [
     "orb_hamming", "orb_three_maxima", "orb_matcher_create", "orb_matcher_destroy", "orb_matcher_sync",
     "orb_match_bow", "orb_match_bow_kk", "orb_match_init", "orb_match_projection", "orb_match_projection_best", "orb_match_triangulation", "orb_vocab_create", "orb_vocab_destroy", "orb_vocab_level_nodes", "orb_bow_transform",
     "orb_bow_transform_device", "orb_distinctive_descriptors", "orb_distinctive_descriptors_device", "orb_bow_assign_device", "orb_match_bow_batch_device", "orb_bow_build_csr_device",
-    "orb_bow_build_csr_desc_device", "orb_match_bow_query_device", "orb_matcher_set_stage_stamps", "orb_gaussian_preset", "orb_extractor_set_gaussian",
+    "orb_bow_build_csr_desc_device", "orb_match_bow_query_device", "orb_bow_query_frames_device", "orb_matcher_set_stage_stamps", "orb_gaussian_preset", "orb_extractor_set_gaussian",
     "orb_matcher_stream", "orb_stereo_match", "orb_stereo_match_device", "orb_stereo_match_batch_device", "orb_extractor_wait_for", "orb_matcher_wait_for", "orb_last_error", "orb_version", "orb_abi_version", "orb_sizeof_featstore", "orb_multi_create", "orb_multi_destroy", "orb_multi_devices", "orb_multi_handle",
     "orb_multi_set_pattern", "orb_multi_extract_batch", "orb_shard_range", "orb_multi_db_create", "orb_multi_db_destroy",
     "orb_multi_db_shards", "orb_multi_match_bow_batch",
@@ -141,6 +141,7 @@ def lib():
     L.orb_bow_build_csr_desc_device.argtypes = [vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp]
     L.orb_matcher_set_stage_stamps.argtypes = [vp, vp, C.c_size_t]
     L.orb_match_bow_query_device.argtypes = [vp, C.POINTER(FeatStoreC), vp, ci, vp, ci, cf, ci, vp, vp]
+    L.orb_bow_query_frames_device.argtypes = [vp, vp, C.POINTER(FeatStoreC), ci, ci, ci, vp, ci, vp, cf, ci, vp, vp]
     L.orb_matcher_stream.argtypes = [vp]
     L.orb_matcher_stream.restype = vp
     L.orb_extractor_wait_for.argtypes = [vp, vp]
@@ -596,6 +597,14 @@ class Matcher:
         s = self._store(store)
         _check(self.L.orb_match_bow_query_device(self.h, C.byref(s), C.c_void_p(d_kf_index), n_kf, C.c_void_p(d_f_index), n_queries,
                                                  self.nnratio, int(self.check_ori), C.c_void_p(d_match), C.c_void_p(d_nmatches)))
+
+    def bow_query_frames_device(self, vocab, store, first_query, n_queries, levelsup, d_kf_index, n_kf, d_f_index, d_match, d_nmatches):
+        """ComputeBoW (descent + feature vector, written into the store) of frames [first_query, +n_queries) and their search
+        against the keyframe list, one call (orb_bow_query_frames_device)."""
+        s = self._store(store)
+        _check(self.L.orb_bow_query_frames_device(self.h, vocab.h, C.byref(s), first_query, n_queries, levelsup, C.c_void_p(d_kf_index),
+                                                  n_kf, C.c_void_p(d_f_index), self.nnratio, int(self.check_ori), C.c_void_p(d_match),
+                                                  C.c_void_p(d_nmatches)))
 
     def match_bow_batch_device(self, store, d_kf_index, d_f_index, n_pairs, d_match, d_nmatches):
         """store = dict(desc=, kps=, valid=, counts=, node_of=, cap=, n_frames=) of raw device pointers."""

@@ -145,3 +145,63 @@ def test_vocab_transform_device_batches_with_ragged_counts(k, L):
             order = np.argsort(gN[f, :n][reached], kind="stable")
             assert (np.diff(gO[f, :n][reached][order].astype(np.int64)) >= 0).all()
     v.close()
+
+
+def test_compute_bow_and_search_in_one_call_equals_the_three_calls():
+    """orb_bow_query_frames_device (Frame::ComputeBoW of the query frames -- descent + feature vector, written into the store --
+    and the search against the keyframe list, reference src/Tracking.cc:1471-1492) against the same work as three calls
+    (orb_bow_transform_device, orb_bow_build_csr_desc_device, orb_match_bow_query_device): identical store rows and matches."""
+    import torch
+    tree = synth.synth_vocab_tree(10, 3, seed=91, prune=0.1)
+    levelsup = 1
+    dev = torch.device("cuda:0")
+    n_kf, n_q, cap = 30, 3, 500
+    F = n_kf + n_q
+    rng = np.random.default_rng(8)
+    base = rng.integers(0, 256, (n_q, cap, 32), dtype=np.uint8)
+    desc = np.zeros((F, cap, 32), np.uint8)
+    counts = np.zeros(F, np.int32)
+    for f in range(F):
+        src = base[f % n_q] if f < n_kf else base[f - n_kf]
+        n = cap if f % 5 else cap - 37
+        d = src[:n].copy()
+        flip = rng.integers(0, 256, (n, 3))
+        for r in range(n):
+            for b in flip[r][: int(rng.integers(0, 4))]:
+                d[r, b >> 3] ^= np.uint8(1 << (b & 7))
+        desc[f, :n], counts[f] = d, n
+    kps = np.zeros((F, cap), capi.KP_DTYPE)
+    kps["angle"] = rng.uniform(0, 360, (F, cap)).astype(np.float32)
+    m, v = capi.Matcher(0.75, True), capi.Vocabulary(tree)
+    nn = v.level_nodes(levelsup)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    results = []
+    for fused in (False, True):
+        d_desc, d_kps, d_counts = t(desc), t(kps.view(np.uint8)), t(counts)
+        z = lambda n, dt: torch.zeros(n, dtype=dt, device=dev)
+        d_node, d_ck, d_cs, d_cc, d_cd = z(F * cap, torch.int16), z(F * cap, torch.int32), z(F * nn, torch.int16), z(F * nn, torch.int16), z(F * cap * 32, torch.uint8)
+        store = dict(desc=d_desc.data_ptr(), kps=d_kps.data_ptr(), valid=0, counts=d_counts.data_ptr(), node_of=d_node.data_ptr(), cap=cap,
+                     n_frames=F, n_nodes=nn, csr_keys=d_ck.data_ptr(), csr_start=d_cs.data_ptr(), csr_cnt=d_cc.data_ptr(), csr_desc=d_cd.data_ptr())
+        torch.cuda.synchronize()
+        # the keyframes' ComputeBoW (once per keyframe in the reference): the plain calls in both runs
+        v.transform_device(m, d_desc.data_ptr(), d_counts.data_ptr(), n_kf, cap, levelsup, d_node_of=d_node.data_ptr())
+        m.build_csr_desc_device(d_node.data_ptr(), d_counts.data_ptr(), d_desc.data_ptr(), n_kf, cap, nn, d_ck.data_ptr(), d_cs.data_ptr(),
+                                d_cc.data_ptr(), d_cd.data_ptr())
+        d_kf, d_f = t(np.arange(n_kf, dtype=np.int32)), t(np.arange(n_kf, F, dtype=np.int32))
+        d_m, d_n = z(n_q * n_kf * cap, torch.int32), z(n_q * n_kf, torch.int32)
+        torch.cuda.synchronize()
+        if fused:
+            m.bow_query_frames_device(v, store, n_kf, n_q, levelsup, d_kf.data_ptr(), n_kf, d_f.data_ptr(), d_m.data_ptr(), d_n.data_ptr())
+        else:
+            o = n_kf
+            v.transform_device(m, d_desc.data_ptr() + o * cap * 32, d_counts.data_ptr() + o * 4, n_q, cap, levelsup, d_node_of=d_node.data_ptr() + o * cap * 2)
+            m.build_csr_desc_device(d_node.data_ptr() + o * cap * 2, d_counts.data_ptr() + o * 4, d_desc.data_ptr() + o * cap * 32, n_q, cap, nn,
+                                    d_ck.data_ptr() + o * cap * 4, d_cs.data_ptr() + o * nn * 2, d_cc.data_ptr() + o * nn * 2, d_cd.data_ptr() + o * cap * 32)
+            m.match_bow_query_device(store, d_kf.data_ptr(), n_kf, d_f.data_ptr(), n_q, d_m.data_ptr(), d_n.data_ptr())
+        m.sync(); torch.cuda.synchronize()
+        results.append([x.cpu().numpy() for x in (d_node, d_ck, d_cs, d_cc, d_cd, d_m, d_n)])
+    for a, b in zip(*results):
+        assert np.array_equal(a, b)
+    nm = results[1][6].reshape(n_q, n_kf)
+    assert (nm >= 0).all() and nm.max() > 50                          # related frames do match
+    v.close()
