@@ -384,6 +384,95 @@ __device__ __forceinline__ void qt_body(unsigned long long* keys, int n, const O
             // the phase starts when 3 x candidates could overshoot N, ~170 on level 0) are rank-sorted -- every thread
             // counts the entries below its own, 8 independent broadcast reads in flight -- : two barriers instead of the
             // 36 steps of the network (6.6 -> ~1 us)
+            if (pc <= T && size0 <= 512) {
+                // ---- the short form (round 4): a thread keeps ITS candidate in registers from the rank to the children (no
+                // sorted copy), the candidates' child counts are scanned by ONE wave (<= 256 values, four per lane), the erased
+                // parents are bits of a 512-bit mask and an alive node's new position is a popcount.  5 barriers instead of 12;
+                // same list, same candidate entries.
+                unsigned long long mine = 0;
+                int t = -1, idx = 0, ch = 0;
+                QtNode nd = {0, 0, 0};
+                int3 c = make_int3(0, 0, 0);
+                if (tid < pc) {
+                    mine = prev[tid];
+                    int rank = 0, j = 0;
+                    for (; j + 8 <= pc; j += 8) {
+                        unsigned long long v[8];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) v[u] = prev[j + u];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) rank += v[u] < mine;
+                    }
+                    for (; j < pc; j++) rank += prev[j] < mine;
+                    t = pc - 1 - rank;                                 // processed from the back (:711-713)
+                    idx = (int)(mine & 0xFFFFFF);
+                    nd = cur[idx];
+                    c = qt_cuts(keys, nd);
+                    ch = (c.x > nd.lo) + (c.y > c.x) + (c.z > c.y) + (nd.hi > c.z);
+                    va[t] = ch;
+                }
+                if (tid < 16) vb[tid] = 0;                             // the mask of erased parents
+                if (tid == 0) { sh_tstar = pc; *cntNext = 0; }
+                __syncthreads();
+                if (tid < 64) {                                        // exclusive scan of va[0 .. pc): lane owns 4 consecutive values
+                    int q[4], mineS = 0;
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { q[u] = 4 * tid + u < pc ? va[4 * tid + u] : 0; mineS += q[u]; }
+                    const int incl = orb_wave_scan_incl(mineS);
+                    int run = incl - mineS;
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { if (4 * tid + u < pc) va[4 * tid + u] = run; run += q[u]; }
+                }
+                __syncthreads();
+                int before = 0;
+                if (t >= 0) {
+                    before = va[t];                                    // children created before candidate t
+                    if (size0 + before + ch - (t + 1) >= N) atomicMin(&sh_tstar, t);
+                }
+                __syncthreads();
+                const int P = min(pc, sh_tstar + 1);                   // candidates actually divided before the break (:758)
+                if (t >= 0 && t < P) {
+                    atomicOr(&vb[idx >> 5], (int)(1u << (idx & 31)));
+                    if (t == P - 1) part[0] = before + ch;             // sTot
+                }
+                __syncthreads();
+                const int sTot = part[0], kTot = size0 - P;
+                if (t >= 0 && t < P) {
+                    const int edge[5] = {nd.lo, c.x, c.y, c.z, nd.hi};
+                    int j = before;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int a = edge[q], b = edge[q + 1];
+                        if (b > a) {
+                            const int pos = sTot - 1 - j;
+                            QtNode chn; chn.lo = a; chn.hi = b; chn.depth = nd.depth + 1;
+                            nxt[pos] = chn;
+                            if (b - a > 1) {
+                                const int slot = atomicAdd(cntNow, 1);
+                                prevNew[slot] = ((unsigned long long)(b - a) << 48) | ((unsigned long long)j << 24) | (unsigned long long)pos;
+                            }
+                            j++;
+                        }
+                    }
+                }
+                for (int i = tid; i < size0; i += T) {
+                    const unsigned w = (unsigned)vb[i >> 5];
+                    if (!((w >> (i & 31)) & 1u)) {                     // alive: its position = i - erased parents before it
+                        int gone = __popc(w & ((1u << (i & 31)) - 1u));
+                        for (int k = 0; k < (i >> 5); k++) gone += __popc((unsigned)vb[k]);
+                        nxt[sTot + i - gone] = cur[i];
+                    }
+                }
+                __syncthreads();
+                const int size = sTot + kTot;
+                pc = *cntNow;
+                inB ^= 1;
+                prevInB ^= 1;
+                par ^= 1;
+                if (size >= N || size == size0) state = 2;                        // :762
+                size0 = size;
+                continue;
+            }
             if (pc <= T) {
                 unsigned long long mine = 0;
                 int rank = 0;
