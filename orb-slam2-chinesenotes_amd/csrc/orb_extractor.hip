@@ -209,8 +209,6 @@ extern "C" int orb_extractor_create(const orb_extractor_params* p, int device_id
         if (orb_copy_blocking(h->dPattern.p, ORB_BRIEF_PATTERN_XY, 1024, hipMemcpyHostToDevice, h->stream) != hipSuccess) rc = ORB_ERR_HIP;
     }
     if (rc == ORB_OK) rc = h->dPatternF.ensure(256 * 16);
-    if (rc == ORB_OK) rc = h->dDone.ensure((size_t)orb_extractor::kDoneFrames * ORB_MAX_LEVELS * 4);
-    if (rc == ORB_OK && hipMemsetAsync(h->dDone.p, 0, h->dDone.bytes, h->stream) != hipSuccess) rc = ORB_ERR_HIP;   // (ordered before every launch of the handle)
     if (rc == ORB_OK) rc = h->dAngTab.ensure(16 * 2 * 32 + 768 * 4);     // + the descriptor kernel's horizontal-blur item table
     if (rc == ORB_OK) {
         // IC_Angle tables (k_orient_desc): per (|v|, half row) 16 mask bytes (1 inside |u| <= umax[|v|]) and
@@ -245,7 +243,7 @@ extern "C" void orb_extractor_destroy(orb_extractor* h)
     }
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    DevBuf* bufs[] = {&h->dPattern, &h->dPatternF, &h->dAngTab, &h->dDone, &h->dCells, &h->dXtab, &h->dYtab, &h->dXq, &h->dPath, &h->dBand, &h->dPyr, &h->dCand, &h->dKpl, &h->dOvf, &h->dQt,
+    DevBuf* bufs[] = {&h->dPattern, &h->dPatternF, &h->dAngTab, &h->dCells, &h->dXtab, &h->dYtab, &h->dXq, &h->dPath, &h->dBand, &h->dPyr, &h->dCand, &h->dKpl, &h->dOvf, &h->dQt,
                       &h->dStat, &h->dImgs, &h->dKps, &h->dDesc, &h->dCounts,
                       &h->dStereo, &h->dStereoIn};
     for (DevBuf* b : bufs) b->release();
@@ -260,6 +258,7 @@ extern "C" void orb_extractor_destroy(orb_extractor* h)
     if (h->graph1.graph) (void)hipGraphDestroy(h->graph1.graph);
     if (h->hStage) (void)hipHostFree(h->hStage);
     if (h->stream) (void)hipStreamDestroy(h->stream);
+    for (hipStream_t st : h->retiredStreams) (void)hipStreamDestroy(st);
     delete h;
 }
 
@@ -285,14 +284,23 @@ extern "C" int orb_extractor_max_keypoints(const orb_extractor* h)
     return tot;
 }
 
+// the reference's table stays within +-13 (src/ORBextractor.cc:175-432); the descriptor kernel's patch and its row-blur item
+// table are sized for that extent (csrc/orb_desc.hip: a sample lies within sqrt(13^2 + 13^2) px of the keypoint)
+static int check_pattern(const int8_t* pat)
+{
+    for (int i = 0; i < 1024; i++)
+        if (pat[i] < -13 || pat[i] > 13) {
+            orb_set_error("BRIEF pattern coordinate %d outside [-13, 13]: the descriptor kernel's patch covers 18 px around a keypoint", (int)pat[i]);
+            return ORB_ERR_UNSUPPORTED;
+        }
+    return ORB_OK;
+}
+
 extern "C" int orb_extractor_set_pattern(orb_extractor* h, const int8_t* pat)
 {
     if (!h || !pat) return ORB_ERR_INVALID;
-    for (int i = 0; i < 1024; i++)
-        if (pat[i] < -13 || pat[i] > 13) {                     // the reference's table stays within +-13 (src/ORBextractor.cc:175-432);
-            orb_set_error("BRIEF pattern coordinate %d outside [-13, 13]: the descriptor kernel's patch covers 18 px around a keypoint", (int)pat[i]);
-            return ORB_ERR_UNSUPPORTED;                         // the kernel's patch / blur extent is sized for it
-        }
+    int rc = check_pattern(pat);
+    if (rc != ORB_OK) return rc;
     ORB_HIP_TRY(hipSetDevice(h->device));
     ORB_HIP_TRY(hipMemcpyAsync(h->dPattern.p, pat, 1024, hipMemcpyHostToDevice, h->stream));
     ORB_HIP_TRY(hipStreamSynchronize(h->stream));
@@ -300,10 +308,19 @@ extern "C" int orb_extractor_set_pattern(orb_extractor* h, const int8_t* pat)
     return ORB_OK;
 }
 
+// The table that arrives over RCCL (csrc/orb_multi.hip) or from a caller's device buffer: it is copied to the host first and
+// held to the same extent rule as the host setter -- a coordinate beyond +-13 would let the descriptor kernel index LDS outside
+// the row-blurred patch and return wrong descriptors without any error.  The handle keeps its previous pattern when
+// the table is rejected.
 extern "C" int orb_extractor_set_pattern_device(orb_extractor* h, const int8_t* dpat)
 {
     if (!h || !dpat) return ORB_ERR_INVALID;
     ORB_HIP_TRY(hipSetDevice(h->device));
+    int8_t host[1024];
+    ORB_HIP_TRY(hipMemcpyAsync(host, dpat, 1024, hipMemcpyDeviceToHost, h->stream));
+    ORB_HIP_TRY(hipStreamSynchronize(h->stream));
+    int rc = check_pattern(host);
+    if (rc != ORB_OK) return rc;
     ORB_HIP_TRY(hipMemcpyAsync(h->dPattern.p, dpat, 1024, hipMemcpyDeviceToDevice, h->stream));
     ORB_HIP_TRY(hipStreamSynchronize(h->stream));
     h->patternPtr = (const int8_t*)h->dPattern.p;
@@ -491,19 +508,10 @@ extern "C" int orb_extract_batch_device(orb_extractor* h, const uint8_t* d_imgs,
     }
     }
     if (prof) ORB_HIP_TRY(hipEventRecord(pe[1], st));
-    // single frames without the dense launch: the last FAST workgroup of a level runs the level's quadtree (one launch less)
-    OrbFastFuse fuse{};
-    const bool wantFuse = h->specNoDense && !h->qtGlobal && n <= orb_extractor::kDoneFrames && h->dDone.p;
-    if (wantFuse) {
-        fuse.kpl = skpl; fuse.kpCount = skc; fuse.done = (int*)h->dDone.p; fuse.sortCap = h->sortCap; fuse.nodeCap = h->nodeCap;
-        for (const OrbStrip& sp : h->strips) fuse.stripsOfLevel[sp.level]++;
-    }
-    const bool qtDone = orb_launch_fast_strips(st, G, pyr, h->pyrSlab, (const OrbStrip*)h->dCells.p, (int)h->strips.size(),
+    orb_launch_fast_strips(st, G, pyr, h->pyrSlab, (const OrbStrip*)h->dCells.p, (int)h->strips.size(),
                            (const uint32_t*)h->dPath.p, scand, h->candSlab, scc, serr, h->ovfCountP(), (int*)h->dOvf.p,
-                           h->prm.ini_th_fast, h->prm.min_th_fast, h->fastPdw, h->fastRows, h->fastSdw, h->fastCandCap, n, h->fastP, h->specNoDense,
-                           wantFuse ? &fuse : nullptr);
+                           h->prm.ini_th_fast, h->prm.min_th_fast, h->fastPdw, h->fastRows, h->fastSdw, h->fastCandCap, n, h->fastP, h->specNoDense);
     if (prof) ORB_HIP_TRY(hipEventRecord(pe[2], st));
-    if (!qtDone)
     orb_launch_quadtree(st, G, scand, h->candSlab, scc, skpl, skc, serr, h->sortCap, h->nodeCap, n, h->ovfCountP(),
                         h->qtGlobal ? (unsigned char*)h->dQt.p : nullptr);
     if (prof) ORB_HIP_TRY(hipEventRecord(pe[3], st));
@@ -705,11 +713,17 @@ extern "C" int orb_extract_batch(orb_extractor* h, const uint8_t* imgs, int nFra
             hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
             if (hipStreamIsCapturing(h->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
                 (void)hipGetLastError();
+                // The old stream stays alive until orb_extractor_destroy: its handle is public (orb_extractor_stream: torch
+                // ExternalStream wrappers, orb_matcher_wait_for, the stereo partner) and a caller that cached it must not be left
+                // with a dangling one; orb_extractor_stream returns the replacement from now on.
                 hipStream_t fresh = nullptr;
-                if (hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) == hipSuccess) {
-                    (void)hipStreamDestroy(h->stream);
-                    h->stream = fresh;
+                if (hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) != hipSuccess) {
+                    (void)hipGetLastError();
+                    orb_set_error("orb_extract: the handle's stream was invalidated by a foreign capture and no replacement could be created");
+                    return ORB_ERR_HIP;
                 }
+                h->retiredStreams.push_back(h->stream);
+                h->stream = fresh;
                 (void)hipGetLastError();
             }
         }

@@ -31,6 +31,7 @@ struct orb_extractor {
     orb_extractor_params prm;
     int device = 0;
     hipStream_t stream = nullptr;
+    std::vector<hipStream_t> retiredStreams;   // streams replaced after a foreign capture invalidated them: destroyed with the handle
     static const int kProfSlots = 64;
     hipEvent_t ev[kProfSlots][5];           // ring of per-batch stage boundaries
     hipEvent_t waitEv = nullptr;
@@ -79,8 +80,6 @@ struct orb_extractor {
     std::vector<size_t> xtabOff, ytabOff;       // per level offsets (in int2 units)
     std::vector<long long> xqOff;               // per level offset into dXq (uint4 units), -1 = level not eligible
     DevBuf dPyr, dCand, dKpl, dOvf;             // per-batch scratch (dOvf: FAST strips to redo densely)
-    DevBuf dDone;                               // [kDoneFrames][ORB_MAX_LEVELS] strips finished per (frame, level): the fused single-frame FAST + quadtree launch
-    static constexpr int kDoneFrames = 16;
     DevBuf dQt;                                 // node lists of k_quadtree_gnodes (quotas beyond one workgroup's LDS)
     bool qtGlobal = false;
     // per-batch status words, ONE allocation so that one memset clears it and one copy fetches it:

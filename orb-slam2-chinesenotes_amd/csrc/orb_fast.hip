@@ -33,7 +33,6 @@
 #include <type_traits>
 
 #include "orb_kernels.h"
-#include "orb_quadtree_device.h"
 #include "orb_wave.h"
 
 #define WAVE 64
@@ -820,7 +819,7 @@ size_t orb_fast_mw_lds_bytes(int P, int rowsMax, int candCap)
     return (size_t)hdr + (size_t)rowsMax * rowb + 16 + tail;
 }
 
-template <int P, bool COH>
+template <int P>
 __device__ __forceinline__ void fast_mw_strip(uint32_t* fsm, const OrbGeom& G, const uint8_t* __restrict__ pyr, size_t pyrSlab,
                                               const OrbStrip& S, int f, int si,
                                               const uint32_t* __restrict__ pathTab,
@@ -1080,56 +1079,25 @@ __device__ __forceinline__ void fast_mw_strip(uint32_t* fsm, const OrbGeom& G, c
         const int row = ent >> 8, col = ent & 0xff;
         const int c = (int)(((unsigned)(col - zLo) * S.invW) >> 16);
         const int Sv = candScore[it * T + tid];
-        // COH (fused form): the keys are read by ANOTHER workgroup of this launch, possibly on another XCD (own L2): stored
-        // coherently at device scope, so that no cache-wide release / acquire is needed around the hand-over
-        if (COH) __hip_atomic_store(&out[w], FAST_KEY(row, col, c, Sv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else out[w] = FAST_KEY(row, col, c, Sv);
+        out[w] = FAST_KEY(row, col, c, Sv);
         w++;
     }
 }
 
-// Fused form (single frames without the dense launch): the workgroup that finishes the LAST strip of a (frame, level) runs
-// that level's quadtree right away -- the counter tells it so, nobody waits --: one launch and its ~4.6 us of fixed cost less
-// in a frame's chain of five, and the small levels' quadtrees no longer wait for the longest strip of level 0.
-struct FastFuse {
-    uint32_t* kpl;
-    int* kpCount;
-    int* done;                                  // [frames][ORB_MAX_LEVELS] strips finished; the last workgroup resets it
-    int sortCap, nodeCap, shOff;                // quadtree LDS carve-up (orb_quadtree_lds_bytes), byte offset of its 4 shared words
-    int stripsOfLevel[ORB_MAX_LEVELS];
-};
-
-template <int P, bool FUSED>
+template <int P>
 __global__ __launch_bounds__(WAVE * MW_WAVES) void k_fast_strips_mw(const OrbGeom G, const uint8_t* __restrict__ pyr, size_t pyrSlab,
                                                                    const OrbStrip* __restrict__ strips,
                                                                    const uint32_t* __restrict__ pathTab,
                                                                    unsigned long long* __restrict__ cand, size_t candSlab,
                                                                    int* __restrict__ candCount, int* __restrict__ errFlags,
                                                                    int* __restrict__ ovfCount, int* __restrict__ ovfList, int iniTh,
-                                                                   int minTh, int rowsMax, int candCap, const FastFuse FZ)
+                                                                   int minTh, int rowsMax, int candCap)
 {
     extern __shared__ uint32_t fsm[];
     const int f = blockIdx.y, si = blockIdx.x;
     const OrbStrip S = strips[si];
-    fast_mw_strip<P, FUSED>(fsm, G, pyr, pyrSlab, S, f, si, pathTab, cand, candSlab, candCount, errFlags, ovfCount, ovfList, iniTh, minTh,
-                            rowsMax, candCap);
-    if (!FUSED) return;
-    const int tid = threadIdx.x, level = S.level;
-    // Hand-over without cache-wide fences (a __threadfence() per workgroup is an L2 write-back + invalidate on a chip of
-    // eight L2s: the fused launch took 52 us with them, against 34 us for the two launches): this strip's keys were stored
-    // coherently and its share of the count is an atomic; once they have been acknowledged (vmcnt) the counter may tell
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                                               // (every wave is done with the strip's LDS)
-    int* sI = reinterpret_cast<int*>(fsm);
-    if (tid == 0) sI[0] = atomicAdd(&FZ.done[f * ORB_MAX_LEVELS + level], 1);
-    __syncthreads();
-    const int arrived = sI[0];
-    __syncthreads();
-    if (arrived != FZ.stripsOfLevel[level] - 1) return;
-    if (tid == 0) FZ.done[f * ORB_MAX_LEVELS + level] = 0;         // ready for the next frame
-    const int n = __hip_atomic_load(&candCount[f * ORB_MAX_LEVELS + level], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    qt_instance_lds<true>(reinterpret_cast<unsigned long long*>(fsm), reinterpret_cast<int*>(reinterpret_cast<uint8_t*>(fsm) + FZ.shOff), G, level, f,
-                          cand, candSlab, n, FZ.kpl, FZ.kpCount, errFlags, FZ.sortCap, FZ.nodeCap, ovfCount);
+    fast_mw_strip<P>(fsm, G, pyr, pyrSlab, S, f, si, pathTab, cand, candSlab, candCount, errFlags, ovfCount, ovfList, iniTh, minTh,
+                     rowsMax, candCap);
 }
 
 // The strips of ovfList ((frame << 16 | strip) entries) again, with a full score map next to the tile and
@@ -1247,12 +1215,12 @@ size_t orb_fast_dense_lds_bytes(int pdw, int rowsMax, int sdw)
 }
 
 // ovfList: nStrips * nFrames ints; *ovfCount zeroed by the caller before the launch
-bool orb_launch_fast_strips(hipStream_t st, const OrbGeom& G, const uint8_t* pyr, size_t pyrSlab,
+void orb_launch_fast_strips(hipStream_t st, const OrbGeom& G, const uint8_t* pyr, size_t pyrSlab,
                             const OrbStrip* strips, int nStrips, const uint32_t* pathTab, unsigned long long* cand,
                             size_t candSlab, int* candCount, int* errFlags, int* ovfCount, int* ovfList, int iniTh, int minTh,
-                            int pdw, int rowsMax, int sdw, int candCap, int nFrames, int fixedPitch, bool skipDense, const OrbFastFuse* fuse)
+                            int pdw, int rowsMax, int sdw, int candCap, int nFrames, int fixedPitch, bool skipDense)
 {
-    if (nStrips == 0) return false;
+    if (nStrips == 0) return;
     unsigned inv = 0;
     const unsigned wgs = orb_xcd_grid((unsigned)nStrips, nFrames, &inv);
     const dim3 grid = wgs ? dim3(wgs) : dim3(nStrips, nFrames);
@@ -1267,28 +1235,13 @@ bool orb_launch_fast_strips(hipStream_t st, const OrbGeom& G, const uint8_t* pyr
     // caps every SIMD at 5 -- 20 per CU, evenly -- and the launch is 3 % SHORTER with fewer waves (0.466 against 0.480 ms per 512
     // frames, natural content 0.540 against 0.555; 20 waves per CU reached through LDS padding instead: 0.506)
     static const int occ = [] { const char* e = std::getenv("ORB_FAST_OCC"); return e ? std::atoi(e) : 5; }();
-    bool fused = false;
     if (mw) {
-        FastFuse FZ{};
-        size_t lds = orb_fast_mw_lds_bytes(fixedPitch, rowsMax, candCap);
-        // (off by default: measured 32.9 us for the fused launch against 10.2 + 23.7 us for the two -- the launch that is saved
-        //  is paid back by the hand-over; ORB_FUSE_QT=1 switches it on, tests/test_gpu_extractor.py runs both)
-        const bool wantFuse = std::getenv("ORB_FUSE_QT") != nullptr;
-        if (fuse && skipDense && wantFuse && fuse->done) {
-            const size_t qb = orb_quadtree_lds_bytes(fuse->sortCap, fuse->nodeCap);
-            if (qb + 16 <= 64 * 1024) {
-                fused = true;
-                FZ.kpl = fuse->kpl; FZ.kpCount = fuse->kpCount; FZ.done = fuse->done;
-                FZ.sortCap = fuse->sortCap; FZ.nodeCap = fuse->nodeCap; FZ.shOff = (int)qb;
-                for (int l = 0; l < ORB_MAX_LEVELS; l++) FZ.stripsOfLevel[l] = fuse->stripsOfLevel[l];
-                lds = std::max(lds, qb + 16);
-            }
-        }
-#define ORB_FAST_MW_LAUNCH(PP, FF)                                                                                              \
-        hipLaunchKernelGGL((k_fast_strips_mw<PP, FF>), dim3(nStrips, nFrames), dim3(WAVE * MW_WAVES), lds, st, G, pyr, pyrSlab, strips, pathTab, \
-                           cand, candSlab, candCount, errFlags, ovfCount, ovfList, iniTh, minTh, rowsMax, candCap, FZ)
-        if (fixedPitch == 28) { if (fused) ORB_FAST_MW_LAUNCH(28, true); else ORB_FAST_MW_LAUNCH(28, false); }
-        else { if (fused) ORB_FAST_MW_LAUNCH(20, true); else ORB_FAST_MW_LAUNCH(20, false); }
+        const size_t lds = orb_fast_mw_lds_bytes(fixedPitch, rowsMax, candCap);
+#define ORB_FAST_MW_LAUNCH(PP)                                                                                                  \
+        hipLaunchKernelGGL((k_fast_strips_mw<PP>), dim3(nStrips, nFrames), dim3(WAVE * MW_WAVES), lds, st, G, pyr, pyrSlab, strips, pathTab, \
+                           cand, candSlab, candCount, errFlags, ovfCount, ovfList, iniTh, minTh, rowsMax, candCap)
+        if (fixedPitch == 28) ORB_FAST_MW_LAUNCH(28);
+        else ORB_FAST_MW_LAUNCH(20);
 #undef ORB_FAST_MW_LAUNCH
     }
     else
@@ -1302,12 +1255,11 @@ bool orb_launch_fast_strips(hipStream_t st, const OrbGeom& G, const uint8_t* pyr
     hipLaunchKernelGGL(k_fast_strips, grid, dim3(WAVE),
                        orb_fast_lds_bytes(pdw, rowsMax, candCap), st, G, pyr, pyrSlab, strips, pathTab, cand, candSlab,
                        candCount, errFlags, ovfCount, ovfList, iniTh, minTh, pdw, rowsMax, candCap, nStrips, nFrames, inv);
-    if (skipDense) return fused;                           // the caller looks at *ovfCount afterwards and redoes the batch if it is not 0
+    if (skipDense) return;                                 // the caller looks at *ovfCount afterwards and redoes the batch if it is not 0
     const long long all = (long long)nStrips * nFrames;
     // (the list is almost always empty: a small grid keeps this launch short in a single frame's chain; the kernel
     // strides over the list whatever its length)
     hipLaunchKernelGGL(k_fast_strips_dense, dim3((unsigned)std::max<long long>(16, std::min<long long>(all / 16, 2048))), dim3(WAVE),
                        orb_fast_dense_lds_bytes(pdw, rowsMax, sdw), st, G, pyr, pyrSlab, strips, pathTab, cand, candSlab,
                        candCount, errFlags, ovfCount, ovfList, iniTh, minTh, pdw, rowsMax, sdw);
-    return false;
 }

@@ -14,20 +14,10 @@ void orb_launch_pyr_chain(hipStream_t st, const OrbPyrChain& C, const uint8_t* i
                           int* clr, int clrInts, const int8_t* pat8, float* patF);
 size_t orb_fast_lds_bytes(int pdw, int rowsMax, int candCap);
 size_t orb_fast_dense_lds_bytes(int pdw, int rowsMax, int sdw);
-// what the fused single-frame form of the FAST launch needs to run the quadtree of a level from the level's last strip
-struct OrbFastFuse {
-    uint32_t* kpl;
-    int* kpCount;
-    int* done;                                  // [frames][ORB_MAX_LEVELS], zero between launches
-    int sortCap, nodeCap;
-    int stripsOfLevel[ORB_MAX_LEVELS];
-};
-// returns true when the quadtree ran inside the launch (the caller then leaves orb_launch_quadtree out)
-bool orb_launch_fast_strips(hipStream_t st, const OrbGeom& G, const uint8_t* pyr, size_t pyrSlab,
+void orb_launch_fast_strips(hipStream_t st, const OrbGeom& G, const uint8_t* pyr, size_t pyrSlab,
                             const OrbStrip* strips, int nStrips, const uint32_t* pathTab, unsigned long long* cand,
                             size_t candSlab, int* candCount, int* errFlags, int* ovfCount, int* ovfList, int iniTh, int minTh,
-                            int pdw, int rowsMax, int sdw, int candCap, int nFrames, int fixedPitch, bool skipDense = false,
-                            const OrbFastFuse* fuse = nullptr);
+                            int pdw, int rowsMax, int sdw, int candCap, int nFrames, int fixedPitch, bool skipDense = false);
 size_t orb_fast_p_lds_bytes(int P, int rowsMax, int candCap);
 size_t orb_quadtree_lds_bytes(int sortCap, int nodeCap);
 void orb_launch_quadtree(hipStream_t st, const OrbGeom& G, unsigned long long* cand, size_t candSlab,

@@ -631,6 +631,21 @@ extern "C" int orb_matcher_create(int device_id, orb_matcher** out)
     if (!m) return ORB_ERR_INTERNAL;
     m->device = device_id;
     { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0) m->cus = cus; }
+    {
+        // LDS a workgroup may take: 160 KB on gfx950 (what this library is written for).  Elsewhere the largest figure the runtime
+        // reports (the plain per-block attribute is the 64 KB default on some parts, the opt-in / per-CU attributes the real size),
+        // so that the query-form matcher falls back to the pair kernel earlier instead of failing its launch.
+        hipDeviceProp_t prop;
+        const bool known = hipGetDeviceProperties(&prop, device_id) == hipSuccess;
+        if (!known || std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+            int best = 64 * 1024, v = 0;
+            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, device_id) == hipSuccess) best = std::max(best, v);
+            if (hipDeviceGetAttribute(&v, hipDeviceAttributeSharedMemPerBlockOptin, device_id) == hipSuccess) best = std::max(best, v);
+            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, device_id) == hipSuccess) best = std::max(best, v);
+            m->ldsMax = (size_t)std::min(best, 160 * 1024);
+        }
+        (void)hipGetLastError();
+    }
     hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete m; orb_set_error("hipStreamCreate: %s", hipGetErrorString(e)); return ORB_ERR_HIP; }
     (void)hipEventCreateWithFlags(&m->waitEv, hipEventDisableTiming);

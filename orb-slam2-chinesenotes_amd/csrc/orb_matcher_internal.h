@@ -19,6 +19,7 @@ struct MBuf {
 struct orb_matcher {
     int device = 0;
     int cus = 256;                       // compute units of the device (grid sizing of the query-form matcher)
+    size_t ldsMax = 160 * 1024;          // LDS a workgroup may take on this device (hipDeviceAttributeMaxSharedMemoryPerBlock; gfx950: 160 KB)
     hipStream_t stream = nullptr;
     MBuf sidesA, sidesB;                 // BowSide arrays of a batch
     MBuf stage[12];                      // host-API staging (SearchByBoW)

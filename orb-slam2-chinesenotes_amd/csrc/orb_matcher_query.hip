@@ -109,7 +109,7 @@ __global__ __launch_bounds__(QK_THREADS) void k_match_bow_query(orb_featstore S,
                                                                const int32_t* __restrict__ fIndex, int nNodes, float ratio, int checkOri,
                                                                int32_t* __restrict__ match, int32_t* __restrict__ nmatches,
                                                                unsigned* __restrict__ groupCtr, unsigned* __restrict__ ctrToClear,
-                                                               unsigned long long* __restrict__ stamps)
+                                                               int ctrStride, unsigned long long* __restrict__ stamps)
 {
     extern __shared__ uint4 qsm[];
     constexpr int QK_HALF = QK_THREADS / QK_G;
@@ -164,7 +164,11 @@ __global__ __launch_bounds__(QK_THREADS) void k_match_bow_query(orb_featstore S,
     // lost 4 us: a workgroup that drew an expensive keyframe then sits on a group that idle workgroups could have taken.
     __shared__ int nextGroup;
     const int nGroups = (nKf + QK_G - 1) / QK_G;
-    if (blockIdx.x == 0 && tid == 0) ctrToClear[q] = 0;            // (the counter a later launch will use; this launch's is groupCtr[q])
+    // The counters a later launch will use (this launch's are groupCtr[]): the WHOLE slot, not only this launch's n_queries
+    // entries -- a launch with fewer queries would otherwise leave the higher entries of a slot as an earlier, wider launch
+    // left them (>= its gridDim.x), and the next wide launch on that slot would skip keyframe groups.
+    if (blockIdx.x == 0 && q == 0)
+        for (int i = tid; i < ctrStride; i += QK_THREADS) ctrToClear[i] = 0;
     int iter = 0;
     QK_STAMP(0);
     for (;; iter++) {
@@ -484,13 +488,15 @@ extern "C" int orb_match_bow_query_device(orb_matcher* m, const orb_featstore* s
     // wait for each other at every barrier (256 threads x 2: 71 us).  Frames too large for two such workgroups per CU
     // (> ~1450 features) take the 1024-thread forms.
     int G = 1, TH = 512, perCu = 2;
-    if (2 * query_lds_bytes(store->cap, nNodes, 1) > 160 * 1024) { G = 2; TH = 1024; perCu = 1; }
+    // the LDS budget comes from the device (160 KB on gfx950; a part with less takes the pair kernel earlier instead of failing)
+    const size_t ldsCu = m->ldsMax, ldsWg = m->ldsMax - 4 * 1024;
+    if (2 * query_lds_bytes(store->cap, nNodes, 1) > ldsCu) { G = 2; TH = 1024; perCu = 1; }
     if (envCfg) sscanf(envCfg, "%d,%d,%d", &G, &TH, &perCu);
     if (!((G == 1 && (TH == 256 || TH == 512 || TH == 1024)) || (G == 2 && TH == 1024) || (G == 4 && TH == 1024))) { G = 2; TH = 1024; perCu = 1; }
-    while (G > 1 && query_lds_bytes(store->cap, nNodes, G) > 156 * 1024) G >>= 1;
+    while (G > 1 && query_lds_bytes(store->cap, nNodes, G) > ldsWg) G >>= 1;
     if (G == 1 && TH != 512 && TH != 256) TH = 1024;
     const size_t lds = query_lds_bytes(store->cap, nNodes, G);
-    if (lds > 156 * 1024) {
+    if (lds > ldsWg) {
         // frames of more than ~2900 features: the same pairs through the pair kernel (17 bytes of LDS per feature)
         const size_t nPairs = (size_t)n_kf * n_queries;
         int rc = m->plan.ensure(nPairs * 8);
@@ -508,7 +514,7 @@ extern "C" int orb_match_bow_query_device(orb_matcher* m, const orb_featstore* s
                    : TH == 256 ? reinterpret_cast<const void*>(k_match_bow_query<1, 256>) : reinterpret_cast<const void*>(k_match_bow_query<1, 1024>);
     if (lds > 64 * 1024) ORB_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // a workgroup stages the query side once and keeps it for its keyframes: perCu resident workgroups per CU, each taking groups
-    perCu = std::max(1, std::min(perCu, (int)((size_t)(160 * 1024) / lds)));
+    perCu = std::max(1, std::min(perCu, (int)(ldsCu / lds)));
     const long long slots = (long long)m->cus * perCu;
     const int blocks = (int)std::max<long long>(1, std::min<long long>((n_kf + G - 1) / G, std::max<long long>(1, slots / n_queries)));      // per query
     unsigned long long* stamps = (unsigned long long)blocks * n_queries * 8 <= m->stampCap ? m->stamps : nullptr;
@@ -531,7 +537,7 @@ extern "C" int orb_match_bow_query_device(orb_matcher* m, const orb_featstore* s
         fprintf(stderr, "[orb] k_match_bow_query<%d>: lds %zu B, blocks %d, occupancy %d workgroups per CU (%s)\n", G, lds, blocks, nb, hipGetErrorString(e));
     }
 #define QK_LAUNCH(GG, TT) hipLaunchKernelGGL((k_match_bow_query<GG, TT>), grid, block, lds, m->stream, *store, d_kf_index, n_kf, d_f_index, nNodes, \
-                                             ratio, check_ori, d_match, d_nmatches, groupCtr, ctrToClear, stamps)
+                                             ratio, check_ori, d_match, d_nmatches, groupCtr, ctrToClear, (int)m->qctrStride, stamps)
     if (G == 4) QK_LAUNCH(4, 1024);
     else if (G == 2) QK_LAUNCH(2, 1024);
     else if (TH == 512) QK_LAUNCH(1, 512);

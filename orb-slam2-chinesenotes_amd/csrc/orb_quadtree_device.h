@@ -1,6 +1,5 @@
 // orb_quadtree_device.h -- device code of the quadtree keypoint distribution (see orb_quadtree.hip for the design notes):
-// included by orb_quadtree.hip (k_quadtree, k_quadtree_gnodes) and by orb_fast.hip (the fused single-frame form, where the
-// last FAST workgroup of a level runs that level's quadtree).
+// included by orb_quadtree.hip (k_quadtree, k_quadtree_gnodes).
 #pragma once
 #include "orb_block_sort.h"
 #include "orb_kernels.h"
@@ -594,9 +593,7 @@ __device__ __forceinline__ void qt_body(unsigned long long* keys, int n, const O
 }
 
 // One (frame, level) instance with its keys and lists in the workgroup's LDS at qsm (carve-up below; sh = four shared words):
-// the body of k_quadtree, also run by the last FAST workgroup of a level in k_fast_strips_mw's fused form (COH: the keys were
-// written by other workgroups of the SAME launch with device-scope stores and are read with device-scope loads).
-template <bool COH = false>
+// the body of k_quadtree
 __device__ __forceinline__ void qt_instance_lds(unsigned long long* qsm, int* sh, const OrbGeom& G, int level, int f,
                                                 unsigned long long* __restrict__ cand, size_t candSlab, int n,
                                                 uint32_t* __restrict__ kpl, int* __restrict__ kpCount, int* __restrict__ errFlags,
@@ -623,7 +620,7 @@ __device__ __forceinline__ void qt_instance_lds(unsigned long long* qsm, int* sh
     }
     unsigned long long* gk = cand + (size_t)f * candSlab + L.candBase;
     if (n <= sortCap) {
-        for (int i = tid; i < n; i += T) ldsKeys[i] = COH ? __hip_atomic_load(&gk[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : gk[i];
+        for (int i = tid; i < n; i += T) ldsKeys[i] = gk[i];
         // scratch of the bucket sort: the node lists behind the keys (prevA .. part), unused until the sort is done
         qt_body(ldsKeys, n, G, L, f, prevA, prevB, A, B, cuts, va, vb, part, kpl, outCount, errFlags, sh,
                 reinterpret_cast<unsigned char*>(prevA), nodeCap * (16 + 2 * (int)sizeof(QtNode) + (int)sizeof(int3) + 8) + 257 * 4, nodeCap);
@@ -631,7 +628,6 @@ __device__ __forceinline__ void qt_instance_lds(unsigned long long* qsm, int* sh
         // more candidates than the LDS holds: the host grows the sort capacity when it hears of it (word 1 of the overflow
         // block: at a sync, or through the unsynchronised feedback of orb_extract_batch_device)
         if (tid == 0) atomicMax(&ovfBlock[1], n);
-        if (COH) __threadfence();                          // (rare path: the keys are sorted where they lie; acquire them cache-wide)
         qt_body(gk, n, G, L, f, prevA, prevB, A, B, cuts, va, vb, part, kpl, outCount, errFlags, sh, nullptr, 0, nodeCap);   // rare: sort in global memory
     }
 }

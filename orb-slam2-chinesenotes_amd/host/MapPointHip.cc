@@ -50,7 +50,6 @@ void MapPoint::ComputeDistinctiveDescriptors()
     if (vDescriptors.empty()) return;
     const size_t N = vDescriptors.size();
     int32_t best = 0;
-    if (N > 256) throw std::runtime_error("MapPoint(HIP): more than 256 observations of one MapPoint");
     std::vector<unsigned char> rows(N * 32);
     for (size_t i = 0; i < N; i++) std::memcpy(&rows[i * 32], vDescriptors[i].ptr<unsigned char>(0), 32);
     const int32_t offsets[2] = {0, (int32_t)N};
@@ -80,7 +79,6 @@ void ComputeDistinctiveDescriptors(const std::vector<MapPoint*>& points)
     std::vector<unsigned char> rows;
     for (size_t p = 0; p < points.size(); p++) {
         if (points[p]) all[p] = static_cast<MapPointAccess*>(points[p])->gather();
-        if (all[p].size() > 256) throw std::runtime_error("MapPoint(HIP): more than 256 observations of one MapPoint");
         for (size_t i = 0; i < all[p].size(); i++) {
             rows.resize(rows.size() + 32);
             std::memcpy(&rows[rows.size() - 32], all[p][i].ptr<unsigned char>(0), 32);

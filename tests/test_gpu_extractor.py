@@ -537,6 +537,40 @@ def test_multi_extractor_shards_and_broadcasts(devices):
     mx.close(); one.close()
 
 
+def test_device_pattern_setter_rejects_what_the_host_setter_rejects():
+    """orb_extractor_set_pattern_device (the setter of the RCCL path and of bench.py) holds a table to the same
+    |coordinate| <= 13 rule as orb_extractor_set_pattern -- the descriptor kernel's patch and row-blur table are sized for it --
+    and a rejected table leaves the handle's pattern as it was."""
+    import torch
+    img = synth.synth_frame(7)
+    ex = capi.Extractor()
+    k0, d0 = ex.extract(img)
+    bad = capi.builtin_pattern().copy()
+    bad[301] = 14
+    with pytest.raises(capi.OrbError) as e:
+        ex.set_pattern(bad)
+    assert e.value.code == -5
+    d_bad = torch.from_numpy(bad.astype(np.int8)).cuda()
+    torch.cuda.synchronize()
+    with pytest.raises(capi.OrbError) as e:
+        ex.set_pattern_device(d_bad.data_ptr())
+    assert e.value.code == -5 and "13" in str(e.value)
+    k1, d1 = ex.extract(img)
+    assert k1.tobytes() == k0.tobytes() and np.array_equal(d1, d0)
+    # a valid device table IS taken (pairs swapped: every bit flips)
+    swapped = capi.builtin_pattern().reshape(256, 2, 2)[:, ::-1, :].copy().reshape(-1)
+    d_ok = torch.from_numpy(swapped.astype(np.int8)).cuda()
+    torch.cuda.synchronize()
+    ex.set_pattern_device(d_ok.data_ptr())
+    k2, d2 = ex.extract(img)
+    one = capi.Extractor()
+    one.set_pattern(swapped)                                       # (the host setter: test_multi_extractor_* checks it)
+    rk, rd = one.extract(img)
+    assert k2.tobytes() == rk.tobytes() and np.array_equal(d2, rd) and not np.array_equal(d2, d0)
+    assert np.all((d2 & d0) == 0)                                  # t0 < t1 and t1 < t0 are never both true
+    ex.close(); one.close()
+
+
 @pytest.mark.parametrize("nf", [4000, 6000, 10000])
 def test_large_feature_counts_kitti_size(nf):
     """Reference src/Tracking.cc:117-126 builds the initialisation extractor with 2 x nFeatures (KITTI: 4000): per-level
@@ -648,12 +682,11 @@ def test_every_pyramid_chain_variant_on_the_same_frames(monkeypatch, variant, w,
     ex.close()
 
 
-@pytest.mark.parametrize("knob", ["ORB_NO_GRAPH", "ORB_NO_ZEROCOPY", "ORB_NO_SPEC", "ORB_NO_ZEROCOPY+ORB_NO_GRAPH", "ORB_FUSE_QT",
-                                  "ORB_FAST_MW=0", "ORB_FUSE_QT+ORB_NO_GRAPH", "ORB_FAST_MW=0+ORB_NO_SPEC"])
+@pytest.mark.parametrize("knob", ["ORB_NO_GRAPH", "ORB_NO_ZEROCOPY", "ORB_NO_SPEC", "ORB_NO_ZEROCOPY+ORB_NO_GRAPH",
+                                  "ORB_FAST_MW=0", "ORB_FAST_MW=0+ORB_NO_SPEC"])
 def test_single_frame_path_switches_do_not_change_results(monkeypatch, knob):
     """The single-frame host call has accelerations that can be switched off one by one (graph replay, zero-copy pinned
-    staging, the chain without the dense-strip launch, four waves per FAST strip) and one that can be switched on (ORB_FUSE_QT: the
-    quadtree of a level run by the FAST workgroup that finishes the level's last strip):
+    staging, the chain without the dense-strip launch, four waves per FAST strip):
     every combination returns what the oracle returns, call after call."""
     for k in knob.split("+"):
         name, _, val = k.partition("=")

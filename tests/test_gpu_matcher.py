@@ -301,7 +301,9 @@ def test_search_by_projection_edges(feats):
 
 def test_distinctive_descriptors_batch():
     rng = np.random.default_rng(11)
-    sizes = [1, 2, 3, 4, 5, 8, 17, 33, 64, 65, 100, 200, 0, 7] + rng.integers(1, 40, 300).tolist()
+    # (256 is the last size whose distance rows fit LDS at once; 257, 300, 513 and 1100 take the histogram form: ADVICE r4 --
+    #  the reference handles any N, src/MapPoint.cc:306-335)
+    sizes = [1, 2, 3, 4, 5, 8, 17, 33, 64, 65, 100, 200, 0, 7, 256, 257, 300, 513, 1100] + rng.integers(1, 40, 300).tolist()
     offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
     # observations of one MapPoint resemble each other: a base descriptor with a few flipped bits, so medians tie often
     desc = np.zeros((offsets[-1], 32), np.uint8)

@@ -163,3 +163,57 @@ def test_query_form_needs_the_sorted_descriptors():
     store["csr_desc"] = z.data_ptr()
     mt.match_bow_query_device(store, z.data_ptr(), 0, z.data_ptr(), 1, z.data_ptr(), z.data_ptr())    # nothing to do
     mt.sync()
+
+
+def test_one_matcher_reused_with_alternating_query_counts():
+    """the ring of group counters.  A launch used to clear only its OWN n_queries entries of the slot a later launch
+    takes, so a wide launch (10 queries), seven narrow ones (1 query) and a wide one again found entries 1..9 of its slot as
+    the first wide launch left them and skipped keyframe groups (rows never written, no error).  One matcher, 19 calls,
+    n_kf well above the workgroups per query; every row of every call equals the pair kernel's, and the wide calls the oracle."""
+    import torch
+    rng = np.random.default_rng(77)
+    n_nodes, cap, n_kf, n_q = 100, 300, 260, 10
+    desc, kps, valid, node, counts = _store(rng, n_kf, n_q, cap, n_nodes, np.ones(n_nodes), reuse=0.3, maxflip=10)
+    F = n_kf + n_q
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    d_desc, d_kps, d_valid, d_node, d_counts = t(desc), t(kps.view(np.uint8)), t(valid), t(node.view(np.int16)), t(counts)
+    d_ck = torch.zeros(F * cap, dtype=torch.int32, device=dev)
+    d_cs = torch.zeros(F * n_nodes, dtype=torch.int16, device=dev)
+    d_cc = torch.zeros(F * n_nodes, dtype=torch.int16, device=dev)
+    d_cd = torch.zeros(F * cap * 32, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    mt = capi.Matcher(0.75, True)
+    mt.build_csr_desc_device(d_node.data_ptr(), d_counts.data_ptr(), d_desc.data_ptr(), F, cap, n_nodes, d_ck.data_ptr(),
+                             d_cs.data_ptr(), d_cc.data_ptr(), d_cd.data_ptr())
+    store = dict(desc=d_desc.data_ptr(), kps=d_kps.data_ptr(), valid=d_valid.data_ptr(), counts=d_counts.data_ptr(),
+                 node_of=d_node.data_ptr(), cap=cap, n_frames=F, n_nodes=n_nodes, csr_keys=d_ck.data_ptr(),
+                 csr_start=d_cs.data_ptr(), csr_cnt=d_cc.data_ptr(), csr_desc=d_cd.data_ptr())
+    kf_list = np.arange(n_kf, dtype=np.int32)
+    d_kf = t(kf_list)
+    # the reference rows, once, from the pair kernel of a SECOND matcher (its own counters)
+    ref = capi.Matcher(0.75, True)
+    d_kf2, d_f2 = t(np.tile(kf_list, n_q)), t(np.repeat(np.arange(n_kf, F, dtype=np.int32), n_kf))
+    d_m2 = torch.zeros(n_q * n_kf * cap, dtype=torch.int32, device=dev)
+    d_n2 = torch.zeros(n_q * n_kf, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    ref.match_bow_batch_device(store, d_kf2.data_ptr(), d_f2.data_ptr(), n_q * n_kf, d_m2.data_ptr(), d_n2.data_ptr())
+    ref.sync()
+    want_m, want_n = d_m2.cpu().numpy().reshape(n_q, n_kf, cap), d_n2.cpu().numpy().reshape(n_q, n_kf)
+    for qi in (0, 9):                                               # ... which the oracle confirms on a sample
+        for kf in (0, 57, n_kf - 1):
+            wn, wm = _oracle_pair(desc, kps, valid, node, counts, kf, n_kf + qi, 0.75, True)
+            assert want_n[qi, kf] == wn and np.array_equal(want_m[qi, kf, :int(counts[n_kf + qi])], wm)
+    widths = [10, 1, 1, 1, 1, 1, 1, 1, 10, 1, 10, 3, 1, 1, 1, 1, 1, 1, 10]
+    for call, nq in enumerate(widths):
+        q_list = np.arange(n_kf, n_kf + nq, dtype=np.int32)
+        d_f = t(q_list)
+        d_m = torch.full((nq * n_kf * cap,), 7, dtype=torch.int32, device=dev)
+        d_n = torch.full((nq * n_kf,), -9, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        mt.match_bow_query_device(store, d_kf.data_ptr(), n_kf, d_f.data_ptr(), nq, d_m.data_ptr(), d_n.data_ptr())
+        mt.sync()
+        got_m, got_n = d_m.cpu().numpy().reshape(nq, n_kf, cap), d_n.cpu().numpy().reshape(nq, n_kf)
+        assert np.array_equal(got_n, want_n[:nq]), (call, nq, np.argwhere(got_n != want_n[:nq])[:5])
+        assert np.array_equal(got_m, want_m[:nq]), (call, nq)
+    assert want_n.sum() > 5000
