@@ -410,6 +410,20 @@ int orb_stereo_match_device(orb_extractor* left, orb_extractor* right, int frame
  * shortens a level's strips rebuilds the strip table, which ends in one hipStreamSynchronize of the handle's stream). */
 int orb_get_fast_overflows(orb_extractor* h, int32_t* overflowed, int32_t* strips_per_frame);
 
+/* Diagnostics: how the descriptor stage of the current geometry (set by the last extraction call's image size) is split.
+ * The reference blurs each pyramid level once and then describes all of the level's keypoints (src/ORBextractor.cc:1118-1136);
+ * levels first_level .. nlevels-1 run that way here (level-resident in LDS, as n_regions row tiles over those levels:
+ * csrc/orb_desc_level.hip) in batches of at least ORB_DESC_LEVEL_MIN_FRAMES frames (default 24); the levels below, and every
+ * level of smaller launches, run one wave per keypoint (csrc/orb_desc.hip).  first_level == nlevels: no level qualifies.
+ * Results never depend on the split. */
+int orb_extractor_desc_plan(const orb_extractor* h, int32_t* first_level, int32_t* n_regions);
+
+/* Diagnostics: d_stamps (device memory, `capacity` 64-bit words, or NULL to switch off) receives, per workgroup w of the
+ * level-resident descriptor kernel of every later batch, 8 words at d_stamps[8 w ..]: the 100 MHz clock at its phase
+ * boundaries (start, staged, IC_Angle done, angles done, blur computed, blur written, samples done) and
+ * (region << 32 | keypoints).  Workgroup w = region + n_regions * frame.  tools/dl_stamps.py prints the table. */
+int orb_extractor_set_desc_stamps(orb_extractor* h, unsigned long long* d_stamps, size_t capacity);
+
 /* The whole pyramid of device-resident frame `frame` of the last batch with ONE device-to-host copy and one
  * synchronisation (the reference keeps it in the public member mvImagePyramid, include/ORBextractor.h:86, read by
  * Frame::ComputeStereoMatches, src/Frame.cc:520,611,626,633).  Level l of the copy starts at dst + offsets[l], has

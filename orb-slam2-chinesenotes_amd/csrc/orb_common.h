@@ -88,6 +88,30 @@ struct OrbPyrChain {
     OrbPyrStep st[ORB_PYR_MAXCHAIN];
 };
 
+// ---- level-resident descriptor stage (k_desc_level, orb_desc_level.hip): a REGION is a run of rows of one pyramid level (the
+// whole level, or a vertical tile of it with 18 rows of halo) that one workgroup stages in LDS, blurs in place and samples.
+#define ORB_DESC_LEVEL_OUTS 56      // blurred dwords a thread keeps in registers across the barrier of the in-place blur
+#define ORB_DESC_MAX_REGIONS 24
+struct OrbDescRegion {
+    short level;
+    short rx0, ry0;             // origin in the level (rx0: multiple of 16); LDS row lr holds level row reflect101(ry0 + lr - 3)
+    short rw4, rh, rwPx;        // dwords per row, rows whose blur is computed, pixels per row
+    short cx0, cx1, cy0, cy1;   // core: the keypoints with cx0 <= x < cx1, cy0 <= y < cy1 are this region's
+    short pd;                   // LDS row pitch in dwords (odd; one pad dword on each side of the rw4)
+    short nBands, bh;           // blur walk: thread = (band, dword column), bands of bh rows
+    short imgRows;              // LDS rows = max(rh, nBands * bh) + 6
+    unsigned char padL, padR;   // the region's left / right edge is the image's: write the reflect-101 frame there
+    unsigned short pad0;
+    unsigned invC, invW;        // ceil(2^32 / chunks per row), ceil(2^32 / rw4): thread -> (row, chunk), (band, column)
+    int ldsBytes;
+};
+struct OrbDescPlan {
+    int nRegions, firstLevel;   // levels firstLevel .. nlevels-1 run level-resident (firstLevel == nlevels: none)
+    int ldsMax;                 // dynamic LDS of the launch: the largest region's
+    int pad0;
+    OrbDescRegion R[ORB_DESC_MAX_REGIONS];
+};
+
 // the 7-tap Gaussian of the descriptor kernel (k0 k1 k2 k3 k2 k1 k0, 8.8 fixed point) packed as its dot4 / dot2 operands
 struct OrbGaussK {
     unsigned h0, h1;            // horizontal pass (v_dot4_u32_u8): k0 | k1 << 8 | k2 << 16 | k3 << 24,  k2 | k1 << 8 | k0 << 16

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
                                                       orb_keypoint* __restrict__ kpsOut,
                                                       uint8_t* __restrict__ descOut, int cap,
                                                       int32_t* __restrict__ countsOut, int* __restrict__ errFlags,
-                                                      int nFrames, unsigned invPerFrame, OrbGaussK gk)
+                                                      int nFrames, unsigned invPerFrame, OrbGaussK gk, int perFrame)
 {
     // ONE LDS region: first the raw patch (2 KB, dword rows with one dword of slack on both sides), later the
     // row-blurred patch H (4 KB, u16) written over it once every lane holds its blur outputs in registers.
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     const int lane = threadIdx.x;
     int slot, f;
     if (invPerFrame) {                                 // 1-D XCD-aware grid: a frame's keypoints share one L2
-        if (!orb_xcd_decode(blockIdx.x, (unsigned)G.kpSlab, invPerFrame, nFrames, f, slot)) return;
+        if (!orb_xcd_decode(blockIdx.x, (unsigned)perFrame, invPerFrame, nFrames, f, slot)) return;
     } else {
         slot = blockIdx.x;
         f = blockIdx.y;
@@ -311,8 +311,10 @@ void orb_desc_hblur_table(uint32_t* tab768)
 void orb_launch_orient_desc(hipStream_t st, const OrbGeom& G, const uint8_t* pyr, size_t pyrSlab,
                             const uint32_t* kpl, const int* kpCount, const float* patternF, const uint4* angTab, const uint32_t* hbTab,
                             orb_keypoint* kps, uint8_t* desc, int cap, int32_t* counts, int* errFlags,
-                            int nFrames, const int* gaussTaps4)
+                            int nFrames, const int* gaussTaps4, int slotLimit)
 {
+    // slotLimit > 0: only the keypoint slots below it (the levels that k_desc_level does not take)
+    const int perFrame = slotLimit > 0 ? std::min(slotLimit, G.kpSlab) : G.kpSlab;
     static const int legacy[4] = {18, 34, 49, 55};
     const int* t = gaussTaps4 ? gaussTaps4 : legacy;
     OrbGaussK gk;                                                  // the taps packed as the kernel's dot4 / dot2 operands
@@ -323,11 +325,11 @@ void orb_launch_orient_desc(hipStream_t st, const OrbGeom& G, const uint8_t* pyr
     gk.v2 = (unsigned)t[2] | ((unsigned)t[1] << 16);
     gk.v3 = (unsigned)t[0];
     unsigned inv = 0;
-    const unsigned wgs = orb_xcd_grid((unsigned)G.kpSlab, nFrames, &inv);
+    const unsigned wgs = orb_xcd_grid((unsigned)perFrame, nFrames, &inv);
     if (wgs)
         hipLaunchKernelGGL(k_orient_desc, dim3(wgs), dim3(WAVE), 0, st, G, pyr, pyrSlab, kpl, kpCount, reinterpret_cast<const float4*>(patternF), angTab, hbTab, kps,
-                           desc, cap, counts, errFlags, nFrames, inv, gk);
+                           desc, cap, counts, errFlags, nFrames, inv, gk, perFrame);
     else
-        hipLaunchKernelGGL(k_orient_desc, dim3(G.kpSlab, nFrames), dim3(WAVE), 0, st, G, pyr, pyrSlab, kpl, kpCount,
-                           reinterpret_cast<const float4*>(patternF), angTab, hbTab, kps, desc, cap, counts, errFlags, nFrames, 0u, gk);
+        hipLaunchKernelGGL(k_orient_desc, dim3(perFrame, nFrames), dim3(WAVE), 0, st, G, pyr, pyrSlab, kpl, kpCount,
+                           reinterpret_cast<const float4*>(patternF), angTab, hbTab, kps, desc, cap, counts, errFlags, nFrames, 0u, gk, perFrame);
 }

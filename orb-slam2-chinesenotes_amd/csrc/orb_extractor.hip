@@ -106,6 +106,7 @@ static int build_geometry(orb_extractor* h, int rows, int cols)
     ORB_HIP_TRY(hipStreamSynchronize(h->stream));     // host vectors go out of scope
     // commit
     h->G = G;
+    orb_desc_level_plan(h->G, &h->descPlan);                  // which levels the level-resident descriptor kernel takes
     h->strips.swap(strips);
     h->nCells = P.nCells;
     std::memcpy(h->fastStripsOfLevel, P.stripsOfLevel, sizeof(P.stripsOfLevel));
@@ -203,6 +204,10 @@ extern "C" int orb_extractor_create(const orb_extractor_params* p, int device_id
         for (int i = 0; i < 5; i++) (void)hipEventCreate(&h->ev[k][i]);
     (void)hipEventCreateWithFlags(&h->waitEv, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&h->ovfEv, hipEventDisableTiming);
+    if (hipStreamCreateWithFlags(&h->sideStream, hipStreamNonBlocking) != hipSuccess) h->sideStream = nullptr;
+    (void)hipEventCreateWithFlags(&h->sideFork, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&h->sideJoin, hipEventDisableTiming);
+    (void)hipGetLastError();
     if (hipHostMalloc((void**)&h->ovfHost, orb_extractor::kOvfInts * 4, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); h->ovfHost = nullptr; }
     int rc = h->dPattern.ensure(1024);
     if (rc == ORB_OK) {
@@ -252,6 +257,9 @@ extern "C" void orb_extractor_destroy(orb_extractor* h)
             if (h->ev[k][i]) (void)hipEventDestroy(h->ev[k][i]);
     if (h->waitEv) (void)hipEventDestroy(h->waitEv);
     if (h->ovfEv) (void)hipEventDestroy(h->ovfEv);
+    if (h->sideFork) (void)hipEventDestroy(h->sideFork);
+    if (h->sideJoin) (void)hipEventDestroy(h->sideJoin);
+    if (h->sideStream) (void)hipStreamDestroy(h->sideStream);
     if (h->ovfHost) (void)hipHostFree(h->ovfHost);
     orb_pipe_release(h);
     if (h->graph1.exec) (void)hipGraphExecDestroy(h->graph1.exec);
@@ -515,8 +523,35 @@ extern "C" int orb_extract_batch_device(orb_extractor* h, const uint8_t* d_imgs,
     orb_launch_quadtree(st, G, scand, h->candSlab, scc, skpl, skc, serr, h->sortCap, h->nodeCap, n, h->ovfCountP(),
                         h->qtGlobal ? (unsigned char*)h->dQt.p : nullptr);
     if (prof) ORB_HIP_TRY(hipEventRecord(pe[3], st));
+    // Batches: the upper pyramid levels go through the level-resident kernel (one staging + one blur per level region, the
+    // angle arithmetic once per 64 keypoints; orb_desc_level.hip), the lower ones -- whose patches hardly overlap -- keep a
+    // wave per keypoint.  A few frames: every keypoint its own wave (a level's workgroup would be the latency of the call).
+    const char* lmfEnv = std::getenv("ORB_DESC_LEVEL_MIN_FRAMES");
+    const int levelMinFrames = lmfEnv ? std::atoi(lmfEnv) : 24;
+    const bool useLevel = h->descPlan.nRegions > 0 && n >= levelMinFrames;
+    // The two kernels are independent (disjoint keypoint slots).  ORB_DESC_LEVEL_SIDE=1 runs the level-resident one on a side
+    // stream BESIDE the per-keypoint one (the idea: single-wave workgroups of k_orient_desc fill the issue cycles that staging
+    // and barriers leave) -- measured slower than one after the other (0.412 against 0.396 ms per 512 frames: the level kernel's
+    // workgroups hold half a CU's LDS each and keep the other kernel's waves OUT), so it is off.
+    const char* sideEnv = std::getenv("ORB_DESC_LEVEL_SIDE");
+    const bool side = useLevel && h->sideStream && h->sideFork && h->sideJoin && n >= 24 && sideEnv && std::atoi(sideEnv) != 0;
+    hipStream_t lst = st;
+    if (side) {
+        ORB_HIP_TRY(hipEventRecord(h->sideFork, st));
+        ORB_HIP_TRY(hipStreamWaitEvent(h->sideStream, h->sideFork, 0));
+        lst = h->sideStream;
+    }
+    if (useLevel && orb_launch_desc_level(lst, G, h->descPlan, pyr, h->pyrSlab, skpl, skc, (const float*)h->dPatternF.p, (const uint4*)h->dAngTab.p, d_kps,
+                                          d_desc, cap, n, h->gaussTaps, h->descStamps, h->descStampCap) != 0) {
+        orb_set_error("k_desc_level: the launch could not be set up");
+        return ORB_ERR_HIP;
+    }
     orb_launch_orient_desc(st, G, pyr, h->pyrSlab, skpl, skc, (const float*)h->dPatternF.p, (const uint4*)h->dAngTab.p, (const uint32_t*)((const uint8_t*)h->dAngTab.p + 16 * 2 * 32), d_kps, d_desc, cap,
-                           d_counts, serr, n, h->gaussTaps);
+                           d_counts, serr, n, h->gaussTaps, useLevel ? G.L[h->descPlan.firstLevel].kpBase : 0);
+    if (side) {
+        ORB_HIP_TRY(hipEventRecord(h->sideJoin, lst));
+        ORB_HIP_TRY(hipStreamWaitEvent(st, h->sideJoin, 0));
+    }
     if (prof) {
         ORB_HIP_TRY(hipEventRecord(pe[4], st));
         h->profCount++;
@@ -860,6 +895,22 @@ extern "C" int orb_get_fast_overflows(orb_extractor* h, int32_t* overflowed, int
         if (overflowed) overflowed[l] = ovf[l];
         if (strips_per_frame) strips_per_frame[l] = h->fastStripsOfLevel[l];
     }
+    return ORB_OK;
+}
+
+extern "C" int orb_extractor_set_desc_stamps(orb_extractor* h, unsigned long long* d_stamps, size_t capacity)
+{
+    if (!h) return ORB_ERR_INVALID;
+    h->descStamps = d_stamps;
+    h->descStampCap = d_stamps ? capacity : 0;
+    return ORB_OK;
+}
+
+extern "C" int orb_extractor_desc_plan(const orb_extractor* h, int32_t* first_level, int32_t* n_regions)
+{
+    if (!h || h->rows <= 0) return ORB_ERR_INVALID;                // (no geometry yet)
+    if (first_level) *first_level = h->descPlan.firstLevel;
+    if (n_regions) *n_regions = h->descPlan.nRegions;
     return ORB_OK;
 }
 

@@ -50,6 +50,9 @@ struct orb_extractor {
     int rows = 0, cols = 0;
     int lastGeomRows = 0, lastGeomCols = 0;     // size of the last successful geometry build (survives a failed one)
     OrbGeom G;
+    unsigned long long* descStamps = nullptr;   // diagnostics: phase stamps of k_desc_level (orb_extractor_set_desc_stamps)
+    size_t descStampCap = 0;
+    OrbDescPlan descPlan;                       // level-resident descriptor stage: regions of the upper levels (orb_desc_level_plan)
     std::vector<OrbStrip> strips;               // FAST work items (runs of cells of one cell row)
     int nCells = 0;
     size_t pyrSlab = 0, candSlab = 0;
@@ -68,6 +71,8 @@ struct orb_extractor {
     bool specNoDense = false;               // single-frame host call: leave k_fast_strips_dense out, redo the frame if a strip overflowed
     int* ovfHost = nullptr;                 // pinned copy of the overflow block (kOvfInts ints)
     hipEvent_t ovfEv = nullptr;
+    hipStream_t sideStream = nullptr;           // the level-resident descriptor kernel of a batch runs here, beside k_orient_desc on `stream`
+    hipEvent_t sideFork = nullptr, sideJoin = nullptr;
     unsigned batchSerial = 0, ovfPendingSerial = 0, ovfAppliedSerial = 0;
     unsigned statSerial = 0;                // batch that h->hStat belongs to (0 = the latest one)
     bool hostCall = false;                  // inside orb_extract_batch: status travels with the results, no feedback copy

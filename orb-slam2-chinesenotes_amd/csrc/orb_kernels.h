@@ -27,5 +27,10 @@ size_t orb_quadtree_scratch_stride(int nodeCap);
 void orb_launch_orient_desc(hipStream_t st, const OrbGeom& G, const uint8_t* pyr, size_t pyrSlab,
                             const uint32_t* kpl, const int* kpCount, const float* patternF, const uint4* angTab, const uint32_t* hbTab,
                             orb_keypoint* kps, uint8_t* desc, int cap, int32_t* counts, int* errFlags,
-                            int nFrames, const int* gaussTaps4 = nullptr);
+                            int nFrames, const int* gaussTaps4 = nullptr, int slotLimit = 0);
 void orb_desc_hblur_table(uint32_t* tab768);
+// level-resident descriptor stage (orb_desc_level.hip): the plan for a geometry, and the launch over the plan's regions
+void orb_desc_level_plan(const OrbGeom& G, OrbDescPlan* P);
+int orb_launch_desc_level(hipStream_t st, const OrbGeom& G, const OrbDescPlan& P, const uint8_t* pyr, size_t pyrSlab, const uint32_t* kpl,
+                          const int* kpCount, const float* patternF, const uint4* angTab, orb_keypoint* kps, uint8_t* desc, int cap,
+                          int nFrames, const int* gaussTaps4, unsigned long long* stamps = nullptr, size_t stampCap = 0);
