@@ -126,10 +126,19 @@ def parse():
     return ap.parse_args()
 
 
+def profile_path(name):
+    """profiles/<name> for the counters bench.py falls back to when it cannot measure them live: the NEWEST committed round's
+    artefact (profiles/rNN_b512_valu.json, rNN_b512_pmc_traffic.json, rNN_c5_pmc_traffic.json), never an unversioned copy."""
+    import glob
+    pat = {"pmc_traffic.json": "r[0-9][0-9]_b512_pmc_traffic.json", "valu.json": "r[0-9][0-9]_b512_valu.json",
+           "c5_pmc_traffic.json": "r[0-9][0-9]_c5_pmc_traffic.json"}.get(name)
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", pat))) if pat else []
+    return cands[-1] if cands else os.path.join(ROOT, "profiles", name)
+
+
 def load_profile(name):
-    p = os.path.join(ROOT, "profiles", name)
     try:
-        return json.load(open(p))
+        return json.load(open(profile_path(name)))
     except Exception:
         return None
 
@@ -205,7 +214,7 @@ def live_counters(kernel, launch_frames, content="shapes", child_args=None):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def roofline_blocks(stage_ms, launch_frames, bytes_frame, extract_total_ms, live=False, content="shapes"):
+def roofline_blocks(stage_ms, launch_frames, bytes_frame, extract_total_ms, live=False, content="shapes", child_args=None):
     """The contract `roofline` block (HBM, as SURVEY 8(d) defines `achieved`) for the dominant extractor kernel, plus
     `roofline_valu`: what actually binds FAST and the descriptor kernel is vector-instruction issue.  With live=True the
     kernel's HBM-side traffic AND its vector-instruction counters are measured in this run (three rocprofv3 child passes);
@@ -222,7 +231,7 @@ def roofline_blocks(stage_ms, launch_frames, bytes_frame, extract_total_ms, live
                       "vector-instruction issue of the fixed-point resampling inside barrier-separated band steps (~50 % VALU-busy), not HBM")}
     key = STAGES[dom].split("(")[0]
     tr = load_profile("pmc_traffic.json")
-    lc = live_counters(key, launch_frames, content) if live else {"traffic": None, "valu": None}
+    lc = live_counters(key, launch_frames, content, child_args) if live else {"traffic": None, "valu": None}
     if lc["traffic"] is not None:
         rf["traffic"] = lc["traffic"]
         rf["traffic_source"] = "measured in this run: child runs of bench.py (3 steps) under rocprofv3 --pmc FETCH_SIZE / " \
@@ -232,8 +241,8 @@ def roofline_blocks(stage_ms, launch_frames, bytes_frame, extract_total_ms, live
             rf["traffic_committed_profile"] = int(tr["bytes_per_launch"][key] * launch_frames / tr["frames_per_launch"])
     elif tr and key in tr.get("bytes_per_launch", {}):
         rf["traffic"] = int(tr["bytes_per_launch"][key] * launch_frames / tr["frames_per_launch"])
-        rf["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2 per " \
-                               "profiles/r02_fetch_calibration.json), scaled to this launch size"
+        rf["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2 per " \
+                               "profiles/r02_fetch_calibration.json), scaled to this launch size" % os.path.basename(profile_path("pmc_traffic.json"))
     rv = None
     k, src = lc["valu"], "measured in this run: a child run of bench.py (3 steps) under rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU ..."
     if k is None:
@@ -241,7 +250,7 @@ def roofline_blocks(stage_ms, launch_frames, bytes_frame, extract_total_ms, live
         if vj and key in vj.get("kernels", {}):
             k = dict(vj["kernels"][key])
             k["valu_insts"] = k["valu_insts"] * launch_frames / vj["frames_per_launch"]
-            src = "profiles/valu.json (tools/prof_collect.sh + tools/pmc_summary.py), scaled to this launch size"
+            src = "profiles/%s (tools/prof_collect.sh + tools/pmc_summary.py), scaled to this launch size" % os.path.basename(profile_path("valu.json"))
     if k is not None:
         insts = k["valu_insts"]
         ach = insts / kern_s / 1e9
@@ -724,7 +733,10 @@ def run_c3(args, rank, local_rank, world, dev, comm_dev, dist):
     bytes_img = algorithmic_bytes_per_frame(W, H, pyr_px, mean_kp)
     # per pair: both extractions + the stereo search's reads (both keypoint/descriptor sets, 11x(2L+11)-px SAD bands)
     bytes_pair = 2 * bytes_img + int(nl.mean() + nr.mean()) * 60 + int(nl.mean()) * 2 * 11 * 21
-    rf, rv = roofline_blocks(stage_ms, 2 * S if one else S, bytes_img, float(stage_ms[4]))
+    # counters of the dominant kernel measured live, like configs 4 and 5: child runs of this configuration under rocprofv3 --pmc
+    c3_child = ["--config", "c3", "--steps", "3", "--warmup", "3", "--no-cpu-baseline", "--no-live-traffic"] + (["--c3-two-handles"] if not one else [])
+    rf, rv = roofline_blocks(stage_ms, 2 * S if one else S, bytes_img, float(stage_ms[4]), live=(world == 1 and not args.no_live_traffic),
+                             child_args=c3_child)
     rf["algorithmic_bytes_per_pair"] = int(bytes_pair)
     out = {"metric": "frames/sec ORB extract + stereo search, 1241x376 stereo pairs, 8-level 2000-feat; HBM GB/s vs peak",
            "value": round(2 * pairs / elapsed, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

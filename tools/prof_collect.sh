@@ -10,6 +10,7 @@ shift
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$tag
 mkdir -p "$OUT"
+python3 "$ROOT/tools/source_hash.py" > "$OUT.source_sha256" 2>/dev/null   # which build this output describes (tools/provenance.py)
 cd /tmp && export TMPDIR=/tmp
 ARGS=("$@")
 if [ ${#ARGS[@]} -eq 0 ]; then ARGS=(--no-cpu-baseline --no-host-path --no-live-traffic --steps 6 --warmup 2 --pipeline 1); fi

@@ -4,6 +4,7 @@
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/lat_trace
 mkdir -p "$OUT"
+python3 "$ROOT/tools/source_hash.py" > "$OUT.source_sha256" 2>/dev/null   # which build this output describes (tools/provenance.py)
 cd /tmp && export TMPDIR=/tmp
 ORB_NO_GRAPH=1 rocprofv3 --kernel-trace --output-format csv -d "$OUT" -o run -- python3 "$ROOT/tools/latency.py" 60 > "$OUT.log" 2>&1 || { tail -5 "$OUT.log"; exit 1; }
 python3 - "$OUT" <<'PY'

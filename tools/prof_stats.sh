@@ -5,6 +5,7 @@ tag=${1:?tag}; shift
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/stats_$tag
 mkdir -p "$OUT"
+python3 "$ROOT/tools/source_hash.py" > "$OUT.source_sha256" 2>/dev/null   # which build this output describes (tools/provenance.py)
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o run -- python3 "$ROOT/bench.py" "$@" > "$OUT.log" 2>&1 || { tail -5 "$OUT.log"; exit 1; }
 python3 - "$OUT" <<'PY'
