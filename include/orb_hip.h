@@ -424,6 +424,13 @@ int orb_extractor_desc_plan(const orb_extractor* h, int32_t* first_level, int32_
  * (region << 32 | keypoints).  Workgroup w = region + n_regions * frame.  tools/dl_stamps.py prints the table. */
 int orb_extractor_set_desc_stamps(orb_extractor* h, unsigned long long* d_stamps, size_t capacity);
 
+/* Diagnostics of the pyramid kernels (k_pyr_chain): d_stamps receives, launch after launch of a later batch, 8 words per
+ * workgroup (band b of frame f of a launch: 8 * (f * bands + b)): the 100 MHz clock at 0 start, 1 source rows requested and
+ * stored, 2 staged (barrier), 3 + k level k of the chain written (barrier).  orb_extractor_pyr_stamp_layout tells how many
+ * launches the last batch had and their bands per frame / levels per launch.  tools/pyr_stamps.py prints the table. */
+int orb_extractor_set_pyr_stamps(orb_extractor* h, unsigned long long* d_stamps, size_t capacity);
+int orb_extractor_pyr_stamp_layout(const orb_extractor* h, int32_t* n_chains, int32_t* bands8, int32_t* steps8);
+
 /* The whole pyramid of device-resident frame `frame` of the last batch with ONE device-to-host copy and one
  * synchronisation (the reference keeps it in the public member mvImagePyramid, include/ORBextractor.h:86, read by
  * Frame::ComputeStereoMatches, src/Frame.cc:520,611,626,633).  Level l of the copy starts at dst + offsets[l], has

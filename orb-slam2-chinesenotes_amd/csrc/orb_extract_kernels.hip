@@ -308,11 +308,16 @@ __global__ __launch_bounds__(256) void k_pyr_chain(const OrbPyrChain C, const ui
                                                    size_t frameStride, uint8_t* __restrict__ pyr, size_t pyrSlab,
                                                    const uint4* __restrict__ xqAll, const int2* __restrict__ ytAll,
                                                    const int2* __restrict__ bandTab, int* __restrict__ clr, int clrInts,
-                                                   const char4* __restrict__ pat8, float4* __restrict__ patF)
+                                                   const char4* __restrict__ pat8, float4* __restrict__ patF,
+                                                   unsigned long long* __restrict__ stamps)
 {
     extern __shared__ uint32_t ldsDw[];
     uint8_t* lds = reinterpret_cast<uint8_t*>(ldsDw);
     const int tid = threadIdx.x, f = blockIdx.y, b = blockIdx.x;
+    // diagnostics (orb_extractor_set_pyr_stamps): thread 0 leaves the 100 MHz clock at the workgroup's phase boundaries:
+    // 0 start, 1 staging loads requested and stored, 2 staged (barrier passed), 3 + k level k of the chain done (barrier passed)
+#define PYR_STAMP(k) do { if (stamps && tid == 0) stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    PYR_STAMP(0);
     if (clr) {                                                     // first kernel of the batch (see k_copy_level0)
         const unsigned g = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
         if (g < (unsigned)clrInts) clr[g] = 0;
@@ -333,25 +338,20 @@ __global__ __launch_bounds__(256) void k_pyr_chain(const OrbPyrChain C, const ui
     const int2 sr = bt[0];
     uint8_t* slab = pyr + (size_t)f * pyrSlab;
 
-    // ---- row parameters: wave k fills those of step k (LDS byte offsets of the two source rows, coefficients << 16)
-    {
-        const int k = tid >> 6, t = tid & 63;
-        if (k < C.nSteps) {
-            const int2 mr = bt[1 + k];
-            const int n4 = (mr.y - mr.x + 4) & ~3;
-            if (t < n4) {
-                const int2 ty = ytAll[C.st[k].ytOff + min(mr.x + t, mr.y)];
-                const int srcRow0 = bt[k].x;                       // the step's source band: bt[0] or the band of step k - 1
-                const int pitchB = 4 * (k == 0 ? C.srcLdsPitchDw : C.st[k - 1].ldsPitchDw);
-                const int base = k == 0 ? C.srcLdsOff : C.st[k - 1].ldsOff;
-                uint4 e;
-                e.x = (unsigned)(base + ((ty.x & 0xffff) - srcRow0) * pitchB);
-                e.y = (unsigned)(base + ((int)((unsigned)ty.x >> 16) - srcRow0) * pitchB);
-                e.z = (unsigned)ty.y << 16;
-                e.w = (unsigned)ty.y & 0xffff0000u;
-                *reinterpret_cast<uint4*>(lds + C.st[k].rpOff + 16 * t) = e;
-            }
-        }
+    // ---- row parameters: wave k fills those of step k (LDS byte offsets of the two source rows, coefficients << 16).  The band
+    // table entries are wave-uniform (scalar loads: they do not count against the vector-memory counter), the row-table entry is
+    // REQUESTED here and used behind the staging loads below -- a wait for it in front of them was two more round trips in a row
+    // at the head of every workgroup.
+    const int rpK = __builtin_amdgcn_readfirstlane(tid >> 6), rpT = tid & 63;
+    int2 rpTy = make_int2(0, 0);
+    int rpSrcRow0 = 0;
+    bool rpAct = false;
+    if (rpK < C.nSteps) {
+        const int2 mr = bt[1 + rpK];
+        const int n4 = (mr.y - mr.x + 4) & ~3;
+        rpSrcRow0 = bt[rpK].x;                                     // the step's source band: bt[0] or the band of step k - 1
+        rpAct = rpT < n4;
+        rpTy = ytAll[C.st[rpK].ytOff + min(mr.x + min(rpT, n4 - 1), mr.y)];
     }
     // ---- stage the source rows sr.x .. sr.y (and write the level-0 rows this band owns)
     {
@@ -364,26 +364,59 @@ __global__ __launch_bounds__(256) void k_pyr_chain(const OrbPyrChain C, const ui
         const int pitchB = 4 * C.srcLdsPitchDw;
         uint8_t* dstL = lds + C.srcLdsOff;
         uint8_t* l0 = slab + C.srcOff + (size_t)sr.x * C.srcPitch;
+        // Every load of a thread must be IN FLIGHT before the first is waited for.  (Round 5: the stamps of
+        // orb_extractor_set_pyr_stamps showed a workgroup spending 7-11 of its 17-19 us here -- the last chunk of a row whose
+        // width is not a multiple of 16 used to be read byte by byte in an else branch, and with loads on both sides of that
+        // branch the compiler put an s_waitcnt vmcnt(0) behind EVERY 16-byte load: eight round trips in a row, not one.)
+        // Now the loop holds one load per chunk and nothing else: a partial last chunk is read as the LAST 16 bytes of its row
+        // (inside the caller's buffer whatever the stride) and shifted into place in registers afterwards.  The rows of a
+        // pyramid level are padded to their pitch, so chains that read the slab never have a partial chunk.
+        const bool canPart = C.copy0 && (w & 15) != 0 && w >= 16;
         for (int base = 0; base < total; base += 256 * PYR_STAGE_MAX) {
             orb_u32x4 v[PYR_STAGE_MAX];
+            if (C.copy0 && w < 16) {                               // (rows narrower than one chunk: byte by byte, no chain is built for them in practice)
 #pragma unroll
-            for (int i = 0; i < PYR_STAGE_MAX; i++) {
-                const int idx = base + i * 256 + tid;
-                if (idx < total) {
-                    const int r = C.invCpr ? (int)__umulhi((unsigned)idx, C.invCpr) : idx, c = idx - r * cpr;
-                    const uint8_t* s = src + (size_t)r * stride + 16 * c;
-                    if (16 * c + 16 <= w) {
-                        v[i] = *reinterpret_cast<const orb_u32x4_a1*>(s);
-                    } else {                                       // last chunk of a row whose width is not a multiple of 16
+                for (int i = 0; i < PYR_STAGE_MAX; i++) {
+                    const int idx = base + i * 256 + tid;
+                    if (idx < total) {
+                        const int r = C.invCpr ? (int)__umulhi((unsigned)idx, C.invCpr) : idx, c = idx - r * cpr;
+                        const uint8_t* s = src + (size_t)r * stride + 16 * c;
                         const int n = w - 16 * c;
-                        unsigned t0 = 0, t1 = 0, t2 = 0, t3 = 0;
-#pragma unroll
+                        unsigned t[4] = {0, 0, 0, 0};
                         for (int j = 0; j < 15; j++)
-                            if (j < n) {
-                                const unsigned by = (unsigned)s[j] << (8 * (j & 3));
-                                if (j < 4) t0 |= by; else if (j < 8) t1 |= by; else if (j < 12) t2 |= by; else t3 |= by;
-                            }
-                        v[i] = orb_u32x4{t0, t1, t2, t3};
+                            if (j < n) t[j >> 2] |= (unsigned)s[j] << (8 * (j & 3));
+                        v[i] = orb_u32x4{t[0], t[1], t[2], t[3]};
+                    }
+                }
+            } else {
+                // UNCONDITIONAL loads (a thread beyond the band's last chunk re-reads that chunk): an `if (idx < total) v[i] = ...`
+                // makes every v[i] a phi of the whole register array, and the compiler then waits for each load where it merges
+#pragma unroll
+                for (int i = 0; i < PYR_STAGE_MAX; i++) {
+                    const int idx = min(base + i * 256 + tid, total - 1);
+                    const int r = C.invCpr ? (int)__umulhi((unsigned)idx, C.invCpr) : idx, c = idx - r * cpr;
+                    const bool part = canPart && 16 * c + 16 > w;
+                    v[i] = *reinterpret_cast<const orb_u32x4_a1*>(src + (size_t)r * stride + (part ? w - 16 : 16 * c));
+                }
+                if (canPart) {
+#pragma unroll
+                    for (int i = 0; i < PYR_STAGE_MAX; i++) {
+                        const int idx = min(base + i * 256 + tid, total - 1);
+                        const int r = C.invCpr ? (int)__umulhi((unsigned)idx, C.invCpr) : idx, c = idx - r * cpr;
+                        // bytes [w - 16, w) of the row are in v; the chunk wants bytes [16 c, w) in front and zeros behind:
+                        // a 128-bit shift right by k = 16 - (w - 16 c) bytes (k = 0 .. 15; whole chunks: k <= 0, left as they are)
+                        const int k = 16 - (w - 16 * c), dw = k >> 2;
+                        const unsigned sh = (unsigned)k & 3u;
+                        const unsigned t0 = v[i].x, t1 = v[i].y, t2 = v[i].z, t3 = v[i].w;
+                        const unsigned a0 = dw == 0 ? t0 : dw == 1 ? t1 : dw == 2 ? t2 : t3;
+                        const unsigned a1 = dw == 0 ? t1 : dw == 1 ? t2 : dw == 2 ? t3 : 0u;
+                        const unsigned a2 = dw == 0 ? t2 : dw == 1 ? t3 : 0u;
+                        const unsigned a3 = dw == 0 ? t3 : 0u;
+                        const bool part = k > 0;
+                        v[i].x = part ? __builtin_amdgcn_alignbyte(a1, a0, sh) : t0;
+                        v[i].y = part ? __builtin_amdgcn_alignbyte(a2, a1, sh) : t1;
+                        v[i].z = part ? __builtin_amdgcn_alignbyte(a3, a2, sh) : t2;
+                        v[i].w = part ? __builtin_amdgcn_alignbyte(0u, a3, sh) : t3;
                     }
                 }
             }
@@ -399,12 +432,25 @@ __global__ __launch_bounds__(256) void k_pyr_chain(const OrbPyrChain C, const ui
             }
         }
     }
+    if (rpAct) {
+        const int k = rpK;
+        const int pitchB = 4 * (k == 0 ? C.srcLdsPitchDw : C.st[k - 1].ldsPitchDw);
+        const int base = k == 0 ? C.srcLdsOff : C.st[k - 1].ldsOff;
+        uint4 e;
+        e.x = (unsigned)(base + ((rpTy.x & 0xffff) - rpSrcRow0) * pitchB);
+        e.y = (unsigned)(base + ((int)((unsigned)rpTy.x >> 16) - rpSrcRow0) * pitchB);
+        e.z = (unsigned)rpTy.y << 16;
+        e.w = (unsigned)rpTy.y & 0xffff0000u;
+        *reinterpret_cast<uint4*>(lds + C.st[k].rpOff + 16 * rpT) = e;
+    }
     if constexpr (XL) {
 #pragma unroll
         for (int i = 0; i < 4; i++)
             if (tid + 256 * i < C.xqLdsN) *reinterpret_cast<orb_u32x4*>(lds + C.xqLdsOff + 16 * (tid + 256 * i)) = xv[i];
     }
+    PYR_STAMP(1);
     __syncthreads();
+    PYR_STAMP(2);
 
     // ---- level after level out of LDS: one item = 4 pixels x RG rows (RG = 4 amortises the column entry best, RG = 1 / 2 leave
     // fewer threads idle in the last pass over a band: the host picks per chain)
@@ -482,7 +528,9 @@ __global__ __launch_bounds__(256) void k_pyr_chain(const OrbPyrChain C, const ui
             if constexpr (!XL) { q0 = n0; q1 = n1; q2 = n2; g = gN; x4 = x4N; }
         }
         __syncthreads();
+        PYR_STAMP(3 + k);
     }
+#undef PYR_STAMP
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -530,13 +578,16 @@ void orb_launch_resize(hipStream_t st, uint8_t* pyr, size_t pyrSlab, const OrbLe
 
 void orb_launch_pyr_chain(hipStream_t st, const OrbPyrChain& C, const uint8_t* img, size_t rowStride, size_t frameStride,
                           uint8_t* pyr, size_t pyrSlab, const uint4* xqAll, const int2* ytAll, const int2* bandTab, int nFrames,
-                          int* clr, int clrInts, const int8_t* pat8, float* patF)
+                          int* clr, int clrInts, const int8_t* pat8, float* patF, unsigned long long* stamps)
 {
     static const int rg = std::getenv("ORB_PYR_RG") ? std::atoi(std::getenv("ORB_PYR_RG")) : 4;
+    // ORB_PYR_LDSMIN=<KB> (tuning): claim at least that much LDS per workgroup, i.e. FEWER workgroups of this latency-bound kernel
+    // per CU, so that other lanes' kernels find LDS and wave slots beside it
+    static const size_t ldsMin = std::getenv("ORB_PYR_LDSMIN") ? (size_t)std::max(0, std::min(64, std::atoi(std::getenv("ORB_PYR_LDSMIN")))) * 1024 : 0;
     auto go = [&](auto kern) {
-        hipLaunchKernelGGL(kern, dim3(C.bands, nFrames), dim3(256), (size_t)C.ldsBytes, st, C, img, rowStride, frameStride, pyr,
+        hipLaunchKernelGGL(kern, dim3(C.bands, nFrames), dim3(256), std::max((size_t)C.ldsBytes, ldsMin), st, C, img, rowStride, frameStride, pyr,
                            pyrSlab, xqAll, ytAll, bandTab, clr, clrInts, reinterpret_cast<const char4*>(pat8),
-                           reinterpret_cast<float4*>(patF));
+                           reinterpret_cast<float4*>(patF), stamps);
     };
     if (C.xqLdsN > 0) {
         if (rg == 1) go(k_pyr_chain<1, true>);

@@ -492,10 +492,17 @@ extern "C" int orb_extract_batch_device(orb_extractor* h, const uint8_t* d_imgs,
                                                      //  16 / 32 frames: one 0.032 / 0.043 ms, few 0.035 / 0.047, batch 0.042 / 0.046;
                                                      //  40 / 64 / 96 frames: batch 0.049 / 0.061 / 0.071, few 0.051 / 0.069 / 0.093)
         const std::vector<OrbPyrChain>& chains = which == 2 ? h->pyrChainsOne : which == 1 ? h->pyrChainsLat : h->pyrChains;
-        for (size_t c = 0; c < chains.size(); c++)
+        size_t stampOff = 0;                                   // diagnostics: 8 words per workgroup, launch after launch
+        for (size_t c = 0; c < chains.size(); c++) {
+            const size_t words = (size_t)chains[c].bands * n * 8;
+            unsigned long long* stp = h->pyrStamps && stampOff + words <= h->pyrStampCap ? h->pyrStamps + stampOff : nullptr;
+            stampOff += words;
             orb_launch_pyr_chain(st, chains[c], d_imgs, rowStride, frameStride, pyr, h->pyrSlab, (const uint4*)h->dXq.p,
                                  (const int2*)h->dYtab.p, (const int2*)h->dBand.p, n, c == 0 ? h->errP() : nullptr,
-                                 (int)orb_extractor::batchInts(n), h->patternPtr, (float*)h->dPatternF.p);
+                                 (int)orb_extractor::batchInts(n), h->patternPtr, (float*)h->dPatternF.p, stp);
+        }
+        h->pyrStampChains = (int)chains.size();
+        for (size_t c = 0; c < chains.size() && c < 8; c++) { h->pyrStampBands[c] = chains[c].bands; h->pyrStampSteps[c] = chains[c].nSteps; }
     } else {
     orb_launch_copy_level0(st, d_imgs, rowStride, frameStride, pyr, h->pyrSlab, G.L[0].w, G.L[0].h, G.L[0].pitch, n, h->errP(),
                            (int)orb_extractor::batchInts(n), h->patternPtr, (float*)h->dPatternF.p);
@@ -903,6 +910,25 @@ extern "C" int orb_extractor_set_desc_stamps(orb_extractor* h, unsigned long lon
     if (!h) return ORB_ERR_INVALID;
     h->descStamps = d_stamps;
     h->descStampCap = d_stamps ? capacity : 0;
+    return ORB_OK;
+}
+
+extern "C" int orb_extractor_set_pyr_stamps(orb_extractor* h, unsigned long long* d_stamps, size_t capacity)
+{
+    if (!h) return ORB_ERR_INVALID;
+    h->pyrStamps = d_stamps;
+    h->pyrStampCap = d_stamps ? capacity : 0;
+    return ORB_OK;
+}
+
+extern "C" int orb_extractor_pyr_stamp_layout(const orb_extractor* h, int32_t* n_chains, int32_t* bands8, int32_t* steps8)
+{
+    if (!h || !n_chains) return ORB_ERR_INVALID;
+    *n_chains = h->pyrStampChains;
+    for (int c = 0; c < 8; c++) {
+        if (bands8) bands8[c] = c < h->pyrStampChains ? h->pyrStampBands[c] : 0;
+        if (steps8) steps8[c] = c < h->pyrStampChains ? h->pyrStampSteps[c] : 0;
+    }
     return ORB_OK;
 }
 

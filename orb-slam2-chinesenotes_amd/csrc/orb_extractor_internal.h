@@ -50,6 +50,9 @@ struct orb_extractor {
     int rows = 0, cols = 0;
     int lastGeomRows = 0, lastGeomCols = 0;     // size of the last successful geometry build (survives a failed one)
     OrbGeom G;
+    unsigned long long* pyrStamps = nullptr;    // diagnostics: phase stamps of the k_pyr_chain launches (orb_extractor_set_pyr_stamps)
+    size_t pyrStampCap = 0;
+    int pyrStampChains = 0, pyrStampBands[8] = {}, pyrStampSteps[8] = {};
     unsigned long long* descStamps = nullptr;   // diagnostics: phase stamps of k_desc_level (orb_extractor_set_desc_stamps)
     size_t descStampCap = 0;
     OrbDescPlan descPlan;                       // level-resident descriptor stage: regions of the upper levels (orb_desc_level_plan)

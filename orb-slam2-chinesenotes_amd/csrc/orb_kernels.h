@@ -11,7 +11,7 @@ void orb_launch_resize(hipStream_t st, uint8_t* pyr, size_t pyrSlab, const OrbLe
                        const OrbLevelGeom& dst, const int2* xtab, const int2* ytab, const uint4* xq, int nFrames);
 void orb_launch_pyr_chain(hipStream_t st, const OrbPyrChain& C, const uint8_t* img, size_t rowStride, size_t frameStride,
                           uint8_t* pyr, size_t pyrSlab, const uint4* xqAll, const int2* ytAll, const int2* bandTab, int nFrames,
-                          int* clr, int clrInts, const int8_t* pat8, float* patF);
+                          int* clr, int clrInts, const int8_t* pat8, float* patF, unsigned long long* stamps = nullptr);
 size_t orb_fast_lds_bytes(int pdw, int rowsMax, int candCap);
 size_t orb_fast_dense_lds_bytes(int pdw, int rowsMax, int sdw);
 void orb_launch_fast_strips(hipStream_t st, const OrbGeom& G, const uint8_t* pyr, size_t pyrSlab,
