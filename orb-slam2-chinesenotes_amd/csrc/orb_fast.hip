@@ -533,7 +533,18 @@ __global__ __launch_bounds__(WAVE) void k_fast_strips_p(const OrbGeom G, const u
         if (lane == 0) orb_flag_error(errFlags, f, 1);
         return;
     }
-    const OrbStrip S = strips[si];
+    // The 48-byte strip record as THREE SCALAR loads (round 5): its fields are bytes and shorts, which the compiler fetched with
+    // five vector loads off a vector index -- a vector-memory round trip at the head of every wave, in front of the staging
+    // loads that depend on it; the index is wave-uniform, the scalar cache serves the record (shared by all frames) at once.
+    f = __builtin_amdgcn_readfirstlane(f);
+    si = __builtin_amdgcn_readfirstlane(si);
+    OrbStrip S;
+    {
+        const uint4* rec = reinterpret_cast<const uint4*>(strips + si);
+        const uint4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+        uint4 tmp[3] = {r0, r1, r2};
+        __builtin_memcpy(&S, tmp, sizeof(S));
+    }
     const OrbLevelGeom& L = G.L[S.level];
 
     // ---- stage rows [y0, y0 + h) from the 8-byte aligned column x0 - xoff, ROWB bytes per row, 16 bytes per lane
@@ -845,20 +856,20 @@ __device__ __forceinline__ void fast_mw_strip(uint32_t* fsm, const OrbGeom& G, c
     int* shared = reinterpret_cast<int*>(lds + CB + ((3 * candCap + 3) & ~3));
     if (tid == 0) { shared[0] = 0; shared[1] = 0; }
 
-    // ---- stage rows [y0, y0 + h): 16 bytes per thread, T / CL rows per step
+    // ---- stage rows [y0, y0 + h): 16 bytes per thread, T / CL rows per step.  UNCONDITIONAL loads (a thread outside the tile
+    // re-reads the tile's last row / last chunk): with `if (...) v[it] = load` the compiler waited for every load before it
+    // issued the next -- three round trips in a row at the head of a kernel whose whole life is ~10 us (round 5, tools/isa_waits.py)
     {
         constexpr int CL = FastMW<P>::CL, RI = FastMW<P>::RI, MAXIT = FastMW<P>::MAXIT, NC = P / 4;
         const int rr = tid / CL, c = tid % CL;
         const int h = S.h, pitch = L.pitch;
-        const uint8_t* src = pyr + (size_t)f * pyrSlab + L.pyrOff + (size_t)(S.y0 + rr) * pitch + (S.x0 - S.xoff) + 16 * c;
+        const uint8_t* src = pyr + (size_t)f * pyrSlab + L.pyrOff + (size_t)S.y0 * pitch + (S.x0 - S.xoff) + 16 * min(c, NC - 1);
         uint8_t* dst = lds + TB + rr * ROWB + 16 * c;
         const bool act = c < NC;
         orb_u32x4 v[MAXIT];
 #pragma unroll
         for (int it = 0; it < MAXIT; it++)
-            if (it * RI < h) {
-                if (act && it * RI + rr < h) v[it] = *reinterpret_cast<const orb_u32x4_a8*>(src + (size_t)it * RI * pitch);
-            }
+            v[it] = *reinterpret_cast<const orb_u32x4_a8*>(src + (size_t)min(it * RI + rr, h - 1) * pitch);
 #pragma unroll
         for (int it = 0; it < MAXIT; it++)
             if (it * RI < h) {
@@ -1095,7 +1106,13 @@ __global__ __launch_bounds__(WAVE * MW_WAVES) void k_fast_strips_mw(const OrbGeo
 {
     extern __shared__ uint32_t fsm[];
     const int f = blockIdx.y, si = blockIdx.x;
-    const OrbStrip S = strips[si];
+    OrbStrip S;                                                    // three scalar loads (see k_fast_strips_p)
+    {
+        const uint4* rec = reinterpret_cast<const uint4*>(strips + si);
+        const uint4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+        uint4 tmp[3] = {r0, r1, r2};
+        __builtin_memcpy(&S, tmp, sizeof(S));
+    }
     fast_mw_strip<P>(fsm, G, pyr, pyrSlab, S, f, si, pathTab, cand, candSlab, candCount, errFlags, ovfCount, ovfList, iniTh, minTh,
                      rowsMax, candCap);
 }
