@@ -105,8 +105,13 @@ def parse():
     ap.add_argument("--c5-extractors", type=int, default=2, help="config 5: extractor handles that consecutive stream frames alternate between")
     ap.add_argument("--c5-three-calls", action="store_true", help="config 5: ComputeBoW and the search as three calls of the C ABI "
                     "(descent, feature vector, search) instead of the fused orb_bow_query_frames_device")
-    ap.add_argument("--c5-matchers", type=int, default=1, help="config 5: matcher handles that consecutive stream frames alternate between")
-    ap.add_argument("--c5-slots", type=int, default=4, help="config 5: query slots in the ring between the extractor and the matcher stream")
+    ap.add_argument("--c5-matchers", type=int, default=2, help="config 5: matcher handles that consecutive stream frames alternate between "
+                    "(round 5: 2 -- ComputeBoW of frame i + 1 beside the search of frame i: 0.077 -> 0.064 ms per frame)")
+    ap.add_argument("--c5-slots", type=int, default=6, help="config 5: query slots in the ring between the extractor and the matcher streams "
+                    "(round 5: 6 with two matcher handles: 0.064 -> 0.051 ms per frame)")
+    ap.add_argument("--c5-python-loop", action="store_true", help="config 5: time the frame loop as bench.py's Python loop submits it (the "
+                    "interpreter is then what bounds the step); default: the same loop from C (tools/c5_loop.c through ctypes), "
+                    "the Python figure reported beside it")
     ap.add_argument("--stream-frames", type=int, default=256,
                     help="config c5: distinct stream frames resident in HBM that the timed steps walk through (3682 = the whole "
                          "EuRoC MH01-sized sequence of BASELINE configs[4]; generating them on the host takes about a minute)")
@@ -134,6 +139,22 @@ def profile_path(name):
            "c5_pmc_traffic.json": "r[0-9][0-9]_c5_pmc_traffic.json"}.get(name)
     cands = sorted(glob.glob(os.path.join(ROOT, "profiles", pat))) if pat else []
     return cands[-1] if cands else os.path.join(ROOT, "profiles", name)
+
+
+def load_c5_loop():
+    """tools/libc5loop.so (tools/c5_loop.c: the frame loop of config 5 from C), built on demand; None when it cannot be built."""
+    import ctypes as C
+    so = os.path.join(ROOT, "tools", "libc5loop.so")
+    src = os.path.join(ROOT, "tools", "c5_loop.c")
+    try:
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "orb-slam2-chinesenotes_amd"), "c5-loop"], check=True, capture_output=True, timeout=120)
+        lib = C.CDLL(so)
+        lib.c5_loop_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        lib.c5_loop_run.restype = C.c_int
+        return lib
+    except Exception:
+        return None
 
 
 def load_profile(name):
@@ -906,20 +927,58 @@ def run_c5(args, rank, local_rank, world, dev, comm_dev, dist):
             match(i)
             ev_mt[i % NSLOT].record(mt_ss[i % NMT])
 
+    # The same loop from C (tools/c5_loop.c, built on demand): the reference's caller is C++ (Tracking::Relocalization), and
+    # through the interpreter the submission of a step -- two library calls, four event operations -- is what bounds it once
+    # the GPU side is pipelined.  Only the plain per-frame configuration (the fused ComputeBoW + search call) has a C form.
+    c_loop = None
+    plain = not (bow_early or args.c5_pair_kernel or args.c5_three_calls)
+    if plain and not args.c5_python_loop:
+        c_loop = load_c5_loop()
+    if c_loop is not None:
+        import ctypes as C
+
+        class LoopArgs(C.Structure):
+            _fields_ = [("ex", C.POINTER(C.c_void_p)), ("mt", C.POINTER(C.c_void_p)), ("voc", C.c_void_p), ("store", C.c_void_p),
+                        ("d_stream", C.c_void_p), ("d_kf_index", C.c_void_p), ("d_f_index", C.POINTER(C.c_void_p)),
+                        ("d_match", C.POINTER(C.c_void_p)), ("d_nmatches", C.POINTER(C.c_void_p)), ("d_kps", C.c_void_p),
+                        ("d_desc", C.c_void_p), ("d_counts", C.c_void_p)] + \
+                       [(n, C.c_int32) for n in ("n_ex", "n_mt", "n_slots", "slot_stride", "n_kf", "cap", "rows", "cols", "n_stream",
+                                                 "levelsup", "check_ori")] + [("ratio", C.c_float)]
+        arr = lambda vals: (C.c_void_p * len(vals))(*vals)
+        c_store = capi.Matcher._store(store)
+        c_keep = (arr([e.h.value for e in exs]), arr([m.h.value for m in mts]), arr([t.data_ptr() for t in f_idx]),
+                  arr([t.data_ptr() for t in d_match]), arr([t.data_ptr() for t in d_nm]), c_store)
+        la = LoopArgs(c_keep[0], c_keep[1], voc.h, C.cast(C.pointer(c_store), C.c_void_p), stream.data_ptr(), kf_idx.data_ptr(), c_keep[2],
+                      c_keep[3], c_keep[4], d_kps.data_ptr(), d_desc.data_ptr(), d_counts.data_ptr(), NEX, NMT, NSLOT, QMAX, n_kf, cap, H, W,
+                      n_q, 4, 1, 0.7)
+
+        def run_c(n, i0=0):
+            sub = C.c_double(0.0)
+            rc = c_loop.c5_loop_run(C.byref(la), i0, n, C.byref(sub))
+            if rc != 0:
+                raise SystemExit("c5_loop_run failed: %d (%s)" % (rc, capi.lib().orb_last_error().decode(errors="replace")))
+            return sub.value
+    sync_all = lambda: ([e.sync() for e in exs], [m.sync() for m in mbs + mts], torch.cuda.synchronize())
+
     for _ in range(3):                             # (synchronised calls first: the FAST strip lengths settle)
         run(1)
-        [e.sync() for e in exs]; [m.sync() for m in mbs + mts]
-    run(max(args.warmup, 2))
-    [e.sync() for e in exs]; [m.sync() for m in mbs + mts]; torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    t0 = time.perf_counter()
-    run(args.steps)
-    t_submit = time.perf_counter() - t0            # host side alone: when it is close to `elapsed` the step is bound by the launches
-    [e.sync() for e in exs]; [m.sync() for m in mbs + mts]; torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = shard.max_over_ranks(dist, time.perf_counter() - t0, comm_dev)
+        sync_all()
+
+    def timed(loop):
+        loop(max(args.warmup, 2))
+        sync_all()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        sub = loop(args.steps)
+        t_sub = time.perf_counter() - t0           # host side alone: when it is close to `elapsed` the step is bound by the launches
+        sync_all()
+        if dist is not None:
+            dist.barrier()
+        return shard.max_over_ranks(dist, time.perf_counter() - t0, comm_dev), (sub if sub is not None else t_sub)
+
+    py_elapsed, py_submit = timed(run)
+    elapsed, t_submit = timed(run_c) if c_loop is not None else (py_elapsed, py_submit)
     done = shard.sum_over_ranks(dist, args.steps, comm_dev)
     # the same stream in mini-batches of QMAX frames per step (offline sequence processing): throughput, not `value`
     mini_fps = 0.0
@@ -978,7 +1037,11 @@ def run_c5(args, rank, local_rank, world, dev, comm_dev, dist):
                       "distinct_stream_frames": n_q, "extractor_handles": NEX, "matcher_handles": NMT, "compute_bow": "behind the extraction" if bow_early else "in front of the search",
                       "frames_per_s_in_mini_batches_of_%d" % QMAX: round(mini_fps, 1),
                       "transform_plus_match_ms_alone": round(match_ms, 4),
-                      "host_submit_ms_per_step": round(t_submit / args.steps * 1e3, 4)},
+                      "query_slots": NSLOT,
+                      "frame_loop": "C (tools/c5_loop.c through ctypes: what a C++ caller of the C ABI submits)" if c_loop is not None else "Python (bench.py)",
+                      "host_submit_ms_per_step": round(t_submit / args.steps * 1e3, 4),
+                      "python_loop_ms_per_step": round(py_elapsed / args.steps * 1e3, 4),
+                      "python_loop_host_submit_ms_per_step": round(py_submit / args.steps * 1e3, 4)},
            "roofline": {"bound": "hbm", "kernel": kern, "achieved": round(ach, 2),
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                         "traffic_source": traffic_src, "algorithmic_bytes_per_query": int(bytes_query),
