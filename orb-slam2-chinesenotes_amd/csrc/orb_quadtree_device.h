@@ -620,7 +620,16 @@ __device__ __forceinline__ void qt_instance_lds(unsigned long long* qsm, int* sh
     }
     unsigned long long* gk = cand + (size_t)f * candSlab + L.candBase;
     if (n <= sortCap) {
-        for (int i = tid; i < n; i += T) ldsKeys[i] = gk[i];
+        // the candidate keys, eight loads of a thread in flight at once (unconditional, clamped: a plain `for (i ...) lds[i] = gk[i]`
+        // compiles to load -> wait -> store per iteration, i.e. n / 256 memory round trips in a row at the head of the workgroup)
+        for (int i0 = tid; i0 < n; i0 += 8 * T) {
+            unsigned long long kv[8];
+#pragma unroll
+            for (int b = 0; b < 8; b++) kv[b] = gk[min(i0 + b * T, n - 1)];
+#pragma unroll
+            for (int b = 0; b < 8; b++)
+                if (i0 + b * T < n) ldsKeys[i0 + b * T] = kv[b];
+        }
         // scratch of the bucket sort: the node lists behind the keys (prevA .. part), unused until the sort is done
         qt_body(ldsKeys, n, G, L, f, prevA, prevB, A, B, cuts, va, vb, part, kpl, outCount, errFlags, sh,
                 reinterpret_cast<unsigned char*>(prevA), nodeCap * (16 + 2 * (int)sizeof(QtNode) + (int)sizeof(int3) + 8) + 257 * 4, nodeCap);
