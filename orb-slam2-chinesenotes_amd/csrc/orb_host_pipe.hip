@@ -15,35 +15,7 @@
 #include <vector>
 
 #include "orb_extractor_internal.h"
-
-// fn(i) for i in [0, n), split over a few short-lived threads when the items are worth it (>= 2 MB per thread)
-template <class F>
-static void par_items(int n, size_t bytesPerItem, F fn)
-{
-    static const int maxT = [] {
-        const char* e = std::getenv("ORB_HOST_THREADS");
-        const int t = e ? std::atoi(e) : (int)std::min(4u, std::max(1u, std::thread::hardware_concurrency()));
-        return std::max(1, std::min(16, t));
-    }();
-    int T = (int)std::min<size_t>((size_t)maxT, std::max<size_t>(1, (size_t)n * bytesPerItem / ((size_t)2 << 20)));
-    T = std::min(T, n);
-    std::vector<std::thread> th;
-    if (T > 1) {
-        try {
-            for (int t = 1; t < T; t++)
-                th.emplace_back([=] { for (int i = t; i < n; i += T) fn(i); });
-        } catch (...) {                                        // no more threads to be had: the caller's thread does the rest
-            const int started = (int)th.size() + 1;
-            for (std::thread& x : th) x.join();
-            for (int t = started; t < T; t++)
-                for (int i = t; i < n; i += T) fn(i);
-            for (int i = 0; i < n; i += T) fn(i);
-            return;
-        }
-    }
-    for (int i = 0; i < n; i += std::max(T, 1)) fn(i);
-    for (std::thread& x : th) x.join();
-}
+#include "orb_host_threads.h"                // the chunk pipeline and its copy threads, HIP-free (runs under TSan with a fake device)
 
 static bool is_pinned(const void* p)
 {
@@ -128,102 +100,111 @@ int orb_extract_batch_pipelined(orb_extractor* h, const uint8_t* imgs, int nFram
     }
     if (!inPinned && (rc = ensure_pinned(P.pinIn, &P.pinInBytes, imgBytes * C)) != ORB_OK) return rc;
     if ((rc = ensure_pinned(P.pinOut, &P.pinOutBytes, outB)) != ORB_OK) return rc;
-    hipStream_t cs = h->stream;
-    int firstErr = ORB_OK;
-    const int NS = orb_extractor::kPipeSlots;
-    unsigned chunkSerial[orb_extractor::kPipeSlots] = {};
-
-    auto issue = [&](int k) -> int {
-        const int s = k % NS, f0 = k * C, c = std::min(C, nFrames - f0);
-        const uint8_t* src = imgs + frameStride * f0;
-        size_t srcRow = rowStride, srcFrame = frameStride;
-        if (!inPinned) {                                       // pageable input: CPU copy into this slot's pinned buffer
+    // The scheduling (issue / retire order, slot reuse, the copy threads) is orb_pipe_run (csrc/orb_host_threads.h, HIP-free:
+    // tools/tsan_host.cpp runs it against a fake device under the thread sanitizer); what follows is its device side.
+    struct HipOps {
+        orb_extractor* h;
+        orb_extractor::Pipe& P;
+        const uint8_t* imgs; orb_keypoint* kps; uint8_t* desc; int32_t* counts;
+        int rows, cols, cap, C;
+        size_t rowStride, frameStride, imgBytes, kpSlab, dsSlab, statB, cntB;
+        bool inPinned, outPinned;
+        hipStream_t cs;
+        unsigned chunkSerial[orb_extractor::kPipeSlots] = {};
+        HipOps(orb_extractor* hh, orb_extractor::Pipe& pp) : h(hh), P(pp) {}
+        bool in_pinned() const { return inPinned; }
+        bool out_pinned() const { return outPinned; }
+        size_t in_bytes_per_frame() const { return imgBytes; }
+        size_t out_bytes_per_frame() const { return kpSlab + dsSlab; }
+        void stage_frame(int s, int f, int frame) const       // pageable input: CPU copy into this slot's pinned buffer
+        {
             uint8_t* st = (uint8_t*)P.pinIn[s];
-            par_items(c, imgBytes, [=](int f) {
-                for (int y = 0; y < (rowStride == (size_t)cols ? 1 : rows); y++)
-                    std::memcpy(st + imgBytes * f + (size_t)y * cols, imgs + frameStride * (f0 + f) + rowStride * y,
-                                rowStride == (size_t)cols ? imgBytes : (size_t)cols);
-            });
-            src = st; srcRow = cols; srcFrame = imgBytes;
+            for (int y = 0; y < (rowStride == (size_t)cols ? 1 : rows); y++)
+                std::memcpy(st + imgBytes * f + (size_t)y * cols, imgs + frameStride * frame + rowStride * y,
+                            rowStride == (size_t)cols ? imgBytes : (size_t)cols);
         }
-        if (srcRow == (size_t)cols && srcFrame == imgBytes) {
-            ORB_HIP_TRY(hipMemcpyAsync(P.dImg[s].p, src, imgBytes * c, hipMemcpyHostToDevice, P.h2d));
-        } else {
-            for (int f = 0; f < c; f++) {
-                if (srcRow == (size_t)cols)
-                    ORB_HIP_TRY(hipMemcpyAsync((uint8_t*)P.dImg[s].p + imgBytes * f, src + srcFrame * f, imgBytes, hipMemcpyHostToDevice, P.h2d));
-                else
-                    ORB_HIP_TRY(hipMemcpy2DAsync((uint8_t*)P.dImg[s].p + imgBytes * f, cols, src + srcFrame * f, srcRow, cols, rows,
-                                                 hipMemcpyHostToDevice, P.h2d));
+        int upload(int s, int f0, int c)
+        {
+            const uint8_t* src = imgs + frameStride * f0;
+            size_t srcRow = rowStride, srcFrame = frameStride;
+            if (!inPinned) { src = (const uint8_t*)P.pinIn[s]; srcRow = cols; srcFrame = imgBytes; }
+            if (srcRow == (size_t)cols && srcFrame == imgBytes) {
+                ORB_HIP_TRY(hipMemcpyAsync(P.dImg[s].p, src, imgBytes * c, hipMemcpyHostToDevice, P.h2d));
+            } else {
+                for (int f = 0; f < c; f++) {
+                    if (srcRow == (size_t)cols)
+                        ORB_HIP_TRY(hipMemcpyAsync((uint8_t*)P.dImg[s].p + imgBytes * f, src + srcFrame * f, imgBytes, hipMemcpyHostToDevice, P.h2d));
+                    else
+                        ORB_HIP_TRY(hipMemcpy2DAsync((uint8_t*)P.dImg[s].p + imgBytes * f, cols, src + srcFrame * f, srcRow, cols, rows,
+                                                     hipMemcpyHostToDevice, P.h2d));
+                }
             }
+            return ORB_OK;
         }
-        ORB_HIP_TRY(hipEventRecord(P.evIn[s], P.h2d));
-        ORB_HIP_TRY(hipStreamWaitEvent(cs, P.evIn[s], 0));
-        if (k >= NS) ORB_HIP_TRY(hipStreamWaitEvent(cs, P.evOut[s], 0));      // this slot's outputs of chunk k - NS have left
-        int r = orb_extract_batch_device(h, (const uint8_t*)P.dImg[s].p, c, rows, cols, cols, imgBytes, (orb_keypoint*)P.dKps[s].p,
-                                         (uint8_t*)P.dDesc[s].p, cap, (int32_t*)P.dCnt[s].p);
-        if (r != ORB_OK) return r;
-        chunkSerial[s] = h->batchSerial;
-        // the status block is the handle's single one: it leaves on the compute stream, before the next chunk clears it
-        uint8_t* po = (uint8_t*)P.pinOut[s];
-        ORB_HIP_TRY(hipMemcpyAsync(po, h->dStat.p, orb_extractor::statInts(c) * 4, hipMemcpyDeviceToHost, cs));
-        ORB_HIP_TRY(hipEventRecord(P.evK[s], cs));
-        ORB_HIP_TRY(hipStreamWaitEvent(P.d2h, P.evK[s], 0));
-        ORB_HIP_TRY(hipMemcpyAsync(po + statB, P.dCnt[s].p, (size_t)4 * c, hipMemcpyDeviceToHost, P.d2h));
-        if (outPinned) {
-            ORB_HIP_TRY(hipMemcpyAsync(kps + (size_t)cap * f0, P.dKps[s].p, kpSlab * c, hipMemcpyDeviceToHost, P.d2h));
-            ORB_HIP_TRY(hipMemcpyAsync(desc + dsSlab * f0, P.dDesc[s].p, dsSlab * c, hipMemcpyDeviceToHost, P.d2h));
-        } else {
-            ORB_HIP_TRY(hipMemcpyAsync(po + statB + cntB, P.dKps[s].p, kpSlab * c, hipMemcpyDeviceToHost, P.d2h));
-            ORB_HIP_TRY(hipMemcpyAsync(po + statB + cntB + kpSlab * C, P.dDesc[s].p, dsSlab * c, hipMemcpyDeviceToHost, P.d2h));
+        int mark_uploaded(int s) { ORB_HIP_TRY(hipEventRecord(P.evIn[s], P.h2d)); return ORB_OK; }
+        int compute_waits_upload(int s) { ORB_HIP_TRY(hipStreamWaitEvent(cs, P.evIn[s], 0)); return ORB_OK; }
+        int compute_waits_download(int s) { ORB_HIP_TRY(hipStreamWaitEvent(cs, P.evOut[s], 0)); return ORB_OK; }   // this slot's outputs of chunk k - NS have left
+        int extract(int s, int c)
+        {
+            int r = orb_extract_batch_device(h, (const uint8_t*)P.dImg[s].p, c, rows, cols, cols, imgBytes, (orb_keypoint*)P.dKps[s].p,
+                                             (uint8_t*)P.dDesc[s].p, cap, (int32_t*)P.dCnt[s].p);
+            if (r != ORB_OK) return r;
+            chunkSerial[s] = h->batchSerial;
+            // the status block is the handle's single one: it leaves on the compute stream, before the next chunk clears it
+            ORB_HIP_TRY(hipMemcpyAsync(P.pinOut[s], h->dStat.p, orb_extractor::statInts(c) * 4, hipMemcpyDeviceToHost, cs));
+            return ORB_OK;
         }
-        ORB_HIP_TRY(hipEventRecord(P.evOut[s], P.d2h));
-        return ORB_OK;
-    };
-
-    auto retire = [&](int k) -> int {
-        const int s = k % NS, f0 = k * C, c = std::min(C, nFrames - f0);
-        ORB_HIP_TRY(hipEventSynchronize(P.evOut[s]));
-        const uint8_t* po = (const uint8_t*)P.pinOut[s];
-        const int keepFrames = h->lastFrames;                  // orb_check_status reads the block of `c` frames
-        h->lastFrames = c;
-        h->hStat.assign((const int*)po, (const int*)po + orb_extractor::statInts(c));
-        h->statSerial = chunkSerial[s];
-        int r = orb_check_status(h);
-        h->statSerial = 0;
-        h->lastFrames = keepFrames;
-        std::memcpy(counts + f0, po + statB, (size_t)4 * c);
-        if (r != ORB_OK) return r;
-        if (!outPinned)
-            par_items(c, kpSlab + dsSlab, [=](int f) {
-                const int n = counts[f0 + f];
-                if (n <= 0) return;
-                std::memcpy(kps + (size_t)cap * (f0 + f), po + statB + cntB + kpSlab * f, sizeof(orb_keypoint) * (size_t)n);
-                std::memcpy(desc + dsSlab * (f0 + f), po + statB + cntB + kpSlab * C + dsSlab * f, (size_t)ORB_DESC_BYTES * n);
-            });
-        return ORB_OK;
-    };
-
-    // chunk k is issued while chunk k - 1 runs and chunk k - 2 is retired: the host copies chunk k's images into pinned
-    // staging (pageable callers) BEFORE it waits for anything -- with two slots it waited for chunk k - 1's results first,
-    // and the H2D engine idled for as long as that copy took
-    int issued = 0;
-    for (int k = 0; k <= nChunks + 1; k++) {
-        if (k < nChunks && firstErr == ORB_OK) {
-            const int r = issue(k);
-            if (r != ORB_OK) firstErr = r; else issued = k + 1;
+        int mark_computed(int s) { ORB_HIP_TRY(hipEventRecord(P.evK[s], cs)); return ORB_OK; }
+        int download_waits_compute(int s) { ORB_HIP_TRY(hipStreamWaitEvent(P.d2h, P.evK[s], 0)); return ORB_OK; }
+        int download(int s, int f0, int c)
+        {
+            uint8_t* po = (uint8_t*)P.pinOut[s];
+            ORB_HIP_TRY(hipMemcpyAsync(po + statB, P.dCnt[s].p, (size_t)4 * c, hipMemcpyDeviceToHost, P.d2h));
+            if (outPinned) {
+                ORB_HIP_TRY(hipMemcpyAsync(kps + (size_t)cap * f0, P.dKps[s].p, kpSlab * c, hipMemcpyDeviceToHost, P.d2h));
+                ORB_HIP_TRY(hipMemcpyAsync(desc + dsSlab * f0, P.dDesc[s].p, dsSlab * c, hipMemcpyDeviceToHost, P.d2h));
+            } else {
+                ORB_HIP_TRY(hipMemcpyAsync(po + statB + cntB, P.dKps[s].p, kpSlab * c, hipMemcpyDeviceToHost, P.d2h));
+                ORB_HIP_TRY(hipMemcpyAsync(po + statB + cntB + kpSlab * C, P.dDesc[s].p, dsSlab * c, hipMemcpyDeviceToHost, P.d2h));
+            }
+            return ORB_OK;
         }
-        if (k >= 2 && k - 2 < issued) {
-            const int r = retire(k - 2);
-            if (r != ORB_OK && firstErr == ORB_OK) firstErr = r;
+        int mark_downloaded(int s) { ORB_HIP_TRY(hipEventRecord(P.evOut[s], P.d2h)); return ORB_OK; }
+        int wait_downloaded(int s) { ORB_HIP_TRY(hipEventSynchronize(P.evOut[s])); return ORB_OK; }
+        int finish(int s, int f0, int c)
+        {
+            const uint8_t* po = (const uint8_t*)P.pinOut[s];
+            const int keepFrames = h->lastFrames;              // orb_check_status reads the block of `c` frames
+            h->lastFrames = c;
+            h->hStat.assign((const int*)po, (const int*)po + orb_extractor::statInts(c));
+            h->statSerial = chunkSerial[s];
+            int r = orb_check_status(h);
+            h->statSerial = 0;
+            h->lastFrames = keepFrames;
+            std::memcpy(counts + f0, po + statB, (size_t)4 * c);
+            return r;
         }
-    }
-    if (firstErr != ORB_OK) {                                  // leave nothing in flight behind an error
-        (void)hipStreamSynchronize(P.h2d);
-        (void)hipStreamSynchronize(cs);
-        (void)hipStreamSynchronize(P.d2h);
-        return firstErr;
-    }
+        void unpack_frame(int s, int f, int frame) const
+        {
+            const uint8_t* po = (const uint8_t*)P.pinOut[s];
+            const int n = counts[frame];
+            if (n <= 0) return;
+            std::memcpy(kps + (size_t)cap * frame, po + statB + cntB + kpSlab * f, sizeof(orb_keypoint) * (size_t)n);
+            std::memcpy(desc + dsSlab * frame, po + statB + cntB + kpSlab * C + dsSlab * f, (size_t)ORB_DESC_BYTES * n);
+        }
+        void drain()                                           // leave nothing in flight behind an error
+        {
+            (void)hipStreamSynchronize(P.h2d);
+            (void)hipStreamSynchronize(cs);
+            (void)hipStreamSynchronize(P.d2h);
+        }
+    } ops(h, P);
+    ops.imgs = imgs; ops.kps = kps; ops.desc = desc; ops.counts = counts;
+    ops.rows = rows; ops.cols = cols; ops.cap = cap; ops.C = C;
+    ops.rowStride = rowStride; ops.frameStride = frameStride; ops.imgBytes = imgBytes; ops.kpSlab = kpSlab; ops.dsSlab = dsSlab;
+    ops.statB = statB; ops.cntB = cntB; ops.inPinned = inPinned; ops.outPinned = outPinned; ops.cs = h->stream;
+    const int firstErr = orb_pipe_run(ops, nFrames, C, orb_extractor::kPipeSlots);
+    if (firstErr != ORB_OK) return firstErr;
     // the device keeps the last chunk (pyramids included): frames [frameBase, frameBase + lastFrames) of this batch
     h->frameBase = (nChunks - 1) * C;
     h->lastFrames = nFrames - h->frameBase;

@@ -17,14 +17,11 @@
 #include <vector>
 
 #include "orb_extractor_internal.h"
+#include "orb_host_threads.h"
 
 extern "C" void orb_shard_range(int total, int world, int rank, int* first, int* count)
 {
-    // contiguous block partition; blocks differ by at most one frame (orbhip/shard.py frame_range is the same rule)
-    if (world <= 0 || rank < 0 || rank >= world || total < 0) { if (first) *first = 0; if (count) *count = 0; return; }
-    const int base = total / world, rem = total % world;
-    if (count) *count = base + (rank < rem ? 1 : 0);
-    if (first) *first = rank * base + std::min(rank, rem);
+    orb_shard_range_impl(total, world, rank, first, count);   // (csrc/orb_host_threads.h: HIP-free, also run by tools/tsan_host.cpp)
 }
 
 // the few RCCL entry points, resolved at run time (types as in rccl.h: ncclComm_t is an opaque pointer, results and
@@ -152,30 +149,20 @@ extern "C" int orb_multi_extract_batch(orb_multi* m, const uint8_t* imgs, int n_
     if (!m || n_frames < 0 || !counts) return ORB_ERR_INVALID;
     if (n_frames == 0) return ORB_OK;
     const int W = (int)m->ex.size();
-    std::vector<int> rcs(W, ORB_OK);
-    std::vector<std::string> errs(W);
-    std::vector<std::thread> th;
-    for (int r = 0; r < W; r++) {
+    std::vector<int> rcs;
+    std::vector<std::string> errs;
+    // one host thread per device, the error of the first failing rank reported (csrc/orb_host_threads.h)
+    const int bad = orb_fan_out(W, [=](int r) -> int {
         int first = 0, count = 0;
         orb_shard_range(n_frames, W, r, &first, &count);
-        if (count == 0) continue;
-        auto work = [=, &rcs, &errs]() {
-            rcs[r] = orb_extract_batch(m->ex[r], imgs ? imgs + frame_stride * (size_t)first : nullptr, count, rows, cols, row_stride,
-                                       frame_stride, kps ? kps + (size_t)cap * first : nullptr,
-                                       desc ? desc + (size_t)ORB_DESC_BYTES * cap * first : nullptr, cap, counts + first);
-            if (rcs[r] != ORB_OK) errs[r] = orb_last_error();          // the error string is thread-local
-        };
-        try {
-            th.emplace_back(work);
-        } catch (...) {                                                // no thread to be had: this block runs here (no exception leaves the C ABI)
-            work();
-        }
+        if (count == 0) return ORB_OK;
+        return orb_extract_batch(m->ex[r], imgs ? imgs + frame_stride * (size_t)first : nullptr, count, rows, cols, row_stride,
+                                 frame_stride, kps ? kps + (size_t)cap * first : nullptr,
+                                 desc ? desc + (size_t)ORB_DESC_BYTES * cap * first : nullptr, cap, counts + first);
+    }, [] { return std::string(orb_last_error()); }, rcs, errs);
+    if (bad >= 0) {
+        orb_set_error("device %d (rank %d): %s", m->devices[bad], bad, errs[bad].c_str());
+        return rcs[bad];
     }
-    for (std::thread& t : th) t.join();
-    for (int r = 0; r < W; r++)
-        if (rcs[r] != ORB_OK) {
-            orb_set_error("device %d (rank %d): %s", m->devices[r], r, errs[r].c_str());
-            return rcs[r];
-        }
     return ORB_OK;
 }

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "orb_matcher_internal.h"
+#include "orb_host_threads.h"
 
 struct OrbDbShard {
     int device = 0, first = 0, count = 0;      // keyframes [first, first + count) of the database
@@ -102,27 +103,23 @@ extern "C" int orb_multi_db_create(const int* devices, int n_devices, const uint
     if (!db) return ORB_ERR_INTERNAL;
     db->nKf = n_kf; db->cap = cap; db->nNodes = n_nodes;
     db->sh.resize(n_devices);
-    std::vector<int> rcs(n_devices, ORB_OK);
-    std::vector<std::string> errs(n_devices);
-    std::vector<std::thread> th;
     for (int r = 0; r < n_devices; r++) {
         OrbDbShard& s = db->sh[r];
         s.device = devices[r];
         orb_shard_range(n_kf, n_devices, r, &s.first, &s.count);
-        auto work = [=, &s, &rcs, &errs]() {
-            rcs[r] = build_shard(s, desc, kps, valid, counts, node_of, cap, n_nodes);
-            if (rcs[r] != ORB_OK) errs[r] = orb_last_error();
-        };
-        try { th.emplace_back(work); } catch (...) { work(); }
     }
-    for (std::thread& t : th) t.join();
-    for (int r = 0; r < n_devices; r++)
-        if (rcs[r] != ORB_OK) {
-            orb_set_error("device %d (shard %d): %s", devices[r], r, errs[r].c_str());
-            const int rc = rcs[r];
+    std::vector<int> rcs;
+    std::vector<std::string> errs;
+    {
+        const int bad = orb_fan_out(n_devices, [=](int r) -> int { return build_shard(db->sh[r], desc, kps, valid, counts, node_of, cap, n_nodes); },
+                                    [] { return std::string(orb_last_error()); }, rcs, errs);
+        if (bad >= 0) {
+            orb_set_error("device %d (shard %d): %s", devices[bad], bad, errs[bad].c_str());
+            const int rc = rcs[bad];
             orb_multi_db_destroy(db);
             return rc;
         }
+    }
     *out = db;
     return ORB_OK;
 }
@@ -165,21 +162,14 @@ extern "C" int orb_multi_match_bow_batch(orb_multi_db* db, const uint8_t* q_desc
     if (!db || q_count < 0 || q_count > db->cap || !match || !nmatches) return ORB_ERR_INVALID;
     if (q_count > 0 && (!q_desc || !q_kps || !q_node_of)) return ORB_ERR_INVALID;
     const int W = (int)db->sh.size();
-    std::vector<int> rcs(W, ORB_OK);
-    std::vector<std::string> errs(W);
-    std::vector<std::thread> th;
-    for (int r = 0; r < W; r++) {
-        auto work = [=, &rcs, &errs]() {
-            rcs[r] = query_shard(db->sh[r], db->cap, db->nNodes, q_desc, q_kps, q_count, q_node_of, ratio, check_ori, match, nmatches);
-            if (rcs[r] != ORB_OK) errs[r] = orb_last_error();
-        };
-        try { th.emplace_back(work); } catch (...) { work(); }
+    std::vector<int> rcs;
+    std::vector<std::string> errs;
+    const int bad = orb_fan_out(W, [=](int r) -> int {
+        return query_shard(db->sh[r], db->cap, db->nNodes, q_desc, q_kps, q_count, q_node_of, ratio, check_ori, match, nmatches);
+    }, [] { return std::string(orb_last_error()); }, rcs, errs);
+    if (bad >= 0) {
+        orb_set_error("device %d (shard %d): %s", db->sh[bad].device, bad, errs[bad].c_str());
+        return rcs[bad];
     }
-    for (std::thread& t : th) t.join();
-    for (int r = 0; r < W; r++)
-        if (rcs[r] != ORB_OK) {
-            orb_set_error("device %d (shard %d): %s", db->sh[r].device, r, errs[r].c_str());
-            return rcs[r];
-        }
     return ORB_OK;
 }

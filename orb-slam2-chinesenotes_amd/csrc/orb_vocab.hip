@@ -143,17 +143,30 @@ __global__ __launch_bounds__(256) void k_vocab_transform_k16(const uint4* __rest
         if (!any) break;
         uint4 nl[NF], nh[NF];
         int2 mine[NF];
+        // all loads of this level, back to back.  The LDS copy of the top levels is taken only when EVERY lane of the wave is
+        // inside it (a wave-uniform branch: in a balanced tree all features are on the same level), otherwise every lane reads
+        // global memory -- a per-lane `if (slot < nTop) LDS else global` put loads on both sides of a divergent branch, and the
+        // compiler then waited for the loads of one feature before it requested those of the next (round 5, tools/isa_waits.py)
+        int s2[NF];
+        bool top = true;
 #pragma unroll
-        for (int j = 0; j < NF; j++) {                            // all loads of this level
-            const int s2 = kids[j].x + min(r, max(kids[j].y - 1, 0));
-            if (s2 < nTop) {
-                nl[j] = vsm[2 * s2];
-                nh[j] = vsm[2 * s2 + 1];
-                mine[j] = kidsL[s2];
-            } else {
-                nl[j] = slotDesc[(size_t)s2 * 2];
-                nh[j] = slotDesc[(size_t)s2 * 2 + 1];
-                mine[j] = slotKids[s2];
+        for (int j = 0; j < NF; j++) {
+            s2[j] = kids[j].x + min(r, max(kids[j].y - 1, 0));
+            top = top && s2[j] < nTop;
+        }
+        if (__all(top)) {
+#pragma unroll
+            for (int j = 0; j < NF; j++) {
+                nl[j] = vsm[2 * s2[j]];
+                nh[j] = vsm[2 * s2[j] + 1];
+                mine[j] = kidsL[s2[j]];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NF; j++) {
+                nl[j] = slotDesc[(size_t)s2[j] * 2];
+                nh[j] = slotDesc[(size_t)s2[j] * 2 + 1];
+                mine[j] = slotKids[s2[j]];
             }
         }
 #pragma unroll
