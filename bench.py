@@ -141,6 +141,23 @@ def profile_path(name):
     return cands[-1] if cands else os.path.join(ROOT, "profiles", name)
 
 
+_PAD_STREAMS = []
+
+
+def hip_pad_streams(n):
+    """Experiment knob (ORB_BENCH_STREAM_PADS): n idle HIP streams created -- and kept -- at this point.  HIP spreads streams over
+    4 hardware queues by load; streams that share a queue serialise, so WHICH of a configuration's streams share one decides
+    how its kernels overlap.  Idle pads shift where the streams created after them land."""
+    if n <= 0:
+        return
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    for _ in range(n):
+        st = C.c_void_p()
+        if hip.hipStreamCreateWithFlags(C.byref(st), 1) == 0:
+            _PAD_STREAMS.append(st)
+
+
 def load_c5_loop():
     """tools/libc5loop.so (tools/c5_loop.c: the frame loop of config 5 from C), built on demand; None when it cannot be built."""
     import ctypes as C
@@ -857,6 +874,8 @@ def run_c5(args, rank, local_rank, world, dev, comm_dev, dist):
 
     # the extraction of one frame is a chain of six latency-bound launches (~92 us for a handful of workgroups each): frame
     # i + 1 goes through a second extractor handle (its own stream and scratch) while frame i is still in its chain
+    pads = [int(v) for v in os.environ.get("ORB_BENCH_STREAM_PADS", "0,0").split(",")]     # experiment: see hip_pad_streams
+    hip_pad_streams(pads[0])
     exs = [ex] + [capi.Extractor(args.nfeatures, device=local_rank) for _ in range(max(1, args.c5_extractors) - 1)]
     NEX = len(exs)
 
@@ -884,6 +903,7 @@ def run_c5(args, rank, local_rank, world, dev, comm_dev, dist):
             compute_bow(mbs[i % NEX], f0, q)
 
     # likewise the matcher side: descent (7 us) + feature vector (6 us) of frame i + 1 run beside frame i's 1000 matchings
+    hip_pad_streams(pads[1])
     mts = [mt] + [capi.Matcher(0.7, True, device=local_rank) for _ in range(max(1, args.c5_matchers) - 1)]
     NMT = len(mts)
 

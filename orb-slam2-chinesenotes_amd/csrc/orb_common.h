@@ -36,6 +36,12 @@ static inline hipError_t orb_fill_blocking(void* dst, int v, size_t n, hipStream
     return e != hipSuccess ? e : hipStreamSynchronize(st);
 }
 
+// The handles' streams (csrc/orb_streams.hip): created on the hardware queue that the fewest library streams of the same role
+// use (0 extractor, 1 matcher, 2 copy / side, 3 other) -- HIP spreads streams over 4 hardware queues by a policy of its own, and
+// streams on one queue serialise; which of a pipeline's streams share a queue decides how it overlaps (round 5).
+hipError_t orb_stream_create(hipStream_t* out, int device, int role);
+void orb_stream_destroy(hipStream_t s, int device);
+
 // ---- geometry of one pyramid level, shared by host set-up code and all kernels ----
 struct OrbLevelGeom {
     int w, h, pitch;            // image size and row pitch (bytes, multiple of 64)

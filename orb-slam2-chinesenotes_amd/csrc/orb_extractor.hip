@@ -198,16 +198,12 @@ extern "C" int orb_extractor_create(const orb_extractor_params* p, int device_id
         if (const char* e = std::getenv("ORB_FAST_STRIP")) { k = std::max(1, std::min(8, std::atoi(e))); h->fastStripFixed = true; }
         for (int l = 0; l < ORB_MAX_LEVELS; l++) h->fastStripK[l] = k ? k : ((l < h->prm.nlevels && h->scale[l] >= 2.4f) ? 2 : 3);
     }
-    hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    hipError_t e = orb_stream_create(&h->stream, device_id, 0);
     if (e != hipSuccess) { delete h; orb_set_error("hipStreamCreate: %s", hipGetErrorString(e)); return ORB_ERR_HIP; }
     for (int k = 0; k < orb_extractor::kProfSlots; k++)
         for (int i = 0; i < 5; i++) (void)hipEventCreate(&h->ev[k][i]);
     (void)hipEventCreateWithFlags(&h->waitEv, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&h->ovfEv, hipEventDisableTiming);
-    if (hipStreamCreateWithFlags(&h->sideStream, hipStreamNonBlocking) != hipSuccess) h->sideStream = nullptr;
-    (void)hipEventCreateWithFlags(&h->sideFork, hipEventDisableTiming);
-    (void)hipEventCreateWithFlags(&h->sideJoin, hipEventDisableTiming);
-    (void)hipGetLastError();
     if (hipHostMalloc((void**)&h->ovfHost, orb_extractor::kOvfInts * 4, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); h->ovfHost = nullptr; }
     int rc = h->dPattern.ensure(1024);
     if (rc == ORB_OK) {
@@ -259,14 +255,14 @@ extern "C" void orb_extractor_destroy(orb_extractor* h)
     if (h->ovfEv) (void)hipEventDestroy(h->ovfEv);
     if (h->sideFork) (void)hipEventDestroy(h->sideFork);
     if (h->sideJoin) (void)hipEventDestroy(h->sideJoin);
-    if (h->sideStream) (void)hipStreamDestroy(h->sideStream);
+    if (h->sideStream) orb_stream_destroy(h->sideStream, h->device);
     if (h->ovfHost) (void)hipHostFree(h->ovfHost);
     orb_pipe_release(h);
     if (h->graph1.exec) (void)hipGraphExecDestroy(h->graph1.exec);
     if (h->graph1.graph) (void)hipGraphDestroy(h->graph1.graph);
     if (h->hStage) (void)hipHostFree(h->hStage);
-    if (h->stream) (void)hipStreamDestroy(h->stream);
-    for (hipStream_t st : h->retiredStreams) (void)hipStreamDestroy(st);
+    if (h->stream) orb_stream_destroy(h->stream, h->device);
+    for (hipStream_t st : h->retiredStreams) orb_stream_destroy(st, h->device);
     delete h;
 }
 
@@ -541,7 +537,17 @@ extern "C" int orb_extract_batch_device(orb_extractor* h, const uint8_t* d_imgs,
     // and barriers leave) -- measured slower than one after the other (0.412 against 0.396 ms per 512 frames: the level kernel's
     // workgroups hold half a CU's LDS each and keep the other kernel's waves OUT), so it is off.
     const char* sideEnv = std::getenv("ORB_DESC_LEVEL_SIDE");
-    const bool side = useLevel && h->sideStream && h->sideFork && h->sideJoin && n >= 24 && sideEnv && std::atoi(sideEnv) != 0;
+    const bool wantSide = useLevel && n >= 24 && sideEnv && std::atoi(sideEnv) != 0;
+    if (wantSide && !h->sideStream) {
+        // created on first use only: HIP deals streams round-robin over a few hardware queues, and a stream that exists but is
+        // never used still shifts which queues the OTHER handles' streams land on (two lanes of a 64-frame batch overlapped
+        // worse with an idle side stream per handle: 251 k against 328 k frames/s)
+        if (orb_stream_create(&h->sideStream, h->device, 2) != hipSuccess) h->sideStream = nullptr;
+        (void)hipEventCreateWithFlags(&h->sideFork, hipEventDisableTiming);
+        (void)hipEventCreateWithFlags(&h->sideJoin, hipEventDisableTiming);
+        (void)hipGetLastError();
+    }
+    const bool side = wantSide && h->sideStream && h->sideFork && h->sideJoin;
     hipStream_t lst = st;
     if (side) {
         ORB_HIP_TRY(hipEventRecord(h->sideFork, st));

@@ -31,8 +31,8 @@ static int pipe_init(orb_extractor* h)
 {
     orb_extractor::Pipe& P = h->pipe;
     if (P.ready) return ORB_OK;
-    ORB_HIP_TRY(hipStreamCreateWithFlags(&P.h2d, hipStreamNonBlocking));
-    ORB_HIP_TRY(hipStreamCreateWithFlags(&P.d2h, hipStreamNonBlocking));
+    ORB_HIP_TRY(orb_stream_create(&P.h2d, h->device, 2));
+    ORB_HIP_TRY(orb_stream_create(&P.d2h, h->device, 2));
     for (int s = 0; s < orb_extractor::kPipeSlots; s++) {
         ORB_HIP_TRY(hipEventCreateWithFlags(&P.evIn[s], hipEventDisableTiming));
         ORB_HIP_TRY(hipEventCreateWithFlags(&P.evK[s], hipEventDisableTiming));
@@ -55,8 +55,8 @@ void orb_pipe_release(orb_extractor* h)
         if (P.evOut[s]) (void)hipEventDestroy(P.evOut[s]);
         P.evIn[s] = P.evK[s] = P.evOut[s] = nullptr;
     }
-    if (P.h2d) (void)hipStreamDestroy(P.h2d);
-    if (P.d2h) (void)hipStreamDestroy(P.d2h);
+    if (P.h2d) orb_stream_destroy(P.h2d, h->device);
+    if (P.d2h) orb_stream_destroy(P.d2h, h->device);
     P.h2d = P.d2h = nullptr;
     P.pinInBytes = P.pinOutBytes = 0;
     P.ready = false;

@@ -646,7 +646,7 @@ extern "C" int orb_matcher_create(int device_id, orb_matcher** out)
         }
         (void)hipGetLastError();
     }
-    hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
+    hipError_t e = orb_stream_create(&m->stream, device_id, 1);
     if (e != hipSuccess) { delete m; orb_set_error("hipStreamCreate: %s", hipGetErrorString(e)); return ORB_ERR_HIP; }
     (void)hipEventCreateWithFlags(&m->waitEv, hipEventDisableTiming);
     *out = m;
@@ -671,7 +671,7 @@ extern "C" void orb_matcher_destroy(orb_matcher* m)
     for (auto& b : m->stage) b.release();
     for (auto& b : m->init) b.release();
     if (m->waitEv) (void)hipEventDestroy(m->waitEv);
-    if (m->stream) (void)hipStreamDestroy(m->stream);
+    if (m->stream) orb_stream_destroy(m->stream, m->device);
     delete m;
 }
 
