@@ -12,7 +12,7 @@ import csv, glob, sys, collections
 rows = []
 for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
     rows += list(csv.DictReader(open(f)))
-rows = [r for r in rows if r["Kernel_Name"].replace("void ", "").startswith("k_")]
+rows = [r for r in rows if r["Kernel_Name"].replace("void ", "").startswith("k_") and not r["Kernel_Name"].replace("void ", "").startswith("k_stream_")]   # (k_stream_*: the queue probes of handle creation, csrc/orb_streams.hip)
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # first size only (640x480): calls = groups starting at k_copy_level0
 calls, cur = [], []
