@@ -429,6 +429,11 @@ int orb_extractor_set_desc_stamps(orb_extractor* h, unsigned long long* d_stamps
  * stored, 2 staged (barrier), 3 + k level k of the chain written (barrier).  orb_extractor_pyr_stamp_layout tells how many
  * launches the last batch had and their bands per frame / levels per launch.  tools/pyr_stamps.py prints the table. */
 int orb_extractor_set_pyr_stamps(orb_extractor* h, unsigned long long* d_stamps, size_t capacity);
+/* The same for the quadtree kernel (one workgroup per (frame, level): workgroup = level * frames + frame): 0 start, 1 keys sorted,
+ * 2 full passes done, 3 careful phase done, 4 keypoints emitted, word 5 = candidates | careful iterations << 16 | expandable nodes at
+ * the first careful iteration << 32 | list size there << 48.  The caller sizes d_stamps for 8 * frames * levels words of the batches
+ * it runs while the stamps are on; process-wide (one diagnostic user at a time).  tools/qt_stamps.py prints the table. */
+int orb_extractor_set_qt_stamps(orb_extractor* h, unsigned long long* d_stamps, size_t capacity);
 int orb_extractor_pyr_stamp_layout(const orb_extractor* h, int32_t* n_chains, int32_t* bands8, int32_t* steps8);
 
 /* The whole pyramid of device-resident frame `frame` of the last batch with ONE device-to-host copy and one

@@ -58,7 +58,7 @@ static int build_geometry(orb_extractor* h, int rows, int cols)
     int sortCap = (rows == h->lastGeomRows && cols == h->lastGeomCols) ? std::max(h->sortCap, 1024) : 1024;
     // per-workgroup LDS budget: 60 KB (several workgroups per CU) unless the node arrays alone need more
     const size_t qtBudget = orb_quadtree_lds_bytes(256, nodeCap) > 60 * 1024 ? (size_t)ORB_QT_LDS_MAX : (size_t)60 * 1024;
-    while (sortCap > 256 && orb_quadtree_lds_bytes(sortCap, nodeCap) > qtBudget) sortCap >>= 1;
+    while (sortCap > 256 && orb_quadtree_lds_bytes(sortCap, nodeCap) > qtBudget) sortCap -= 256;
     // quotas whose node lists do not fit one workgroup's LDS (nFeatures >~ 12 000): the lists go to a global scratch slab
     // (k_quadtree_gnodes: same results, every step a round trip to L2)
     const bool qtGlobal = orb_quadtree_lds_bytes(sortCap, nodeCap) > ORB_QT_LDS_MAX;
@@ -404,10 +404,12 @@ extern "C" void* orb_extractor_stream(orb_extractor* h) { return h ? (void*)h->s
 static void grow_sort_cap(orb_extractor* h, int maxCandidates)
 {
     if (h->qtGlobal) return;                           // (the keys alone: 4096 of them in LDS, fixed)
-    int want = 1024;
-    while (want < maxCandidates && want < 4096) want <<= 1;
+    // the largest count seen + 1/8, in steps of 256 keys (2 KB) -- NOT the next power of two: the sorts take any n, and a level-0
+    // count of 1086 (drawn content) / 2115 (natural statistics) used to claim 2048 / 4096 key slots, i.e. 31 / 47 KB of LDS per
+    // workgroup = 5 / 3 workgroups of this latency-bound kernel per CU where 23 / 34 KB (6 / 4) do (round 5, tools/qt_stamps.py)
+    int want = std::max(1024, std::min(4096, (maxCandidates + maxCandidates / 8 + 255) & ~255));
     const size_t budget = orb_quadtree_lds_bytes(256, h->nodeCap) > 60 * 1024 ? (size_t)ORB_QT_LDS_MAX : (size_t)60 * 1024;
-    while (want > 256 && orb_quadtree_lds_bytes(want, h->nodeCap) > budget) want >>= 1;
+    while (want > 256 && orb_quadtree_lds_bytes(want, h->nodeCap) > budget) want -= 256;
     if (want > h->sortCap) h->sortCap = want;
 }
 
@@ -916,6 +918,16 @@ extern "C" int orb_extractor_set_desc_stamps(orb_extractor* h, unsigned long lon
     if (!h) return ORB_ERR_INVALID;
     h->descStamps = d_stamps;
     h->descStampCap = d_stamps ? capacity : 0;
+    return ORB_OK;
+}
+
+extern "C" int orb_extractor_set_qt_stamps(orb_extractor* h, unsigned long long* d_stamps, size_t capacity)
+{
+    if (!h) return ORB_ERR_INVALID;
+    ORB_HIP_TRY(hipSetDevice(h->device));
+    // 8 words per workgroup of a batch (frames x levels); the pointer is process-wide (one diagnostic user at a time)
+    if (d_stamps && capacity < (size_t)8 * ORB_MAX_LEVELS) return ORB_ERR_INVALID;
+    if (orb_quadtree_set_stamps(d_stamps, h->stream) != 0) return ORB_ERR_HIP;
     return ORB_OK;
 }
 

@@ -24,6 +24,7 @@ void orb_launch_quadtree(hipStream_t st, const OrbGeom& G, unsigned long long* c
                          const int* candCount, uint32_t* kpl, int* kpCount, int* errFlags, int sortCap,
                          int nodeCap, int nFrames, int* ovfBlock, unsigned char* globalScratch);
 size_t orb_quadtree_scratch_stride(int nodeCap);
+int orb_quadtree_set_stamps(unsigned long long* d_stamps, hipStream_t st);
 void orb_launch_orient_desc(hipStream_t st, const OrbGeom& G, const uint8_t* pyr, size_t pyrSlab,
                             const uint32_t* kpl, const int* kpCount, const float* patternF, const uint4* angTab, const uint32_t* hbTab,
                             orb_keypoint* kps, uint8_t* desc, int cap, int32_t* counts, int* errFlags,

@@ -74,6 +74,13 @@ __global__ __launch_bounds__(256) void k_quadtree_gnodes(const OrbGeom G, unsign
     }
 }
 
+// diagnostics: where the stage stamps of k_quadtree go (nullptr: none); see QT_STAMP in orb_quadtree_device.h
+int orb_quadtree_set_stamps(unsigned long long* d_stamps, hipStream_t st)
+{
+    if (hipMemcpyToSymbolAsync(HIP_SYMBOL(g_qtStamps), &d_stamps, sizeof(d_stamps), 0, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+    return hipStreamSynchronize(st) == hipSuccess ? 0 : -1;
+}
+
 size_t orb_quadtree_scratch_stride(int nodeCap) { return ((size_t)nodeCap * (16 + 2 * sizeof(QtNode) + sizeof(int3) + 8) + 15) & ~(size_t)15; }
 
 size_t orb_quadtree_lds_bytes(int sortCap, int nodeCap)

@@ -5,6 +5,13 @@
 #include "orb_kernels.h"
 #include "orb_wave.h"
 
+// diagnostics (orb_extractor_set_qt_stamps): thread 0 of a workgroup leaves the 100 MHz clock at the stage boundaries of its
+// (frame, level) instance: 0 start, 1 keys sorted, 2 full passes done (closed form or roots), 3 careful phase done, 4 keypoints
+// emitted; word 5 = candidates | careful iterations << 16 | expandable nodes at the first careful iteration << 32 | list size
+// there << 48.  8 words per workgroup, workgroup = level * frames + frame.
+__device__ unsigned long long* g_qtStamps = nullptr;
+#define QT_STAMP(k) do { if (qtStamps && threadIdx.x == 0) qtStamps[(k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+
 struct QtNode {
     int lo, hi;      // key range in the sorted candidate array
     int depth;       // number of path digits already consumed
@@ -93,6 +100,80 @@ __device__ __forceinline__ bool qt_bucket_sort(unsigned long long* keys, int n, 
         for (int j = 0; j < c; j++) rank += tmp[s0 + j] < k;
         keys[s0 + rank] = k;
     }
+    __syncthreads();
+    return true;
+}
+
+// The same sort with the keys in REGISTERS (round 5): the candidates come from global memory QT_RK at a time per thread and never
+// need a second LDS copy -- the version above scatters into tmp[] and ranks from tmp[] into keys[], i.e. wants 10 bytes of
+// scratch per key, and a level-0 workgroup of a natural-statistics frame (1900 candidates against ~950 on the drawn content)
+// did not have them: it fell back to the sorting network, 33 us of a 46 us workgroup (tools/qt_stamps.py).  Here a thread keeps
+// its keys in registers from the load to the final store: histogram -> scan -> scatter into keys[] (grouped by bucket) ->
+// barrier -> rank inside the bucket (reads only) -> barrier -> store to the final slot.  Scratch: 8 bytes per bucket + 2 per
+// key.  Returns false -- keys[] then holds the UNSORTED candidates -- when a bucket exceeds QT_BUCKET_MAX or the scratch is too
+// small; the caller sorts with the network.  n <= QT_RK * blockDim.x (QT_RK = 8 keys per thread up to 2048 candidates, 16 up to
+// 4096: natural-statistics frames reach 2100 on level 0).
+template <int QT_RK>
+__device__ __forceinline__ bool qt_bucket_sort_regs(unsigned long long* keys, const unsigned long long* __restrict__ gk, int n, int nIni,
+                                                    unsigned char* scratch, int scratchBytes, int* shFlag)
+{
+    const int T = blockDim.x, tid = threadIdx.x;
+    unsigned long long kv[QT_RK];
+#pragma unroll
+    for (int b = 0; b < QT_RK; b++) kv[b] = gk[min(tid + b * T, n - 1)];          // all loads in flight (unconditional, clamped)
+    const int D = n >= 256 ? 3 : 2;
+    const int nb = nIni << (2 * D);
+    const bool fits = (size_t)n * 2 + (size_t)nb * 8 + 16 <= (size_t)scratchBytes && nb <= 1024;
+    const int shift = ORB_KEY_PATH_SHIFT + 2 * (ORB_KEY_PATH_LEVELS - D);
+    int* cnt = reinterpret_cast<int*>(scratch);
+    int* start = cnt + nb;
+    unsigned short slotv[QT_RK];
+    if (fits) {
+        for (int t = tid; t < nb; t += T) cnt[t] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < QT_RK; b++)
+            if (tid + b * T < n) slotv[b] = (unsigned short)atomicAdd(&cnt[(int)(kv[b] >> shift)], 1);
+        __syncthreads();
+        if (tid < 64) {                                    // exclusive scan over the buckets + the largest bucket
+            const int C = (nb + 63) / 64;
+            const int b0 = min(tid * C, nb), e = min(b0 + C, nb);
+            int sum = 0, mx = 0;
+            for (int t = b0; t < e; t++) { const int c = cnt[t]; sum += c; mx = max(mx, c); }
+            const int incl = orb_wave_scan_incl(sum);
+            int run = incl - sum;
+            for (int t = b0; t < e; t++) { start[t] = run; run += cnt[t]; }
+            mx = (int)~orb_wave_umin(~(unsigned)mx);
+            if (tid == 0) *shFlag = mx;
+        }
+        __syncthreads();
+    }
+    if (!fits || *shFlag > QT_BUCKET_MAX) {                // (uniform) the network sorts them: hand the candidates over as they came
+#pragma unroll
+        for (int b = 0; b < QT_RK; b++)
+            if (tid + b * T < n) keys[tid + b * T] = kv[b];
+        __syncthreads();
+        return false;
+    }
+#pragma unroll
+    for (int b = 0; b < QT_RK; b++)
+        if (tid + b * T < n) keys[start[(int)(kv[b] >> shift)] + slotv[b]] = kv[b];
+    __syncthreads();
+    int rankv[QT_RK];
+#pragma unroll
+    for (int b = 0; b < QT_RK; b++) {
+        rankv[b] = 0;
+        if (tid + b * T < n) {
+            const int bk = (int)(kv[b] >> shift), s0 = start[bk], c = cnt[bk];
+            int r = 0;
+            for (int j = 0; j < c; j++) r += keys[s0 + j] < kv[b];
+            rankv[b] = s0 + r;
+        }
+    }
+    __syncthreads();                                       // every read of the grouped order is done
+#pragma unroll
+    for (int b = 0; b < QT_RK; b++)
+        if (tid + b * T < n) keys[rankv[b]] = kv[b];
     __syncthreads();
     return true;
 }
@@ -274,7 +355,8 @@ __device__ __forceinline__ QtClosed qt_full_passes_closed(const unsigned long lo
 __device__ __forceinline__ void qt_body(unsigned long long* keys, int n, const OrbGeom& G, const OrbLevelGeom& L, int f,
                                         unsigned long long* prevA, unsigned long long* prevB, QtNode* A, QtNode* B,
                                         int3* cuts, int* va, int* vb, int* part, uint32_t* __restrict__ kpl,
-                                        int* outCount, int* __restrict__ errFlags, int* sh, unsigned char* scratch, int scratchBytes, int nodeCap)
+                                        int* outCount, int* __restrict__ errFlags, int* sh, unsigned char* scratch, int scratchBytes, int nodeCap,
+                                        int sorted = 0)     // 0: keys unsorted, 1: sorted already, 2: unsorted and the bucket sort already refused them
 {
     // shared words: sh[0] number of roots, sh[1] / sh[2] the two "expandable children" counters (passes alternate between
     // them: the one a pass does not count into is cleared for the next pass), sh[3] t* of the careful phase.
@@ -283,8 +365,13 @@ __device__ __forceinline__ void qt_body(unsigned long long* keys, int n, const O
     // and none at its start (a pass is a chain of barrier-separated steps; two of seven were only that bookkeeping).
     int& sh_tstar = sh[3];
     const int tid = threadIdx.x, T = blockDim.x;
+    unsigned long long* qtStamps = g_qtStamps ? g_qtStamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 : nullptr;
+    int dbgIters = 0, dbgPc = 0, dbgSize = 0;
+    QT_STAMP(0);
     __syncthreads();
-    if (!(scratch && qt_bucket_sort(keys, n, L.nIni, scratch, scratchBytes, &sh[3]))) orb_block_sort(keys, n);
+    if (sorted == 2) orb_block_sort(keys, n);
+    else if (sorted == 0 && !(scratch && qt_bucket_sort(keys, n, L.nIni, scratch, scratchBytes, &sh[3]))) orb_block_sort(keys, n);
+    QT_STAMP(1);
 
     const int N = L.quota;
     int state = 0;                                     // 0 full passes, 1 careful phase, 2 done
@@ -318,8 +405,10 @@ __device__ __forceinline__ void qt_body(unsigned long long* keys, int n, const O
     __syncthreads();
     size0 = sh[0];
     }
+    QT_STAMP(2);
     while (state != 2) {
         if (state == 1 && pc == 0) break;              // nothing left to expand: size cannot change (:762)
+        if (state == 1) { if (dbgIters == 0) { dbgPc = pc; dbgSize = size0; } dbgIters++; }
         QtNode* cur = inB ? B : A;
         QtNode* nxt = inB ? A : B;
         unsigned long long* prev = prevInB ? prevB : prevA;
@@ -566,6 +655,7 @@ __device__ __forceinline__ void qt_body(unsigned long long* keys, int n, const O
         }
     }
 
+    QT_STAMP(3);
     // ---- keep the best key of every node, in list order (:770-789)
     const QtNode* fin = inB ? B : A;
     const int size = size0;
@@ -590,6 +680,10 @@ __device__ __forceinline__ void qt_body(unsigned long long* keys, int n, const O
         out[i] = ((uint32_t)x << 20) | ((uint32_t)y << 8) | (uint32_t)(bestKey & 0xFF);
     }
     if (tid == 0) *outCount = size;
+    QT_STAMP(4);
+    if (qtStamps && tid == 0)
+        qtStamps[5] = (unsigned long long)(unsigned)n | ((unsigned long long)(dbgIters & 0xFFFF) << 16) | ((unsigned long long)(dbgPc & 0xFFFF) << 32) |
+                      ((unsigned long long)(dbgSize & 0xFFFF) << 48);
 }
 
 // One (frame, level) instance with its keys and lists in the workgroup's LDS at qsm (carve-up below; sh = four shared words):
@@ -620,19 +714,26 @@ __device__ __forceinline__ void qt_instance_lds(unsigned long long* qsm, int* sh
     }
     unsigned long long* gk = cand + (size_t)f * candSlab + L.candBase;
     if (n <= sortCap) {
-        // the candidate keys, eight loads of a thread in flight at once (unconditional, clamped: a plain `for (i ...) lds[i] = gk[i]`
-        // compiles to load -> wait -> store per iteration, i.e. n / 256 memory round trips in a row at the head of the workgroup)
-        for (int i0 = tid; i0 < n; i0 += 8 * T) {
-            unsigned long long kv[8];
-#pragma unroll
-            for (int b = 0; b < 8; b++) kv[b] = gk[min(i0 + b * T, n - 1)];
-#pragma unroll
-            for (int b = 0; b < 8; b++)
-                if (i0 + b * T < n) ldsKeys[i0 + b * T] = kv[b];
-        }
         // scratch of the bucket sort: the node lists behind the keys (prevA .. part), unused until the sort is done
-        qt_body(ldsKeys, n, G, L, f, prevA, prevB, A, B, cuts, va, vb, part, kpl, outCount, errFlags, sh,
-                reinterpret_cast<unsigned char*>(prevA), nodeCap * (16 + 2 * (int)sizeof(QtNode) + (int)sizeof(int3) + 8) + 257 * 4, nodeCap);
+        unsigned char* scr = reinterpret_cast<unsigned char*>(prevA);
+        const int scrBytes = nodeCap * (16 + 2 * (int)sizeof(QtNode) + (int)sizeof(int3) + 8) + 257 * 4;
+        int sorted = 0;
+        if (n <= 16 * T) {
+            // the candidates go from global memory through registers straight to their sorted place (qt_bucket_sort_regs)
+            __syncthreads();
+            if (n <= 8 * T) sorted = qt_bucket_sort_regs<8>(ldsKeys, gk, n, L.nIni, scr, scrBytes, &sh[3]) ? 1 : 2;
+            else sorted = qt_bucket_sort_regs<16>(ldsKeys, gk, n, L.nIni, scr, scrBytes, &sh[3]) ? 1 : 2;
+        } else {
+            for (int i0 = tid; i0 < n; i0 += 8 * T) {
+                unsigned long long kv[8];
+#pragma unroll
+                for (int b = 0; b < 8; b++) kv[b] = gk[min(i0 + b * T, n - 1)];
+#pragma unroll
+                for (int b = 0; b < 8; b++)
+                    if (i0 + b * T < n) ldsKeys[i0 + b * T] = kv[b];
+            }
+        }
+        qt_body(ldsKeys, n, G, L, f, prevA, prevB, A, B, cuts, va, vb, part, kpl, outCount, errFlags, sh, scr, scrBytes, nodeCap, sorted);
     } else {
         // more candidates than the LDS holds: the host grows the sort capacity when it hears of it (word 1 of the overflow
         // block: at a sync, or through the unsynchronised feedback of orb_extract_batch_device)

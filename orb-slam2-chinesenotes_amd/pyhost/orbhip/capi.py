@@ -59,7 +59,7 @@ _lib = None
 # every symbol include/orb_hip.h declares
 SYMBOLS = [
     "orb_extractor_create", "orb_extractor_destroy", "orb_extractor_get_tables", "orb_extractor_max_keypoints",
-    "orb_extractor_set_pattern", "orb_extractor_set_pattern_device", "orb_extractor_desc_plan", "orb_extractor_set_desc_stamps", "orb_extractor_set_pyr_stamps", "orb_extractor_pyr_stamp_layout", "orb_builtin_pattern", "orb_extract",
+    "orb_extractor_set_pattern", "orb_extractor_set_pattern_device", "orb_extractor_desc_plan", "orb_extractor_set_desc_stamps", "orb_extractor_set_pyr_stamps", "orb_extractor_set_qt_stamps", "orb_extractor_pyr_stamp_layout", "orb_builtin_pattern", "orb_extract",
     "orb_extract_batch", "orb_extract_batch_device", "orb_extractor_sync", "orb_get_pyramid_level",
     "orb_get_level_counts", "orb_get_fast_overflows", "orb_get_pyramid", "orb_host_alloc", "orb_host_free", "orb_extractor_set_profiling", "orb_extractor_get_stage_ms", "orb_extractor_profiled_frames", "orb_extractor_stream",
     "orb_hamming", "orb_three_maxima", "orb_matcher_create", "orb_matcher_destroy", "orb_matcher_sync",
@@ -96,6 +96,7 @@ def lib():
     L.orb_extractor_desc_plan.argtypes = [vp, vp, vp]
     L.orb_extractor_set_desc_stamps.argtypes = [vp, vp, sz]
     L.orb_extractor_set_pyr_stamps.argtypes = [vp, vp, sz]
+    L.orb_extractor_set_qt_stamps.argtypes = [vp, vp, sz]
     L.orb_extractor_pyr_stamp_layout.argtypes = [vp, vp, vp, vp]
     L.orb_builtin_pattern.argtypes = [vp]
     L.orb_extract.argtypes = [vp, vp, ci, ci, sz, vp, vp, ci, C.POINTER(ci)]
@@ -317,6 +318,9 @@ class Extractor:
 
     def set_desc_stamps(self, d_ptr, capacity):
         _check(self.L.orb_extractor_set_desc_stamps(self.h, C.c_void_p(d_ptr), capacity))
+
+    def set_qt_stamps(self, d_ptr, capacity):
+        _check(self.L.orb_extractor_set_qt_stamps(self.h, C.c_void_p(d_ptr), capacity))
 
     def set_pyr_stamps(self, d_ptr, capacity):
         _check(self.L.orb_extractor_set_pyr_stamps(self.h, C.c_void_p(d_ptr), capacity))
