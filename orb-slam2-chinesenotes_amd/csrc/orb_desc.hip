@@ -233,10 +233,13 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     // column index through a 24-bit multiply-add: the low 24 bits of the biased column are 0x400000 + ic
     const unsigned eC = (unsigned)((xoff + PR - 4 * qFirst) * HT_RP + (PR - 3)) - 0x400000u * (unsigned)HT_RP - kBias;
     const unsigned K0 = gk.v0, K1 = gk.v1, K2 = gk.v2, K3 = gk.v3;    // taps, two per dot2: k0 | k1 << 16, k2 | k3 << 16, k2 | k1 << 16, k0
-    auto sample = [&](float px, float py) -> int {
-        const float fr = __fadd_rn(__fmul_rn(px, b), __fmul_rn(py, a));
-        const float fc = __fsub_rn(__fmul_rn(px, a), __fmul_rn(py, b));
-        const unsigned br = __float_as_uint(__fadd_rn(fr, 12582912.f)), bc = __float_as_uint(__fadd_rn(fc, 12582912.f));
+    // The two points of a pair are rotated TOGETHER: patF holds a pair as {x0, x1, y0, y1}, so row = x * b + y * a and
+    // col = x * a - y * b of both points are four packed multiplies and two packed adds on aligned register pairs (+ two
+    // for the rounding constant).  With the pair stored {x0, y0, x1, y1} the compiler packed (x, y) of ONE point instead and
+    // then had to move six registers around per pair to add across the halves: 24 of the kernel's ~435 instructions (round 5).
+    typedef float orb_f2 __attribute__((ext_vector_type(2)));
+    const orb_f2 a2 = {a, a}, b2 = {b, b}, magic2 = {12582912.f, 12582912.f};
+    auto blurred = [&](unsigned br, unsigned bc) -> int {
         // u16 index of the topmost tap: H[xoff + 21 + ic - 4 qFirst][21 + ir - 3]; its 7 rows lie in 4 consecutive dwords,
         // starting in the low (even index) or the high half of the first
         const unsigned e = __umul24(bc, (unsigned)HT_RP) + br + eC;
@@ -251,10 +254,20 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
         acc = __builtin_amdgcn_udot2(__builtin_bit_cast(orb_u16x2, p0), __builtin_bit_cast(orb_u16x2, K0), acc, false);
         return (int)min(255u, acc >> 16);
     };
-    const unsigned long long w0 = __ballot(sample(q0.x, q0.y) < sample(q0.z, q0.w));
-    const unsigned long long w1 = __ballot(sample(q1.x, q1.y) < sample(q1.z, q1.w));
-    const unsigned long long w2 = __ballot(sample(q2.x, q2.y) < sample(q2.z, q2.w));
-    const unsigned long long w3 = __ballot(sample(q3.x, q3.y) < sample(q3.z, q3.w));
+    // t0 < t1 of a pair (GET_VALUE of both points, :132-134, :141-160)
+    auto pair_bit = [&](const float4& q) -> bool {
+        const orb_f2 X = {q.x, q.y}, Y = {q.z, q.w};
+        const orb_f2 fr = X * b2 + Y * a2;                      // (float)(x * b + y * a): two roundings of the products, one of the sum
+        const orb_f2 fc = X * a2 - Y * b2;
+        const orb_f2 rr = fr + magic2, cc = fc + magic2;        // cvRound: see kBias above
+        const int t0 = blurred(__float_as_uint(rr.x), __float_as_uint(cc.x));
+        const int t1 = blurred(__float_as_uint(rr.y), __float_as_uint(cc.y));
+        return t0 < t1;
+    };
+    const unsigned long long w0 = __ballot(pair_bit(q0));
+    const unsigned long long w1 = __ballot(pair_bit(q1));
+    const unsigned long long w2 = __ballot(pair_bit(q2));
+    const unsigned long long w3 = __ballot(pair_bit(q3));
 
     if (lane < 4) {
         const unsigned long long w = lane == 0 ? w0 : lane == 1 ? w1 : lane == 2 ? w2 : w3;

@@ -310,16 +310,22 @@ void k_desc_level(const OrbGeom G, const OrbDescPlan P, const uint8_t* __restric
             // 1.5 * 2^23: the low 24 bits of the sum are 0x400000 + i), the biases fold into one wave-uniform constant
             const unsigned base = (unsigned)(((y0 - R.ry0 + 3) * pd + 1) * 4 + (x0 - R.rx0));
             const unsigned eC = base - 0x400000u * P4 - kBias;
-            auto sample = [&](float px, float py) -> int {
-                const float fr = __fadd_rn(__fmul_rn(px, b), __fmul_rn(py, a));
-                const float fc = __fsub_rn(__fmul_rn(px, a), __fmul_rn(py, b));
-                const unsigned br = __float_as_uint(__fadd_rn(fr, 12582912.f)), bc = __float_as_uint(__fadd_rn(fc, 12582912.f));
-                return (int)imgB[__umul24(br, P4) + bc + eC];
+            // (a pair's two points rotated together: patF = {x0, x1, y0, y1}, see orb_desc.hip)
+            typedef float dl_f2 __attribute__((ext_vector_type(2)));
+            const dl_f2 a2 = {a, a}, b2 = {b, b}, magic2 = {12582912.f, 12582912.f};
+            auto pair_bit = [&](const float4& q) -> bool {
+                const dl_f2 X = {q.x, q.y}, Y = {q.z, q.w};
+                const dl_f2 fr = X * b2 + Y * a2;
+                const dl_f2 fc = X * a2 - Y * b2;
+                const dl_f2 rr = fr + magic2, cc = fc + magic2;
+                const int t0 = (int)imgB[__umul24(__float_as_uint(rr.x), P4) + __float_as_uint(cc.x) + eC];
+                const int t1 = (int)imgB[__umul24(__float_as_uint(rr.y), P4) + __float_as_uint(cc.y) + eC];
+                return t0 < t1;
             };
-            const unsigned long long w0 = __ballot(sample(q0.x, q0.y) < sample(q0.z, q0.w));
-            const unsigned long long w1 = __ballot(sample(q1.x, q1.y) < sample(q1.z, q1.w));
-            const unsigned long long w2 = __ballot(sample(q2.x, q2.y) < sample(q2.z, q2.w));
-            const unsigned long long w3 = __ballot(sample(q3.x, q3.y) < sample(q3.z, q3.w));
+            const unsigned long long w0 = __ballot(pair_bit(q0));
+            const unsigned long long w1 = __ballot(pair_bit(q1));
+            const unsigned long long w2 = __ballot(pair_bit(q2));
+            const unsigned long long w3 = __ballot(pair_bit(q3));
             if (lane < 4) {
                 const unsigned long long w = lane == 0 ? w0 : lane == 1 ? w1 : lane == 2 ? w2 : w3;
                 reinterpret_cast<unsigned long long*>(descOut + ((size_t)f * cap + off + kpK[j]) * ORB_DESC_BYTES)[lane] = w;

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void k_copy_level0(const uint8_t* __restrict__
         // batch, so whoever wrote the int8 pattern (orb_extractor_set_pattern*, an RCCL broadcast) needs no hook
         if (g < 256u) {
             const char4 q = pat8[g];
-            patF[g] = make_float4((float)q.x, (float)q.y, (float)q.z, (float)q.w);
+            patF[g] = make_float4((float)q.x, (float)q.z, (float)q.y, (float)q.w);   // {x0, x1, y0, y1}: the two points of a pair side by side per axis (orb_desc.hip)
         }
     }
     // flattened (row, 16-byte column) index: every lane of every wave has work (a 640-px row is only 40 columns)
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256) void k_pyr_chain(const OrbPyrChain C, const ui
         if (g < (unsigned)clrInts) clr[g] = 0;
         if (g < 256u) {
             const char4 q = pat8[g];
-            patF[g] = make_float4((float)q.x, (float)q.y, (float)q.z, (float)q.w);
+            patF[g] = make_float4((float)q.x, (float)q.z, (float)q.y, (float)q.w);   // {x0, x1, y0, y1}: the two points of a pair side by side per axis (orb_desc.hip)
         }
     }
     // XL: the column tables of the chain's levels go to LDS (requested first: their addresses depend on nothing)
