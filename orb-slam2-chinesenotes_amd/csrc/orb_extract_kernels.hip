@@ -507,15 +507,16 @@ __global__ __launch_bounds__(256) void k_pyr_chain(const OrbPyrChain C, const ui
                 h[0] = resize_h(wa, q0.z, q1.z); h[1] = resize_h(wa, q0.w, q1.w);
                 h[2] = resize_h(wb, q1.x, q2.x); h[3] = resize_h(wb, q1.y, q2.y);
             };
-            unsigned hA[4], hB[4];
+            // two register sets that the rows alternate between: row r's upper source row lives in hh[r & 1], its lower one in
+            // hh[(r + 1) & 1] -- which IS the upper set of row r + 1, so a reused horizontal pass stays where it is (it used to be
+            // copied, four register moves per reuse, three reuses in four rows)
+            unsigned hh[2][4];
 #pragma unroll
             for (int r = 0; r < RG; r++) {
                 const unsigned lr = g * RG + r;
+                unsigned (&hA)[4] = hh[r & 1];
+                unsigned (&hB)[4] = hh[(r + 1) & 1];
                 if (r == 0 || e[r].x != e[r - 1].y) hrow(e[r].x, hA);
-                else {
-#pragma unroll
-                    for (int j = 0; j < 4; j++) hA[j] = hB[j];
-                }
                 hrow(e[r].y, hB);
                 unsigned out = 0;
 #pragma unroll
