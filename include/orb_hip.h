@@ -435,6 +435,9 @@ int orb_extractor_set_pyr_stamps(orb_extractor* h, unsigned long long* d_stamps,
  * it runs while the stamps are on; process-wide (one diagnostic user at a time).  tools/qt_stamps.py prints the table. */
 int orb_extractor_set_qt_stamps(orb_extractor* h, unsigned long long* d_stamps, size_t capacity);
 int orb_extractor_pyr_stamp_layout(const orb_extractor* h, int32_t* n_chains, int32_t* bands8, int32_t* steps8);
+/* How many pyramid launches of the last batch took the persistent, prefetching form (k_pyr_chain_p: batches that fill the chip
+ * several times over, and only with ORB_PYR_PERSIST=1: measured neutral, off by default).  In that form a stamp record belongs to a (frame, band) unit, same index. */
+int orb_extractor_pyr_persistent(const orb_extractor* h, int32_t* launches);
 
 /* The whole pyramid of device-resident frame `frame` of the last batch with ONE device-to-host copy and one
  * synchronisation (the reference keeps it in the public member mvImagePyramid, include/ORBextractor.h:86, read by

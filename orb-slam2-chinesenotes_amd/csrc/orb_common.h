@@ -85,6 +85,7 @@ struct OrbPyrChain {
     int srcOff, srcPitch, srcW, srcH;   // source level inside the slab (copy0: where level 0 goes)
     int srcLdsOff, srcLdsPitchDw;
     int cpr;                    // 16-byte chunks per source row
+    int srcRowsMax;             // source rows of the largest band (k_pyr_chain_p: chunks per thread)
     unsigned invCpr;            // ceil(2^32 / cpr), 0 when cpr == 1
     int bands, tabOff;          // workgroups per frame; offset (int2 units) of the band table [band][nSteps + 2]:
                                 //   [0] source rows (first, last), [1 + k] rows of step k, [nSteps + 1] level-0 rows to copy

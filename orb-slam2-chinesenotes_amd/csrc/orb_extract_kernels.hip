@@ -9,6 +9,9 @@
 //   (k_orient_desc lives in orb_desc.hip)
 // Every kernel takes blockIdx.y (or .z) = frame: batched frames are independent.
 #include <cstdlib>
+#include <map>
+#include <mutex>
+#include <tuple>
 
 #include "orb_kernels.h"
 
@@ -303,6 +306,90 @@ typedef unsigned int orb_u32x4 __attribute__((ext_vector_type(4)));
 typedef orb_u32x4 __attribute__((aligned(1))) orb_u32x4_a1;
 #define PYR_STAGE_MAX 8            // 16-byte chunks a thread has in flight while staging
 
+// One level of a chain out of LDS: one item = 4 pixels x RG rows (RG = 4 amortises the column entry best, RG = 1 / 2 leave
+// fewer threads idle in the last pass over a band: the host picks per chain).  hook() runs once, behind the request for the
+// first item's column entry (k_pyr_chain_p puts the NEXT band's source loads there: younger than that request, so the wait
+// for it does not wait for them).
+template <int RG, bool XL, class Hook>
+__device__ __forceinline__ void pyr_chain_step(const OrbPyrChain& C, int k, const int2* bt, uint8_t* slab, uint8_t* lds,
+                                               const uint4* __restrict__ xqAll, int tid, Hook&& hook)
+{
+    const OrbPyrStep& T = C.st[k];
+    const int2 mr = bt[1 + k];
+    const int nM = mr.y - mr.x + 1, gM = (nM + RG - 1) / RG;
+    const uint4* xq = xqAll + T.xqOff;
+    uint8_t* dst = slab + T.dstOff + (size_t)mr.x * T.dstPitch;
+    const bool keep = k + 1 < C.nSteps;
+    const uint8_t* rp = lds + T.rpOff;
+    uint8_t* keepL = lds + T.ldsOff;
+    const unsigned x4n = (unsigned)T.x4, inv = T.invX4, dpitch = (unsigned)T.dstPitch, kpitch = 4u * (unsigned)T.ldsPitchDw;
+    // the column entry of the NEXT item is requested before the current one is computed (an L2 round trip per item
+    // otherwise: the entry's selectors are needed by the item's first instructions)
+    const unsigned nItems = (unsigned)gM * x4n;
+    uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0;
+    uint2 q2 = make_uint2(0, 0);
+    unsigned g = 0, x4 = 0;
+    const uint8_t* xl = lds + C.xqLdsOff + 16 * (T.xqOff - C.st[0].xqOff);
+    if (!XL && (unsigned)tid < nItems) {
+        g = inv ? __umulhi((unsigned)tid, inv) : (unsigned)tid;
+        x4 = (unsigned)tid - g * x4n;
+        q0 = xq[3 * x4]; q1 = xq[3 * x4 + 1];
+        q2 = *reinterpret_cast<const uint2*>(xq + 3 * x4 + 2);
+    }
+    hook();
+    for (unsigned idx = tid; idx < nItems; idx += 256) {
+        const unsigned idxN = idx + 256;
+        uint4 n0 = q0, n1 = q1;
+        uint2 n2 = q2;
+        unsigned gN = g, x4N = x4;
+        if constexpr (XL) {
+            g = inv ? __umulhi(idx, inv) : idx;
+            x4 = idx - g * x4n;
+            q0 = *reinterpret_cast<const uint4*>(xl + 48 * x4);
+            q1 = *reinterpret_cast<const uint4*>(xl + 48 * x4 + 16);
+            q2 = *reinterpret_cast<const uint2*>(xl + 48 * x4 + 32);
+        } else if (idxN < nItems) {
+            gN = inv ? __umulhi(idxN, inv) : idxN;
+            x4N = idxN - gN * x4n;
+            n0 = xq[3 * x4N]; n1 = xq[3 * x4N + 1];
+            n2 = *reinterpret_cast<const uint2*>(xq + 3 * x4N + 2);
+        }
+        uint4 e[RG];
+#pragma unroll
+        for (int r = 0; r < RG; r++) e[r] = *reinterpret_cast<const uint4*>(rp + 16 * (g * RG + r));
+        // horizontal pass of a source row for the item's 4 pixels: (S[sx] a0 + S[sx + 1] a1) >> 4, the form the vertical
+        // pass consumes.  At scale 1.2 the lower source row of an output row is the upper source row of the next output row
+        // four times in five: its horizontal pass (2 LDS reads, 4 x (v_perm, v_dot2, shift)) is then reused, not redone.
+        auto hrow = [&](unsigned rowOff, unsigned (&h)[4]) {
+            const uint32_t* w0 = reinterpret_cast<const uint32_t*>(lds + rowOff + q0.x);
+            const uint32_t* w1 = reinterpret_cast<const uint32_t*>(lds + rowOff + q0.y);
+            const uint2 wa = make_uint2(w0[0], w0[1]), wb = make_uint2(w1[0], w1[1]);
+            h[0] = resize_h(wa, q0.z, q1.z); h[1] = resize_h(wa, q0.w, q1.w);
+            h[2] = resize_h(wb, q1.x, q2.x); h[3] = resize_h(wb, q1.y, q2.y);
+        };
+        // two register sets that the rows alternate between: row r's upper source row lives in hh[r & 1], its lower one in
+        // hh[(r + 1) & 1] -- which IS the upper set of row r + 1, so a reused horizontal pass stays where it is (it used to be
+        // copied, four register moves per reuse, three reuses in four rows)
+        unsigned hh[2][4];
+#pragma unroll
+        for (int r = 0; r < RG; r++) {
+            const unsigned lr = g * RG + r;
+            unsigned (&hA)[4] = hh[r & 1];
+            unsigned (&hB)[4] = hh[(r + 1) & 1];
+            if (r == 0 || e[r].x != e[r - 1].y) hrow(e[r].x, hA);
+            hrow(e[r].y, hB);
+            unsigned out = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) out |= ((__umulhi(hA[j], e[r].z) + __umulhi(hB[j], e[r].w) + 2) >> 2) << (8 * j);
+            if (lr < (unsigned)nM) {
+                *reinterpret_cast<uint32_t*>(dst + (lr * dpitch + x4 * 4)) = out;
+                if (keep) *reinterpret_cast<uint32_t*>(keepL + (lr * kpitch + x4 * 4)) = out;
+            }
+        }
+        if constexpr (!XL) { q0 = n0; q1 = n1; q2 = n2; g = gN; x4 = x4N; }
+    }
+}
+
 template <int RG, bool XL>
 __global__ __launch_bounds__(256) void k_pyr_chain(const OrbPyrChain C, const uint8_t* __restrict__ img, size_t rowStride,
                                                    size_t frameStride, uint8_t* __restrict__ pyr, size_t pyrSlab,
@@ -452,84 +539,163 @@ __global__ __launch_bounds__(256) void k_pyr_chain(const OrbPyrChain C, const ui
     __syncthreads();
     PYR_STAMP(2);
 
-    // ---- level after level out of LDS: one item = 4 pixels x RG rows (RG = 4 amortises the column entry best, RG = 1 / 2 leave
-    // fewer threads idle in the last pass over a band: the host picks per chain)
+    // ---- level after level out of LDS (pyr_chain_step above)
     for (int k = 0; k < C.nSteps; k++) {
-        const OrbPyrStep& T = C.st[k];
-        const int2 mr = bt[1 + k];
-        const int nM = mr.y - mr.x + 1, gM = (nM + RG - 1) / RG;
-        const uint4* xq = xqAll + T.xqOff;
-        uint8_t* dst = slab + T.dstOff + (size_t)mr.x * T.dstPitch;
-        const bool keep = k + 1 < C.nSteps;
-        const uint8_t* rp = lds + T.rpOff;
-        uint8_t* keepL = lds + T.ldsOff;
-        const unsigned x4n = (unsigned)T.x4, inv = T.invX4, dpitch = (unsigned)T.dstPitch, kpitch = 4u * (unsigned)T.ldsPitchDw;
-        // the column entry of the NEXT item is requested before the current one is computed (an L2 round trip per item
-        // otherwise: the entry's selectors are needed by the item's first instructions)
-        const unsigned nItems = (unsigned)gM * x4n;
-        uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0;
-        uint2 q2 = make_uint2(0, 0);
-        unsigned g = 0, x4 = 0;
-        const uint8_t* xl = lds + C.xqLdsOff + 16 * (T.xqOff - C.st[0].xqOff);
-        if (!XL && (unsigned)tid < nItems) {
-            g = inv ? __umulhi((unsigned)tid, inv) : (unsigned)tid;
-            x4 = (unsigned)tid - g * x4n;
-            q0 = xq[3 * x4]; q1 = xq[3 * x4 + 1];
-            q2 = *reinterpret_cast<const uint2*>(xq + 3 * x4 + 2);
-        }
-        for (unsigned idx = tid; idx < nItems; idx += 256) {
-            const unsigned idxN = idx + 256;
-            uint4 n0 = q0, n1 = q1;
-            uint2 n2 = q2;
-            unsigned gN = g, x4N = x4;
-            if constexpr (XL) {
-                g = inv ? __umulhi(idx, inv) : idx;
-                x4 = idx - g * x4n;
-                q0 = *reinterpret_cast<const uint4*>(xl + 48 * x4);
-                q1 = *reinterpret_cast<const uint4*>(xl + 48 * x4 + 16);
-                q2 = *reinterpret_cast<const uint2*>(xl + 48 * x4 + 32);
-            } else if (idxN < nItems) {
-                gN = inv ? __umulhi(idxN, inv) : idxN;
-                x4N = idxN - gN * x4n;
-                n0 = xq[3 * x4N]; n1 = xq[3 * x4N + 1];
-                n2 = *reinterpret_cast<const uint2*>(xq + 3 * x4N + 2);
-            }
-            uint4 e[RG];
-#pragma unroll
-            for (int r = 0; r < RG; r++) e[r] = *reinterpret_cast<const uint4*>(rp + 16 * (g * RG + r));
-            // horizontal pass of a source row for the item's 4 pixels: (S[sx] a0 + S[sx + 1] a1) >> 4, the form the vertical
-            // pass consumes.  At scale 1.2 the lower source row of an output row is the upper source row of the next output row
-            // four times in five: its horizontal pass (2 LDS reads, 4 x (v_perm, v_dot2, shift)) is then reused, not redone.
-            auto hrow = [&](unsigned rowOff, unsigned (&h)[4]) {
-                const uint32_t* w0 = reinterpret_cast<const uint32_t*>(lds + rowOff + q0.x);
-                const uint32_t* w1 = reinterpret_cast<const uint32_t*>(lds + rowOff + q0.y);
-                const uint2 wa = make_uint2(w0[0], w0[1]), wb = make_uint2(w1[0], w1[1]);
-                h[0] = resize_h(wa, q0.z, q1.z); h[1] = resize_h(wa, q0.w, q1.w);
-                h[2] = resize_h(wb, q1.x, q2.x); h[3] = resize_h(wb, q1.y, q2.y);
-            };
-            // two register sets that the rows alternate between: row r's upper source row lives in hh[r & 1], its lower one in
-            // hh[(r + 1) & 1] -- which IS the upper set of row r + 1, so a reused horizontal pass stays where it is (it used to be
-            // copied, four register moves per reuse, three reuses in four rows)
-            unsigned hh[2][4];
-#pragma unroll
-            for (int r = 0; r < RG; r++) {
-                const unsigned lr = g * RG + r;
-                unsigned (&hA)[4] = hh[r & 1];
-                unsigned (&hB)[4] = hh[(r + 1) & 1];
-                if (r == 0 || e[r].x != e[r - 1].y) hrow(e[r].x, hA);
-                hrow(e[r].y, hB);
-                unsigned out = 0;
-#pragma unroll
-                for (int j = 0; j < 4; j++) out |= ((__umulhi(hA[j], e[r].z) + __umulhi(hB[j], e[r].w) + 2) >> 2) << (8 * j);
-                if (lr < (unsigned)nM) {
-                    *reinterpret_cast<uint32_t*>(dst + (lr * dpitch + x4 * 4)) = out;
-                    if (keep) *reinterpret_cast<uint32_t*>(keepL + (lr * kpitch + x4 * 4)) = out;
-                }
-            }
-            if constexpr (!XL) { q0 = n0; q1 = n1; q2 = n2; g = gN; x4 = x4N; }
-        }
+        pyr_chain_step<RG, XL>(C, k, bt, slab, lds, xqAll, tid, [] {});
         __syncthreads();
         PYR_STAMP(3 + k);
+    }
+#undef PYR_STAMP
+}
+
+// ------------------------------------------------------------------------------------------------
+// The batch form of k_pyr_chain (round 5): PERSISTENT workgroups, one per resident slot, that walk the (frame, band) units
+// u = blockIdx.x, + gridDim.x, ... and hold the NEXT unit's source chunks (and its row-table entry) in registers, requested
+// at the start of the current unit's first level: the stamps of k_pyr_chain showed a workgroup waiting 3-4 of its 10-14 us
+// for the one round trip of its staging loads, five workgroups per CU notwithstanding.  Here that round trip runs under the
+// resampling of the unit before.  The compute phase keeps its own loads out of the way of the prefetch: column entries are
+// either in LDS (XL: copied once per workgroup, not once per band) or requested one item ahead -- the first before the
+// prefetch (older: waited for alone), the later ones when the prefetch has long arrived.  NPF = 16-byte chunks per thread
+// (the host picks it from the chain's largest band; chains whose bands need more than 8 use k_pyr_chain).
+template <int RG, bool XL, int NPF>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_pyr_chain_p(const OrbPyrChain C, const uint8_t* __restrict__ img, size_t rowStride,
+                                                     size_t frameStride, uint8_t* __restrict__ pyr, size_t pyrSlab,
+                                                     const uint4* __restrict__ xqAll, const int2* __restrict__ ytAll,
+                                                     const int2* __restrict__ bandTab, int* __restrict__ clr, int clrInts,
+                                                     const char4* __restrict__ pat8, float4* __restrict__ patF,
+                                                     unsigned long long* __restrict__ stamps, int nUnits, unsigned invBands)
+{
+    extern __shared__ uint32_t ldsDw[];
+    uint8_t* lds = reinterpret_cast<uint8_t*>(ldsDw);
+    const int tid = threadIdx.x;
+    if (clr) {                                                     // first kernel of the batch (see k_copy_level0)
+        for (unsigned g = blockIdx.x * 256u + (unsigned)tid; g < (unsigned)clrInts; g += gridDim.x * 256u) clr[g] = 0;
+        const unsigned g = blockIdx.x * 256u + (unsigned)tid;
+        if (g < 256u) {
+            const char4 q = pat8[g];
+            patF[g] = make_float4((float)q.x, (float)q.z, (float)q.y, (float)q.w);   // {x0, x1, y0, y1} (orb_desc.hip)
+        }
+    }
+    if constexpr (XL) {                                            // the chain's column tables: once per workgroup
+        const orb_u32x4* xg = reinterpret_cast<const orb_u32x4*>(xqAll + C.st[0].xqOff);
+        orb_u32x4 xv[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) xv[i] = xg[min(tid + 256 * i, C.xqLdsN - 1)];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (tid + 256 * i < C.xqLdsN) *reinterpret_cast<orb_u32x4*>(lds + C.xqLdsOff + 16 * (tid + 256 * i)) = xv[i];
+    }
+    const int w = C.srcW, cpr = C.cpr;
+    const bool canPart = C.copy0 && (w & 15) != 0;                 // (w >= 16: the host sends narrower sources to k_pyr_chain)
+    const int rpK = __builtin_amdgcn_readfirstlane(tid >> 6), rpT = tid & 63;
+    struct Unit { int f, b; const int2* bt; int2 sr; };
+    auto unit = [&](int u) {
+        Unit U;
+        U.f = invBands ? (int)__umulhi((unsigned)u, invBands) : u;
+        U.b = u - U.f * C.bands;
+        U.bt = bandTab + C.tabOff + U.b * (C.nSteps + 2);
+        U.sr = U.bt[0];
+        return U;
+    };
+    auto chunk = [&](int idx, int& r, int& c) { r = C.invCpr ? (int)__umulhi((unsigned)idx, C.invCpr) : idx; c = idx - r * cpr; };
+    // what a unit's staging needs from memory: NPF chunks and one row-table entry per thread, all requested at once
+    orb_u32x4 v[NPF];
+    int2 rpTy = make_int2(0, 0);
+    auto request = [&](int u) {
+        const Unit U = unit(u);
+        if (rpK < C.nSteps) {
+            const int2 mr = U.bt[1 + rpK];
+            const int n4 = (mr.y - mr.x + 4) & ~3;
+            rpTy = ytAll[C.st[rpK].ytOff + min(mr.x + min(rpT, n4 - 1), mr.y)];
+        }
+        const int total = (U.sr.y - U.sr.x + 1) * cpr;
+        const uint8_t* src;
+        size_t stride;
+        if (C.copy0) { src = img + (size_t)U.f * frameStride + (size_t)U.sr.x * rowStride; stride = rowStride; }
+        else { src = pyr + (size_t)U.f * pyrSlab + C.srcOff + (size_t)U.sr.x * C.srcPitch; stride = (size_t)C.srcPitch; }
+#pragma unroll
+        for (int i = 0; i < NPF; i++) {                            // unconditional, clamped (see k_pyr_chain)
+            int r, c;
+            chunk(min(i * 256 + tid, total - 1), r, c);
+            const bool part = canPart && 16 * c + 16 > w;
+            v[i] = *reinterpret_cast<const orb_u32x4_a1*>(src + (size_t)r * stride + (part ? w - 16 : 16 * c));
+        }
+    };
+#define PYR_STAMP(k) do { if (stamps && tid == 0) stamps[(size_t)u * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    int u = blockIdx.x;
+    request(u);
+    for (;;) {
+        PYR_STAMP(0);
+        const Unit U = unit(u);
+        uint8_t* slab = pyr + (size_t)U.f * pyrSlab;
+        // ---- the unit's source rows, out of the registers: LDS (and the level-0 rows this band owns)
+        {
+            const int total = (U.sr.y - U.sr.x + 1) * cpr;
+            const int2 cp = U.bt[C.nSteps + 1];
+            const int pitchB = 4 * C.srcLdsPitchDw;
+            uint8_t* dstL = lds + C.srcLdsOff;
+            uint8_t* l0 = slab + C.srcOff + (size_t)U.sr.x * C.srcPitch;
+#pragma unroll
+            for (int i = 0; i < NPF; i++) {
+                const int idx = i * 256 + tid;
+                int r, c;
+                chunk(min(idx, total - 1), r, c);
+                orb_u32x4 o = v[i];
+                if (canPart) {                                     // a partial last chunk was read as the row's last 16 bytes (k_pyr_chain)
+                    const int k = 16 - (w - 16 * c), dw = k >> 2;
+                    const unsigned sh = (unsigned)k & 3u;
+                    const unsigned t0 = o.x, t1 = o.y, t2 = o.z, t3 = o.w;
+                    const unsigned a0 = dw == 0 ? t0 : dw == 1 ? t1 : dw == 2 ? t2 : t3;
+                    const unsigned a1 = dw == 0 ? t1 : dw == 1 ? t2 : dw == 2 ? t3 : 0u;
+                    const unsigned a2 = dw == 0 ? t2 : dw == 1 ? t3 : 0u;
+                    const unsigned a3 = dw == 0 ? t3 : 0u;
+                    const bool part = k > 0;
+                    o.x = part ? __builtin_amdgcn_alignbyte(a1, a0, sh) : t0;
+                    o.y = part ? __builtin_amdgcn_alignbyte(a2, a1, sh) : t1;
+                    o.z = part ? __builtin_amdgcn_alignbyte(a3, a2, sh) : t2;
+                    o.w = part ? __builtin_amdgcn_alignbyte(0u, a3, sh) : t3;
+                }
+                if (idx < total) {
+                    *reinterpret_cast<orb_u32x4*>(dstL + r * pitchB + 16 * c) = o;
+                    if (C.copy0 && (unsigned)(U.sr.x + r - cp.x) < (unsigned)(cp.y - cp.x))
+                        *reinterpret_cast<orb_u32x4*>(l0 + (size_t)r * C.srcPitch + 16 * c) = o;   // (row padding up to the pitch gets zeros)
+                }
+            }
+        }
+        if (rpK < C.nSteps) {                                      // row parameters: wave k fills those of step k (k_pyr_chain)
+            const int k = rpK;
+            const int2 mr = U.bt[1 + k];
+            const int n4 = (mr.y - mr.x + 4) & ~3;
+            if (rpT < n4) {
+                const int srcRow0 = U.bt[k].x;
+                const int pitchB = 4 * (k == 0 ? C.srcLdsPitchDw : C.st[k - 1].ldsPitchDw);
+                const int base = k == 0 ? C.srcLdsOff : C.st[k - 1].ldsOff;
+                uint4 e;
+                e.x = (unsigned)(base + ((rpTy.x & 0xffff) - srcRow0) * pitchB);
+                e.y = (unsigned)(base + ((int)((unsigned)rpTy.x >> 16) - srcRow0) * pitchB);
+                e.z = (unsigned)rpTy.y << 16;
+                e.w = (unsigned)rpTy.y & 0xffff0000u;
+                *reinterpret_cast<uint4*>(lds + C.st[k].rpOff + 16 * rpT) = e;
+            }
+        }
+        PYR_STAMP(1);
+        __syncthreads();
+        PYR_STAMP(2);
+        // ---- the next unit's requests go out under this unit's first level (the last unit asks for itself again: a branch
+        // around the loads would make the registers conditional, and conditional loads are waited for one by one)
+        const int uNext = u + (int)gridDim.x;
+        const bool more = uNext < nUnits;
+        const int uReq = more ? uNext : u;
+        pyr_chain_step<RG, XL>(C, 0, U.bt, slab, lds, xqAll, tid, [&] { request(uReq); });
+        __syncthreads();
+        PYR_STAMP(3);
+        for (int k = 1; k < C.nSteps; k++) {
+            pyr_chain_step<RG, XL>(C, k, U.bt, slab, lds, xqAll, tid, [] {});
+            __syncthreads();
+            PYR_STAMP(3 + k);
+        }
+        if (!more) break;
+        u = uNext;
     }
 #undef PYR_STAMP
 }
@@ -577,16 +743,68 @@ void orb_launch_resize(hipStream_t st, uint8_t* pyr, size_t pyrSlab, const OrbLe
                            dst.pyrOff, dst.pitch, dst.w, dst.h, xtab, ytab);
 }
 
-void orb_launch_pyr_chain(hipStream_t st, const OrbPyrChain& C, const uint8_t* img, size_t rowStride, size_t frameStride,
+// resident workgroups of a persistent kernel on the current device (occupancy x CUs), remembered per (device, kernel, LDS)
+static int pyr_resident_slots(const void* kern, size_t ldsBytes)
+{
+    static std::mutex mu;
+    static std::map<std::tuple<int, const void*, size_t>, int> memo;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    std::lock_guard<std::mutex> lock(mu);
+    const auto key = std::make_tuple(dev, kern, ldsBytes);
+    auto it = memo.find(key);
+    if (it != memo.end()) return it->second;
+    int occ = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 256, ldsBytes) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); occ = 0; }
+    const int slots = occ > 0 && cus > 0 ? occ * cus : 0;
+    memo[key] = slots;
+    return slots;
+}
+
+// persist: the batch form (k_pyr_chain_p) where the chain allows it -- the caller offers it for batches that fill the chip
+// several times over, ORB_PYR_PERSIST=1 takes the offer.  OFF by default: it hides the staging round trip as designed and the
+// launches take as long as before (profiles/r05_pyr_persistent_attempt.txt).  Returns true when the
+// persistent form was launched.
+bool orb_launch_pyr_chain(hipStream_t st, const OrbPyrChain& C, const uint8_t* img, size_t rowStride, size_t frameStride,
                           uint8_t* pyr, size_t pyrSlab, const uint4* xqAll, const int2* ytAll, const int2* bandTab, int nFrames,
-                          int* clr, int clrInts, const int8_t* pat8, float* patF, unsigned long long* stamps)
+                          int* clr, int clrInts, const int8_t* pat8, float* patF, unsigned long long* stamps, bool persist)
 {
     static const int rg = std::getenv("ORB_PYR_RG") ? std::atoi(std::getenv("ORB_PYR_RG")) : 4;
     // ORB_PYR_LDSMIN=<KB> (tuning): claim at least that much LDS per workgroup, i.e. FEWER workgroups of this latency-bound kernel
     // per CU, so that other lanes' kernels find LDS and wave slots beside it
     static const size_t ldsMin = std::getenv("ORB_PYR_LDSMIN") ? (size_t)std::max(0, std::min(64, std::atoi(std::getenv("ORB_PYR_LDSMIN")))) * 1024 : 0;
+    // (read per launch, not once: the tests switch them within one process)
+    const char* envP = std::getenv("ORB_PYR_PERSIST");
+    const bool persistOn = envP && std::atoi(envP) != 0;
+    // ORB_PYR_SLOTS=<percent> (tuning, tests): persistent workgroups as a share of the resident slots
+    const char* envS = std::getenv("ORB_PYR_SLOTS");
+    const bool debug = std::getenv("ORB_PYR_DEBUG") != nullptr;
+    const int slotPct = envS ? std::max(10, std::min(400, std::atoi(envS))) : 100;
+    const size_t ldsBytes = std::max((size_t)C.ldsBytes, ldsMin);
+    const long long nUnits = (long long)C.bands * nFrames;
+    const long long chunks = (long long)C.srcRowsMax * C.cpr;
+    if (persist && persistOn && rg == 4 && C.srcW >= 16 && chunks <= 256 * PYR_STAGE_MAX && nUnits * C.bands < (1ll << 32) && nUnits < (1ll << 31)) {
+        const unsigned invBands = C.bands <= 1 ? 0u : (unsigned)(((1ull << 32) + C.bands - 1) / C.bands);
+        auto gop = [&](auto kern) -> bool {
+            const int slots = pyr_resident_slots(reinterpret_cast<const void*>(kern), ldsBytes);
+            if (slots <= 0) return false;
+            if (debug) std::fprintf(stderr, "[orb] k_pyr_chain_p: %d bands x %d frames, %lld chunks per band, LDS %zu, %d resident slots\n", C.bands, nFrames, chunks, ldsBytes, slots);
+            const long long want = std::max(1ll, (long long)slots * slotPct / 100);
+            if (nUnits < 2 * want) return false;                   // (nothing to prefetch for: the plain form)
+            hipLaunchKernelGGL(kern, dim3((unsigned)want), dim3(256), ldsBytes, st, C, img, rowStride, frameStride, pyr, pyrSlab, xqAll,
+                               ytAll, bandTab, clr, clrInts, reinterpret_cast<const char4*>(pat8), reinterpret_cast<float4*>(patF),
+                               stamps, (int)nUnits, invBands);
+            return true;
+        };
+        const int npf = (int)((chunks + 255) / 256);
+        bool done;
+        if (C.xqLdsN > 0) done = npf <= 2 ? gop(k_pyr_chain_p<4, true, 2>) : npf <= 4 ? gop(k_pyr_chain_p<4, true, 4>) : npf <= 6 ? gop(k_pyr_chain_p<4, true, 6>) : gop(k_pyr_chain_p<4, true, 8>);
+        else done = npf <= 2 ? gop(k_pyr_chain_p<4, false, 2>) : npf <= 3 ? gop(k_pyr_chain_p<4, false, 3>) : npf <= 4 ? gop(k_pyr_chain_p<4, false, 4>) : npf <= 6 ? gop(k_pyr_chain_p<4, false, 6>) : gop(k_pyr_chain_p<4, false, 8>);
+        if (done) return true;
+    }
     auto go = [&](auto kern) {
-        hipLaunchKernelGGL(kern, dim3(C.bands, nFrames), dim3(256), std::max((size_t)C.ldsBytes, ldsMin), st, C, img, rowStride, frameStride, pyr,
+        hipLaunchKernelGGL(kern, dim3(C.bands, nFrames), dim3(256), ldsBytes, st, C, img, rowStride, frameStride, pyr,
                            pyrSlab, xqAll, ytAll, bandTab, clr, clrInts, reinterpret_cast<const char4*>(pat8),
                            reinterpret_cast<float4*>(patF), stamps);
     };
@@ -598,6 +816,7 @@ void orb_launch_pyr_chain(hipStream_t st, const OrbPyrChain& C, const uint8_t* i
     else if (rg == 1) go(k_pyr_chain<1, false>);
     else if (rg == 2) go(k_pyr_chain<2, false>);
     else go(k_pyr_chain<4, false>);
+    return false;
 }
 
 // Levels M and M+1 in one launch (k_resize_pair); returns false when the pair is not eligible (the caller then

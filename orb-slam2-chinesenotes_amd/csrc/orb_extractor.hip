@@ -491,14 +491,16 @@ extern "C" int orb_extract_batch_device(orb_extractor* h, const uint8_t* d_imgs,
                                                      //  40 / 64 / 96 frames: batch 0.049 / 0.061 / 0.071, few 0.051 / 0.069 / 0.093)
         const std::vector<OrbPyrChain>& chains = which == 2 ? h->pyrChainsOne : which == 1 ? h->pyrChainsLat : h->pyrChains;
         size_t stampOff = 0;                                   // diagnostics: 8 words per workgroup, launch after launch
+        int persistent = 0;
         for (size_t c = 0; c < chains.size(); c++) {
             const size_t words = (size_t)chains[c].bands * n * 8;
             unsigned long long* stp = h->pyrStamps && stampOff + words <= h->pyrStampCap ? h->pyrStamps + stampOff : nullptr;
             stampOff += words;
-            orb_launch_pyr_chain(st, chains[c], d_imgs, rowStride, frameStride, pyr, h->pyrSlab, (const uint4*)h->dXq.p,
+            persistent += orb_launch_pyr_chain(st, chains[c], d_imgs, rowStride, frameStride, pyr, h->pyrSlab, (const uint4*)h->dXq.p,
                                  (const int2*)h->dYtab.p, (const int2*)h->dBand.p, n, c == 0 ? h->errP() : nullptr,
-                                 (int)orb_extractor::batchInts(n), h->patternPtr, (float*)h->dPatternF.p, stp);
+                                 (int)orb_extractor::batchInts(n), h->patternPtr, (float*)h->dPatternF.p, stp, which == 0) ? 1 : 0;
         }
+        h->pyrPersistent = persistent;
         h->pyrStampChains = (int)chains.size();
         for (size_t c = 0; c < chains.size() && c < 8; c++) { h->pyrStampBands[c] = chains[c].bands; h->pyrStampSteps[c] = chains[c].nSteps; }
     } else {
@@ -947,6 +949,13 @@ extern "C" int orb_extractor_pyr_stamp_layout(const orb_extractor* h, int32_t* n
         if (bands8) bands8[c] = c < h->pyrStampChains ? h->pyrStampBands[c] : 0;
         if (steps8) steps8[c] = c < h->pyrStampChains ? h->pyrStampSteps[c] : 0;
     }
+    return ORB_OK;
+}
+
+extern "C" int orb_extractor_pyr_persistent(const orb_extractor* h, int32_t* launches)
+{
+    if (!h || !launches) return ORB_ERR_INVALID;
+    *launches = h->pyrPersistent;
     return ORB_OK;
 }
 

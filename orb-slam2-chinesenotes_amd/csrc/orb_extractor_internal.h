@@ -50,6 +50,7 @@ struct orb_extractor {
     int rows = 0, cols = 0;
     int lastGeomRows = 0, lastGeomCols = 0;     // size of the last successful geometry build (survives a failed one)
     OrbGeom G;
+    int pyrPersistent = 0;                      // launches of the last batch's pyramid that took the persistent form (k_pyr_chain_p)
     unsigned long long* pyrStamps = nullptr;    // diagnostics: phase stamps of the k_pyr_chain launches (orb_extractor_set_pyr_stamps)
     size_t pyrStampCap = 0;
     int pyrStampChains = 0, pyrStampBands[8] = {}, pyrStampSteps[8] = {};

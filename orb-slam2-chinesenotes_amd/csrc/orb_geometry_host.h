@@ -244,6 +244,7 @@ static bool plan_pyr_chain(const OrbGeom& G, const std::vector<int2>& yt, const 
     const size_t rowParamBytes = off;
     C.srcLdsPitchDw = align_up((S.w + 3) / 4 + 2, 4);
     C.cpr = (S.w + 15) / 16;
+    C.srcRowsMax = maxRows[0];
     C.invCpr = C.cpr <= 1 ? 0u : (unsigned)(((1ull << 32) + C.cpr - 1) / C.cpr);
     for (int k = 0; k <= nSteps; k++)
         if (maxRows[k] + 3 > 64 || (long long)maxRows[0] * C.cpr * C.cpr >= (1ll << 32)) { tab.resize(tab0); return false; }   // one wave fills a step's row parameters

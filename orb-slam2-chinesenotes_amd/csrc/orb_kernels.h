@@ -9,9 +9,9 @@ bool orb_launch_resize_pair(hipStream_t st, uint8_t* pyr, size_t pyrSlab, const 
                             int nFrames);
 void orb_launch_resize(hipStream_t st, uint8_t* pyr, size_t pyrSlab, const OrbLevelGeom& src,
                        const OrbLevelGeom& dst, const int2* xtab, const int2* ytab, const uint4* xq, int nFrames);
-void orb_launch_pyr_chain(hipStream_t st, const OrbPyrChain& C, const uint8_t* img, size_t rowStride, size_t frameStride,
+bool orb_launch_pyr_chain(hipStream_t st, const OrbPyrChain& C, const uint8_t* img, size_t rowStride, size_t frameStride,
                           uint8_t* pyr, size_t pyrSlab, const uint4* xqAll, const int2* ytAll, const int2* bandTab, int nFrames,
-                          int* clr, int clrInts, const int8_t* pat8, float* patF, unsigned long long* stamps = nullptr);
+                          int* clr, int clrInts, const int8_t* pat8, float* patF, unsigned long long* stamps = nullptr, bool persist = false);
 size_t orb_fast_lds_bytes(int pdw, int rowsMax, int candCap);
 size_t orb_fast_dense_lds_bytes(int pdw, int rowsMax, int sdw);
 void orb_launch_fast_strips(hipStream_t st, const OrbGeom& G, const uint8_t* pyr, size_t pyrSlab,

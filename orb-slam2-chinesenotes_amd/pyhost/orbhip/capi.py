@@ -59,7 +59,7 @@ _lib = None
 # every symbol include/orb_hip.h declares
 SYMBOLS = [
     "orb_extractor_create", "orb_extractor_destroy", "orb_extractor_get_tables", "orb_extractor_max_keypoints",
-    "orb_extractor_set_pattern", "orb_extractor_set_pattern_device", "orb_extractor_desc_plan", "orb_extractor_set_desc_stamps", "orb_extractor_set_pyr_stamps", "orb_extractor_set_qt_stamps", "orb_extractor_pyr_stamp_layout", "orb_builtin_pattern", "orb_extract",
+    "orb_extractor_set_pattern", "orb_extractor_set_pattern_device", "orb_extractor_desc_plan", "orb_extractor_set_desc_stamps", "orb_extractor_set_pyr_stamps", "orb_extractor_set_qt_stamps", "orb_extractor_pyr_stamp_layout", "orb_extractor_pyr_persistent", "orb_builtin_pattern", "orb_extract",
     "orb_extract_batch", "orb_extract_batch_device", "orb_extractor_sync", "orb_get_pyramid_level",
     "orb_get_level_counts", "orb_get_fast_overflows", "orb_get_pyramid", "orb_host_alloc", "orb_host_free", "orb_extractor_set_profiling", "orb_extractor_get_stage_ms", "orb_extractor_profiled_frames", "orb_extractor_stream",
     "orb_hamming", "orb_three_maxima", "orb_matcher_create", "orb_matcher_destroy", "orb_matcher_sync",
@@ -98,6 +98,7 @@ def lib():
     L.orb_extractor_set_pyr_stamps.argtypes = [vp, vp, sz]
     L.orb_extractor_set_qt_stamps.argtypes = [vp, vp, sz]
     L.orb_extractor_pyr_stamp_layout.argtypes = [vp, vp, vp, vp]
+    L.orb_extractor_pyr_persistent.argtypes = [vp, vp]
     L.orb_builtin_pattern.argtypes = [vp]
     L.orb_extract.argtypes = [vp, vp, ci, ci, sz, vp, vp, ci, C.POINTER(ci)]
     L.orb_extract_batch.argtypes = [vp, vp, ci, ci, ci, sz, sz, vp, vp, ci, vp]
@@ -330,6 +331,12 @@ class Extractor:
         bands, steps = np.zeros(8, np.int32), np.zeros(8, np.int32)
         _check(self.L.orb_extractor_pyr_stamp_layout(self.h, C.byref(n), _p(bands), _p(steps)))
         return [(int(bands[i]), int(steps[i])) for i in range(n.value)]
+
+    def pyr_persistent(self):
+        """Pyramid launches of the last batch that took the persistent form (orb_extractor_pyr_persistent)."""
+        n = C.c_int32()
+        _check(self.L.orb_extractor_pyr_persistent(self.h, C.byref(n)))
+        return n.value
 
     def desc_plan(self):
         """(first level that runs level-resident, number of regions) of the current geometry (orb_extractor_desc_plan)."""

@@ -27,7 +27,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 N_SIMD, N_XCD = 1024, 8
 # load width (bytes per lane) of each kernel's dominant global reads -> which calibration factor applies
-LOAD_WIDTH = {"k_copy_level0": 16, "k_fast_strips": 16, "k_fast_strips_p": 16, "k_pyr_chain": 16, "k_resize_pair": 8, "k_resize_level4p": 8, "k_orient_desc": "rows48_dword",
+LOAD_WIDTH = {"k_copy_level0": 16, "k_fast_strips": 16, "k_fast_strips_p": 16, "k_pyr_chain": 16, "k_pyr_chain_p": 16, "k_resize_pair": 8, "k_resize_level4p": 8, "k_orient_desc": "rows48_dword",
               "k_quadtree": 8, "k_match_bow": 16, "k_match_bow_store": 16, "k_bow_assign": 16, "k_vocab_transform": 16, "k_fill_sides": 4}
 
 
