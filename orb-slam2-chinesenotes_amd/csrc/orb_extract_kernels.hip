@@ -774,12 +774,13 @@ bool orb_launch_pyr_chain(hipStream_t st, const OrbPyrChain& C, const uint8_t* i
     // ORB_PYR_LDSMIN=<KB> (tuning): claim at least that much LDS per workgroup, i.e. FEWER workgroups of this latency-bound kernel
     // per CU, so that other lanes' kernels find LDS and wave slots beside it
     static const size_t ldsMin = std::getenv("ORB_PYR_LDSMIN") ? (size_t)std::max(0, std::min(64, std::atoi(std::getenv("ORB_PYR_LDSMIN")))) * 1024 : 0;
-    // (read per launch, not once: the tests switch them within one process)
-    const char* envP = std::getenv("ORB_PYR_PERSIST");
+    // (read per OFFERED launch, not once: the tests switch them within one process; the few-frame launches never get here --
+    // a getenv is a scan of the environment, three of them per launch were 2 us of a single frame's chain)
+    const char* envP = persist ? std::getenv("ORB_PYR_PERSIST") : nullptr;
     const bool persistOn = envP && std::atoi(envP) != 0;
     // ORB_PYR_SLOTS=<percent> (tuning, tests): persistent workgroups as a share of the resident slots
-    const char* envS = std::getenv("ORB_PYR_SLOTS");
-    const bool debug = std::getenv("ORB_PYR_DEBUG") != nullptr;
+    const char* envS = persistOn ? std::getenv("ORB_PYR_SLOTS") : nullptr;
+    const bool debug = persistOn && std::getenv("ORB_PYR_DEBUG") != nullptr;
     const int slotPct = envS ? std::max(10, std::min(400, std::atoi(envS))) : 100;
     const size_t ldsBytes = std::max((size_t)C.ldsBytes, ldsMin);
     const long long nUnits = (long long)C.bands * nFrames;

@@ -533,14 +533,17 @@ extern "C" int orb_extract_batch_device(orb_extractor* h, const uint8_t* d_imgs,
     // Batches: the upper pyramid levels go through the level-resident kernel (one staging + one blur per level region, the
     // angle arithmetic once per 64 keypoints; orb_desc_level.hip), the lower ones -- whose patches hardly overlap -- keep a
     // wave per keypoint.  A few frames: every keypoint its own wave (a level's workgroup would be the latency of the call).
-    const char* lmfEnv = std::getenv("ORB_DESC_LEVEL_MIN_FRAMES");
+    // (the knobs are read only where a plan exists, i.e. with ORB_DESC_LEVEL=1: a getenv is a scan of the environment, and this
+    // function is a single frame's whole host cost in config 5)
+    const bool havePlan = h->descPlan.nRegions > 0;
+    const char* lmfEnv = havePlan ? std::getenv("ORB_DESC_LEVEL_MIN_FRAMES") : nullptr;
     const int levelMinFrames = lmfEnv ? std::atoi(lmfEnv) : 24;
-    const bool useLevel = h->descPlan.nRegions > 0 && n >= levelMinFrames;
+    const bool useLevel = havePlan && n >= levelMinFrames;
     // The two kernels are independent (disjoint keypoint slots).  ORB_DESC_LEVEL_SIDE=1 runs the level-resident one on a side
     // stream BESIDE the per-keypoint one (the idea: single-wave workgroups of k_orient_desc fill the issue cycles that staging
     // and barriers leave) -- measured slower than one after the other (0.412 against 0.396 ms per 512 frames: the level kernel's
     // workgroups hold half a CU's LDS each and keep the other kernel's waves OUT), so it is off.
-    const char* sideEnv = std::getenv("ORB_DESC_LEVEL_SIDE");
+    const char* sideEnv = useLevel ? std::getenv("ORB_DESC_LEVEL_SIDE") : nullptr;
     const bool wantSide = useLevel && n >= 24 && sideEnv && std::atoi(sideEnv) != 0;
     if (wantSide && !h->sideStream) {
         // created on first use only: HIP deals streams round-robin over a few hardware queues, and a stream that exists but is
