@@ -828,6 +828,8 @@ def run_c5(args, rank, local_rank, world, dev, comm_dev, dist):
     src/Tracking.cc:1471-1492, is the batch axis); the extractor stream runs ahead of the matcher stream over a ring of
     NSLOT query slots (per-slot events: match(i) waits for extract(i), extract(i) for match(i - NSLOT))."""
     W, H, n_kf = 752, 480, 1000
+    if os.environ.get("ORB_BENCH_C5_KF"):                      # experiments only (tools/experiments/c5_host_bound.sh): NOT BASELINE's configs[4]
+        n_kf = max(8, int(os.environ["ORB_BENCH_C5_KF"])) // 8 * 8
     ex, mt = capi.Extractor(args.nfeatures, device=local_rank), capi.Matcher(0.7, True, device=local_rank)
     cap = ex.max_keypoints
     QMAX = 8                                                      # stream frames per step in the mini-batch variant
@@ -999,6 +1001,8 @@ def run_c5(args, rank, local_rank, world, dev, comm_dev, dist):
 
     py_elapsed, py_submit = timed(run)
     elapsed, t_submit = timed(run_c) if c_loop is not None else (py_elapsed, py_submit)
+    if c_loop is not None and os.environ.get("C5_LOOP_TIMING"):
+        c_loop.c5_loop_report()                    # (stderr: the host's time per call site of the C loop)
     done = shard.sum_over_ranks(dist, args.steps, comm_dev)
     # the same stream in mini-batches of QMAX frames per step (offline sequence processing): throughput, not `value`
     mini_fps = 0.0

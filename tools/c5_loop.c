@@ -12,6 +12,7 @@
 #define __HIP_PLATFORM_AMD__ 1
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <time.h>
 
@@ -44,8 +45,24 @@ typedef struct c5_loop_args {
 } c5_loop_args;
 
 /* steps i0 .. i0 + n - 1 (+ the extraction of frame i0 + n, as bench.py's run()); *submit_s = host time of the loop */
+/* C5_LOOP_TIMING=1: where the host's time goes, per call site (printed by c5_loop_report) */
+static double g_t[4];          /* extract, event waits, query, event records */
+static long g_steps;
+static int g_timing = -1;
+#define TIMED(k, call) do { if (g_timing) { const double t_ = now_s(); call; g_t[k] += now_s() - t_; } else { call; } } while (0)
+
+void c5_loop_report(void)
+{
+    if (g_timing > 0 && g_steps > 0)
+        fprintf(stderr, "[c5_loop] host us per frame over %ld frames: extract call %.2f, stream waits %.2f, query call %.2f, event records %.2f\n",
+                g_steps, 1e6 * g_t[0] / g_steps, 1e6 * g_t[1] / g_steps, 1e6 * g_t[2] / g_steps, 1e6 * g_t[3] / g_steps);
+    g_t[0] = g_t[1] = g_t[2] = g_t[3] = 0.0;
+    g_steps = 0;
+}
+
 int c5_loop_run(const c5_loop_args* A, int i0, int n, double* submit_s)
 {
+    if (g_timing < 0) g_timing = getenv("C5_LOOP_TIMING") != NULL;
     static hipEvent_t evEx[MAX_SLOTS], evMt[MAX_SLOTS];
     static int haveEvents = 0;
     if (A->n_slots > MAX_SLOTS || A->n_slots < 2 || A->n_ex < 1 || A->n_mt < 1) return ORB_ERR_INVALID;
@@ -63,26 +80,34 @@ int c5_loop_run(const c5_loop_args* A, int i0, int n, double* submit_s)
     do {                                                                                                                        \
         const int s_ = (i) % A->n_slots;                                                                                        \
         const size_t f0_ = (size_t)A->n_kf + (size_t)s_ * A->slot_stride;                                                       \
-        rc = orb_extract_batch_device(A->ex[(i) % A->n_ex], A->d_stream + (size_t)((i) % A->n_stream) * frameB, 1, A->rows, A->cols,  \
+        TIMED(0, rc = orb_extract_batch_device(A->ex[(i) % A->n_ex], A->d_stream + (size_t)((i) % A->n_stream) * frameB, 1, A->rows, A->cols,  \
                                       (size_t)A->cols, frameB, A->d_kps + f0_ * A->cap, A->d_desc + f0_ * A->cap * 32, A->cap,  \
-                                      A->d_counts + f0_);                                                                       \
+                                      A->d_counts + f0_));                                                                      \
         if (rc != ORB_OK) return rc;                                                                                            \
-        if (hipEventRecord(evEx[s_], (hipStream_t)orb_extractor_stream(A->ex[(i) % A->n_ex])) != hipSuccess) return ORB_ERR_HIP; \
+        hipError_t e_;                                                                                                          \
+        TIMED(3, e_ = hipEventRecord(evEx[s_], (hipStream_t)orb_extractor_stream(A->ex[(i) % A->n_ex])));                       \
+        if (e_ != hipSuccess) return ORB_ERR_HIP;                                                                               \
     } while (0)
     EXTRACT(i0);
     for (int i = i0; i < i0 + n; i++) {
         const int j = i + 1;
-        if (j - A->n_slots >= i0)       /* the search that last used the slot has let go of it */
-            if (hipStreamWaitEvent((hipStream_t)orb_extractor_stream(A->ex[j % A->n_ex]), evMt[j % A->n_slots], 0) != hipSuccess) return ORB_ERR_HIP;
+        hipError_t e;
+        if (j - A->n_slots >= i0) {     /* the search that last used the slot has let go of it */
+            TIMED(1, e = hipStreamWaitEvent((hipStream_t)orb_extractor_stream(A->ex[j % A->n_ex]), evMt[j % A->n_slots], 0));
+            if (e != hipSuccess) return ORB_ERR_HIP;
+        }
         EXTRACT(j);
         const int s = i % A->n_slots;
         orb_matcher* m = A->mt[i % A->n_mt];
         hipStream_t ms = (hipStream_t)orb_matcher_stream(m);
-        if (hipStreamWaitEvent(ms, evEx[s], 0) != hipSuccess) return ORB_ERR_HIP;
-        rc = orb_bow_query_frames_device(m, A->voc, A->store, A->n_kf + s * A->slot_stride, 1, A->levelsup, A->d_kf_index, A->n_kf,
-                                         A->d_f_index[s], A->ratio, A->check_ori, A->d_match[s], A->d_nmatches[s]);
+        TIMED(1, e = hipStreamWaitEvent(ms, evEx[s], 0));
+        if (e != hipSuccess) return ORB_ERR_HIP;
+        TIMED(2, rc = orb_bow_query_frames_device(m, A->voc, A->store, A->n_kf + s * A->slot_stride, 1, A->levelsup, A->d_kf_index, A->n_kf,
+                                         A->d_f_index[s], A->ratio, A->check_ori, A->d_match[s], A->d_nmatches[s]));
         if (rc != ORB_OK) return rc;
-        if (hipEventRecord(evMt[s], ms) != hipSuccess) return ORB_ERR_HIP;
+        TIMED(3, e = hipEventRecord(evMt[s], ms));
+        if (e != hipSuccess) return ORB_ERR_HIP;
+        g_steps++;
     }
 #undef EXTRACT
     if (submit_s) *submit_s = now_s() - t0;
