@@ -19,7 +19,7 @@ struct orb_vocab {
     // are consecutive slots in their stored order (what "first minimum wins" iterates over) and one level of a descent
     // reads ONE contiguous run of k x 32 bytes instead of k scattered 32-byte rows (ids come from file order in DBoW2).
     MBuf slotDesc;          // [nNodes][32]
-    MBuf slotKids;          // int2 per slot: {first child slot, number of children}
+    MBuf slotKids;          // int2 per slot: {first child slot, number of children | ORB_VOCAB_LEAFKIDS when every child is a leaf}
     MBuf slotNode;          // int32 per slot: the caller's node id
     MBuf slotWord;          // int32 per slot: word id of the slot's node (one load at the end of a descent, not two)
     std::vector<int> depth;                         // host: depth of every node
@@ -30,6 +30,10 @@ struct orb_vocab {
 };
 
 #include "orb_wave.h"
+
+// bit 30 of a slot's child count: all its children are leaves -- the descent then needs no child record from that level (they
+// are all {0, 0}: in a complete k = 10, L = 6 tree 8 MB of zeros that the last, least cached level of every descent used to fetch)
+#define ORB_VOCAB_LEAFKIDS 0x40000000
 
 // minimum over the 16 lanes of a DPP row, returned in every lane of the row (row_ror 8, 4, 2, 1)
 __device__ __forceinline__ unsigned row16_umin(unsigned v)
@@ -65,6 +69,7 @@ __global__ __launch_bounds__(256) void k_vocab_transform(const uint4* __restrict
     int slot = 0, level = 0;
     int nid = (nidLevel <= 0) ? slotNode[0] : -1, cix = (nidLevel <= 0 && compactOfSlot) ? compactOfSlot[0] : -1;
     int2 kids = slotKids[0];
+    kids.y &= 0xFFFF;
     while (kids.y > 0) {                                          // do { ... } while (!isLeaf())
         ++level;
         unsigned best = 0xFFFFFFFFu;
@@ -82,6 +87,7 @@ __global__ __launch_bounds__(256) void k_vocab_transform(const uint4* __restrict
         }
         slot = kids.x + (int)(best & 0xffffu);
         kids = slotKids[slot];
+        kids.y &= 0xFFFF;
         if (level == nidLevel) {
             nid = slotNode[slot];
             if (compactOfSlot) cix = compactOfSlot[slot];
@@ -139,7 +145,7 @@ __global__ __launch_bounds__(256) void k_vocab_transform_k16(const uint4* __rest
     while (true) {
         bool any = false;
 #pragma unroll
-        for (int j = 0; j < NF; j++) any |= kids[j].y > 0;
+        for (int j = 0; j < NF; j++) any |= (kids[j].y & 0xFFFF) != 0;
         if (!any) break;
         uint4 nl[NF], nh[NF];
         int2 mine[NF];
@@ -148,11 +154,13 @@ __global__ __launch_bounds__(256) void k_vocab_transform_k16(const uint4* __rest
         // global memory -- a per-lane `if (slot < nTop) LDS else global` put loads on both sides of a divergent branch, and the
         // compiler then waited for the loads of one feature before it requested those of the next (round 5, tools/isa_waits.py)
         int s2[NF];
-        bool top = true;
+        bool top = true, leafKids = true;
 #pragma unroll
         for (int j = 0; j < NF; j++) {
-            s2[j] = kids[j].x + min(r, max(kids[j].y - 1, 0));
+            const int cj = kids[j].y & 0xFFFF;
+            s2[j] = kids[j].x + min(r, max(cj - 1, 0));
             top = top && s2[j] < nTop;
+            leafKids = leafKids && (cj == 0 || (kids[j].y & ORB_VOCAB_LEAFKIDS) != 0);
         }
         if (__all(top)) {
 #pragma unroll
@@ -160,6 +168,13 @@ __global__ __launch_bounds__(256) void k_vocab_transform_k16(const uint4* __rest
                 nl[j] = vsm[2 * s2[j]];
                 nh[j] = vsm[2 * s2[j] + 1];
                 mine[j] = kidsL[s2[j]];
+            }
+        } else if (__all(leafKids)) {                              // the last level: the children's records are all {0, 0}, not fetched
+#pragma unroll
+            for (int j = 0; j < NF; j++) {
+                nl[j] = slotDesc[(size_t)s2[j] * 2];
+                nh[j] = slotDesc[(size_t)s2[j] * 2 + 1];
+                mine[j] = make_int2(0, 0);
             }
         } else {
 #pragma unroll
@@ -171,10 +186,11 @@ __global__ __launch_bounds__(256) void k_vocab_transform_k16(const uint4* __rest
         }
 #pragma unroll
         for (int j = 0; j < NF; j++) {
-            const bool active = kids[j].y > 0;
+            const int cj = kids[j].y & 0xFFFF;
+            const bool active = cj > 0;
             const int h = __popc(lo[j].x ^ nl[j].x) + __popc(lo[j].y ^ nl[j].y) + __popc(lo[j].z ^ nl[j].z) + __popc(lo[j].w ^ nl[j].w) +
                           __popc(hi[j].x ^ nh[j].x) + __popc(hi[j].y ^ nh[j].y) + __popc(hi[j].z ^ nh[j].z) + __popc(hi[j].w ^ nh[j].w);
-            const unsigned key = r < kids[j].y ? ((unsigned)h << 16) | (unsigned)r : 0xFFFFFFFFu;   // first minimum wins
+            const unsigned key = r < cj ? ((unsigned)h << 16) | (unsigned)r : 0xFFFFFFFFu;   // first minimum wins
             const int b = (int)(row16_umin(key) & 15u);
             const int nx = __builtin_amdgcn_ds_bpermute((rowBase + b) << 2, mine[j].x);
             const int ny = __builtin_amdgcn_ds_bpermute((rowBase + b) << 2, mine[j].y);
@@ -241,6 +257,13 @@ extern "C" int orb_vocab_create(int device, const uint8_t* node_desc, const int3
         std::memcpy(&sdesc[(size_t)32 * s2], node_desc + (size_t)32 * node, 32);
         sword[s2] = word_id[node];
     }
+    if (!std::getenv("ORB_VOCAB_NO_LEAFFLAG"))
+        for (int s2 = 0; s2 < nSlots; s2++) {                          // ORB_VOCAB_LEAFKIDS: every child of the slot is a leaf
+            const int nc = kids[2 * (size_t)s2 + 1], c0 = kids[2 * (size_t)s2];
+            bool all = nc > 0;
+            for (int r = 0; r < nc && all; r++) all = kids[2 * (size_t)(c0 + r) + 1] == 0;
+            if (all) kids[2 * (size_t)s2 + 1] |= ORB_VOCAB_LEAFKIDS;
+        }
     orb_vocab* v = new (std::nothrow) orb_vocab();
     if (!v) return ORB_ERR_INTERNAL;
     v->device = device; v->nNodes = n_nodes; v->L = L; v->depth = depth; v->slotNodeHost = slotNode;
