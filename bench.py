@@ -1063,6 +1063,7 @@ def run_c5(args, rank, local_rank, world, dev, comm_dev, dist):
                       "transform_plus_match_ms_alone": round(match_ms, 4),
                       "query_slots": NSLOT,
                       "frame_loop": "C (tools/c5_loop.c through ctypes: what a C++ caller of the C ABI submits)" if c_loop is not None else "Python (bench.py)",
+                      "process_cpus": len(os.sched_getaffinity(0)),
                       "host_submit_ms_per_step": round(t_submit / args.steps * 1e3, 4),
                       "python_loop_ms_per_step": round(py_elapsed / args.steps * 1e3, 4),
                       "python_loop_host_submit_ms_per_step": round(py_submit / args.steps * 1e3, 4)},

@@ -17,7 +17,7 @@ step "bench default";  python3 bench.py > "$OUT/bench_default.json" 2> "$OUT/ben
 step "bench b64";      python3 bench.py --frames-per-gpu 64 --no-cpu-baseline --no-natural --no-host-path --steps 400 --warmup 40 > "$OUT/bench_b64.json" 2> "$OUT/bench_b64.err" || exit 1
 step "bench natural";  python3 bench.py --content natural --no-cpu-baseline --no-natural --no-host-path > "$OUT/bench_natural.json" 2> "$OUT/bench_natural.err" || exit 1
 step "bench c3";       python3 bench.py --config c3 > "$OUT/bench_c3.json" 2> "$OUT/bench_c3.err" || { tail -3 "$OUT/bench_c3.err"; exit 1; }
-step "bench c5";       python3 bench.py --config c5 --steps 400 --warmup 40 > "$OUT/bench_c5.json" 2> "$OUT/bench_c5.err" || { tail -3 "$OUT/bench_c5.err"; exit 1; }
+step "bench c5";       python3 bench.py --config c5 --steps 2000 --warmup 200 > "$OUT/bench_c5.json" 2> "$OUT/bench_c5.err" || { tail -3 "$OUT/bench_c5.err"; exit 1; }
 step "bench c5, whole stream"; python3 bench.py --config c5 --steps 3682 --warmup 40 --stream-frames 3682 --no-cpu-baseline --no-live-traffic --c5-no-minibatch > "$OUT/bench_c5_full_stream.json" 2> "$OUT/bench_c5_full_stream.err" || exit 1
 step "kernel table c3"; bash tools/prof_stats.sh ${tag}_c3 --config c3 --no-cpu-baseline --no-live-traffic --steps 20 --warmup 6 > "$OUT/c3_kernel_stats.txt" 2>&1 || exit 1
 step "kernel table c5"; bash tools/prof_stats.sh ${tag}_c5 --config c5 --no-cpu-baseline --no-live-traffic --c5-no-minibatch --steps 200 --warmup 20 > "$OUT/c5_kernel_stats.txt" 2>&1 || exit 1
