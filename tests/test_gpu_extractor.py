@@ -731,6 +731,44 @@ def test_persistent_pyramid_form_level_by_level(monkeypatch, w, h, nf, slots):
     ex.close()
 
 
+def test_persistent_pyramid_form_reads_padded_unaligned_frames(monkeypatch):
+    """The persistent form stages the caller's frames like the plain one: any base alignment, any row stride (a partial last
+    chunk of a row is read as the row's LAST 16 bytes and shifted into place, so nothing outside a row's own bytes is needed --
+    here the bytes behind every row and behind the last frame are poison that would change level 0 if they leaked in)."""
+    import torch
+    monkeypatch.setenv("ORB_PYR_SET", "batch")
+    monkeypatch.setenv("ORB_PYR_PERSIST", "1")
+    monkeypatch.setenv("ORB_PYR_SLOTS", "10")
+    w, h, n, pad, off = 630, 470, 40, 7, 3
+    base = [synth.synth_frame(70, w, h), synth.synth_natural(71, w, h)]
+    stride, fstride = w + pad, (w + pad) * h + 11
+    host = np.full(off + n * fstride, 0xA5, np.uint8)
+    for i in range(n):
+        rows = host[off + i * fstride: off + i * fstride + stride * h].reshape(h, stride)
+        rows[:, :w] = base[i % 2]
+    d = torch.from_numpy(host).cuda()
+    ex = capi.Extractor(800)
+    cap = ex.max_keypoints
+    k = torch.zeros(n * cap * 28, dtype=torch.uint8, device="cuda")
+    de = torch.zeros(n * cap * 32, dtype=torch.uint8, device="cuda")
+    c = torch.zeros(n, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    ex.extract_batch_device(d.data_ptr() + off, n, h, w, stride, fstride, k.data_ptr(), de.data_ptr(), cap, c.data_ptr())
+    ex.sync()
+    assert ex.pyr_persistent() >= 1, "the persistent form did not run"
+    ref = oracle.Extractor(800)
+    want = [ref.extract(im) for im in base]
+    cnt = c.cpu().numpy()
+    kk = k.cpu().numpy().view(capi.KP_DTYPE).reshape(n, cap)
+    dd = de.cpu().numpy().reshape(n, cap, 32)
+    for i in (0, 1, n // 2, n - 2, n - 1):
+        assert np.array_equal(ex.pyramid_level(i, 0), base[i % 2]), i
+    for i in range(n):
+        rk, rd = want[i % 2]
+        assert cnt[i] == len(rk) and kk[i, :len(rk)].tobytes() == rk.tobytes() and np.array_equal(dd[i, :len(rk)], rd), i
+    ex.close()
+
+
 @pytest.mark.parametrize("knob", ["ORB_NO_GRAPH", "ORB_NO_ZEROCOPY", "ORB_NO_SPEC", "ORB_NO_ZEROCOPY+ORB_NO_GRAPH",
                                   "ORB_FAST_MW=0", "ORB_FAST_MW=0+ORB_NO_SPEC"])
 def test_single_frame_path_switches_do_not_change_results(monkeypatch, knob):
